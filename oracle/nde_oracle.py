@@ -1,0 +1,533 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.  **parity unpinned.**
+
+A NumPy restatement (float64 by default) of the reference's NDE column-model hot path: the RHS
+variants, a fixed-step classical RK4 solve, the profile/gradient MSE losses and the *discrete*
+adjoint (back-propagation through the RK4 steps) giving ∂loss/∂weights.
+
+Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import this
+module; the product path (`climateparameterizations.jl_amd`) never does.
+
+"parity unpinned": the reference (pure Julia; OrdinaryDiffEq 5.55.1 / DiffEqSensitivity 6.45.0 /
+Flux 0.11.6 / Zygote 0.6.11 pinned in wind_mixing/Manifest.toml) cannot run in the build container
+(no `julia`), and its own tests hold no golden vector, known-answer test or fixture for this path
+(SURVEY §4, §8c).  What pins this oracle instead: analytic known-answer cases, a literal
+dense-matrix torch-autograd restatement, finite differences, and SciPy adaptive solves (tests/).
+
+Each function cites the reference lines it restates (paths relative to /root/reference).
+Index convention here is 0-based: cells k = 0..Nz-1 (0 = deepest), faces f = 0..Nz (0 = bottom).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+WIND_MIXING, FREE_CONVECTION, CONVECTIVE_ADJUSTMENT_NDE = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------------------------
+# operators  (src/differentiation_operators.jl, wind_mixing/src/filtering_operators.jl)
+# ----------------------------------------------------------------------------------------------
+def Dc(N, delta):
+    """`Dᶜ(N, Δ)`: N×(N+1), face→cell  (src/differentiation_operators.jl:6-14)."""
+    D = np.zeros((N, N + 1))
+    for k in range(N):
+        D[k, k] = -1.0
+        D[k, k + 1] = 1.0
+    return D / delta
+
+
+def Df(N, delta):
+    """`Dᶠ(N, Δ)`: (N+1)×N, cell→face, first and last rows zero  (src/differentiation_operators.jl:21-29)."""
+    D = np.zeros((N + 1, N))
+    for k in range(1, N):
+        D[k, k - 1] = -1.0
+        D[k, k] = 1.0
+    return D / delta
+
+
+def smoothing_filter(N, filter_width=3):
+    """`smoothing_filter(N, w)`: moving average with shortened end windows (filtering_operators.jl:1-14)."""
+    assert N >= filter_width and filter_width % 2 == 1
+    F = np.zeros((N, N))
+    hw = (filter_width - 1) // 2
+    for i in range(1, hw + 1):                       # Julia 1-based i
+        F[i - 1, 0:hw + i] = 1.0 / (hw + i)
+        F[N - i, N - (hw + i):N] = 1.0 / (hw + i)
+    for i in range(hw + 1, N - hw + 1):
+        F[i - 1, i - hw - 1:i + hw] = 1.0 / filter_width
+    return F
+
+
+def _face_grad(q, Nz):
+    """(Dᶠ q) with Δ = 1/Nz, batched over the leading axis: [n, Nz] → [n, Nz+1]."""
+    g = np.zeros(q.shape[:-1] + (Nz + 1,), dtype=q.dtype)
+    g[..., 1:Nz] = (q[..., 1:] - q[..., :-1]) * Nz
+    return g
+
+
+def _face_grad_T(gbar, Nz):
+    """transpose of `_face_grad`."""
+    qbar = np.zeros(gbar.shape[:-1] + (Nz,), dtype=gbar.dtype)
+    qbar[..., 1:] += gbar[..., 1:Nz] * Nz
+    qbar[..., :-1] -= gbar[..., 1:Nz] * Nz
+    return qbar
+
+
+# ----------------------------------------------------------------------------------------------
+# activations (NNlib 0.7: relu, mish, swish, leakyrelu, tanh)
+# ----------------------------------------------------------------------------------------------
+def _softplus(x):
+    return np.where(x > 0, x + np.log1p(np.exp(-np.abs(x))), np.log1p(np.exp(-np.abs(x))))
+
+
+def _sigmoid(x):
+    e = np.exp(-np.abs(x))
+    return np.where(x >= 0, 1.0 / (1.0 + e), e / (1.0 + e))
+
+
+def act(name, z):
+    if name == "identity":
+        return z
+    if name == "relu":
+        return np.maximum(z, 0)
+    if name == "mish":
+        return z * np.tanh(_softplus(z))
+    if name == "swish":
+        return z * _sigmoid(z)
+    if name == "tanh":
+        return np.tanh(z)
+    if name == "leakyrelu":
+        return np.maximum(0.01 * z, z)
+    raise ValueError(name)
+
+
+def act_grad(name, z):
+    if name == "identity":
+        return np.ones_like(z)
+    if name == "relu":
+        return (z > 0).astype(z.dtype)
+    if name == "mish":
+        t = np.tanh(_softplus(z))
+        return t + z * (1 - t * t) * _sigmoid(z)
+    if name == "swish":
+        s = _sigmoid(z)
+        return s + z * s * (1 - s)
+    if name == "tanh":
+        t = np.tanh(z)
+        return 1 - t * t
+    if name == "leakyrelu":
+        return np.where(z > 0, 1.0, 0.01).astype(z.dtype)
+    raise ValueError(name)
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter packing (Flux.destructure order; NDE_training.jl:11-21,37,58-64)
+# ----------------------------------------------------------------------------------------------
+def unpack(theta, layer_sizes, n_nets):
+    nets, o = [], 0
+    for _ in range(n_nets):
+        layers = []
+        for i in range(len(layer_sizes) - 1):
+            n_in, n_out = layer_sizes[i], layer_sizes[i + 1]
+            W = theta[o:o + n_in * n_out].reshape((n_out, n_in), order="F")
+            o += n_in * n_out
+            b = theta[o:o + n_out]
+            o += n_out
+            layers.append((W, b))
+        nets.append(layers)
+    assert o == len(theta), (o, len(theta))
+    return nets
+
+
+def pack_grads(grads):
+    parts = []
+    for layers in grads:
+        for Wb, bb in layers:
+            parts.append(Wb.reshape(-1, order="F"))
+            parts.append(bb.reshape(-1))
+    return np.concatenate(parts)
+
+
+def mlp_forward(layers, acts, x):
+    """`Chain(Dense…)(x)`: σ.(W*x .+ b) per layer; batched x [n, in].  Returns output and the tape."""
+    a, tape = x, []
+    for (W, b), name in zip(layers, acts):
+        z = a @ W.T + b
+        tape.append((a, z))
+        a = act(name, z)
+    return a, tape
+
+
+def mlp_vjp(layers, acts, tape, ybar):
+    """Pullback of `mlp_forward`: returns xbar and [(Wbar, bbar)] summed over the batch."""
+    grads = [None] * len(layers)
+    abar = ybar
+    for li in range(len(layers) - 1, -1, -1):
+        W, _ = layers[li]
+        a_prev, z = tape[li]
+        zbar = abar * act_grad(acts[li], z)
+        grads[li] = (zbar.T @ a_prev, zbar.sum(axis=0))
+        abar = zbar @ W
+    return abar, grads
+
+
+# ----------------------------------------------------------------------------------------------
+# RHS variants
+# ----------------------------------------------------------------------------------------------
+class Model:
+    """Bundles cfg-derived constants; `cfg` is any object with NDEConfig's attribute names."""
+
+    def __init__(self, cfg, dtype=np.float64):
+        self.cfg, self.dtype = cfg, dtype
+        self.Nz = cfg.Nz
+        self.acts = tuple(cfg.activations)
+        self.n_nets = 3 if cfg.model == WIND_MIXING else 1
+        mu, sg = cfg.mu, cfg.sigma
+        self.mu_u, self.mu_v, self.mu_T, self.mu_uw, self.mu_vw, self.mu_wT = [dtype(m) for m in mu]
+        self.s_u, self.s_v, self.s_T, self.s_uw, self.s_vw, self.s_wT = [dtype(s) for s in sg]
+        if cfg.smooth_NN:
+            self.F_int = smoothing_filter(cfg.Nz - 1, 3).astype(dtype)
+        if cfg.smooth_Ri:
+            self.F_face = smoothing_filter(cfg.Nz + 1, 3).astype(dtype)
+
+    def unpack(self, theta):
+        return unpack(np.asarray(theta, dtype=self.dtype), self.cfg.layer_sizes, self.n_nets)
+
+    # -- wind mixing: NDE / predict_flux / predict_NDE  (NDE_training.jl:56-165; in-place twin
+    #    training_postprocessing.jl:105-153 when cfg.inplace_variant) -----------------------------
+    def wm_top_flux(self, bcs, t):
+        """wT_top; diurnal: `scalings.wT(Qᵇ sin(2π/86400 · t τ)/(α g))` (NDE_training.jl:73, data_containers.jl:135)."""
+        c = self.cfg
+        if not c.diurnal:
+            return bcs[:, 5]
+        Q = bcs[:, 5]
+        return (Q * np.sin(2 * np.pi / 86400.0 * (t * c.tau)) / (c.alpha * c.g) - self.mu_wT) / self.s_wT
+
+    def wm_rhs(self, x, bcs, nets, t=0.0, want_vjp=False):
+        c, Nz = self.cfg, self.Nz
+        H, tau, f = c.H, c.tau, c.f
+        u, v, T = x[:, :Nz], x[:, Nz:2 * Nz], x[:, 2 * Nz:]
+        s_u, s_v, s_T, s_uw, s_vw, s_wT = self.s_u, self.s_v, self.s_T, self.s_uw, self.s_vw, self.s_wT
+        n = x.shape[0]
+        # (1) three MLPs on the full 3Nz vector (NDE_training.jl:94-96)
+        outs, tapes = [], []
+        for k in range(3):
+            o, tp = mlp_forward(nets[k], self.acts, x)
+            if c.smooth_NN:                               # :98-102
+                o = o @ self.F_int.T
+            outs.append(o)
+            tapes.append(tp)
+        s0 = (-self.mu_uw / s_uw, -self.mu_vw / s_vw, -self.mu_wT / s_wT)   # scalings.φ(0f0)
+        bc_b = (bcs[:, 0], bcs[:, 2], bcs[:, 4])
+        bc_t = (bcs[:, 1], bcs[:, 3], self.wm_top_flux(bcs, t))
+        # (2) face vectors (:104-112)
+        F = []
+        for k in range(3):
+            Fk = np.zeros((n, Nz + 1), dtype=x.dtype)
+            Fk[:, 1:Nz] = outs[k]
+            if not c.zero_weights:
+                Fk[:, 0], Fk[:, Nz] = bc_b[k], bc_t[k]
+            F.append(Fk)
+        cs = (s_u / s_uw / H, s_v / s_vw / H, s_T / s_wT / H)
+        save = {}
+        if c.modified_pacanowski_philander:               # :114-139
+            eps = 0.0 if c.inplace_variant else c.eps
+            gu, gv, gT = _face_grad(u, Nz), _face_grad(v, Nz), _face_grad(T, Nz)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                S2 = (s_u * (gu + eps)) ** 2 + (s_v * (gv + eps)) ** 2
+                B = H * c.g * c.alpha * s_T
+                Ri = B * (gT + eps) / S2                  # local_richardson :46-52
+            Ri_s = Ri @ self.F_face.T if c.smooth_Ri else Ri      # :121-123
+            y = (Ri_s - c.Ric) / c.dRi
+            th = np.tanh(y)
+            nu = c.nu0 + c.nu_minus * (1 - th) / 2        # tanh_step :54, :125
+            nu_T = nu / c.Pr
+            if c.inplace_variant and c.convective_adjustment:
+                # training_postprocessing.jl:118-121 — tests ∂u∂z (sic), not ∂T∂z
+                nu_T = np.where(gu > 0, nu / c.Pr, c.kappa)
+            D = [cs[0] * nu * gu, cs[1] * nu * gv, cs[2] * nu_T * gT]
+            for k in range(3):
+                if c.zero_weights:                        # :129-132
+                    top = bc_t[k]
+                    if c.inplace_variant and c.diurnal and k == 2:
+                        # training_postprocessing.jl:142-144 overwrites wT[end] without the -scaling(0)
+                        F[k][:, 0] += bc_b[k] - s0[k]
+                        F[k][:, Nz] += top
+                    else:
+                        F[k][:, 0] += bc_b[k] - s0[k]
+                        F[k][:, Nz] += top - s0[k]
+                F[k][:, 1:Nz] -= D[k][:, 1:Nz]
+            save.update(gu=gu, gv=gv, gT=gT, S2=S2, Ri=Ri, th=th, nu=nu, B=B, eps=eps)
+        elif c.convective_adjustment:                     # :140-143 (reference leaves κ unbound; constants.κ meant)
+            gT = _face_grad(T, Nz)
+            F[2] = F[2] - cs[2] * c.kappa * np.minimum(0.0, gT)
+            save.update(gT=gT)
+        # (3) tendencies (predict_NDE :160-162)
+        A = (tau / H * s_uw / s_u * Nz, tau / H * s_vw / s_v * Nz, tau / H * s_wT / s_T * Nz)
+        du = -A[0] * (F[0][:, 1:] - F[0][:, :-1]) + f * tau / s_u * (s_v * v + self.mu_v)
+        dv = -A[1] * (F[1][:, 1:] - F[1][:, :-1]) - f * tau / s_v * (s_u * u + self.mu_u)
+        dT = -A[2] * (F[2][:, 1:] - F[2][:, :-1])
+        dx = np.concatenate([du, dv, dT], axis=1)
+        if not want_vjp:
+            return dx
+
+        def vjp(dbar):
+            dub, dvb, dTb = dbar[:, :Nz], dbar[:, Nz:2 * Nz], dbar[:, 2 * Nz:]
+            xb_u = -(f * tau / s_v) * s_u * dvb
+            xb_v = (f * tau / s_u) * s_v * dub
+            xb_T = np.zeros_like(dTb)
+            Fbar = []
+            for k, db in enumerate((dub, dvb, dTb)):
+                Fb = np.zeros((n, Nz + 1), dtype=x.dtype)
+                Fb[:, 1:] += -A[k] * db
+                Fb[:, :-1] += A[k] * db
+                Fbar.append(Fb)
+            if c.modified_pacanowski_philander:
+                gu, gv, gT, S2, Ri, th, nu = (save[q] for q in ("gu", "gv", "gT", "S2", "Ri", "th", "nu"))
+                eps, B = save["eps"], save["B"]
+                sl = slice(1, Nz)
+                Db = [-Fbar[k] for k in range(3)]
+                gub = np.zeros_like(gu); gvb = np.zeros_like(gu); gTb = np.zeros_like(gu)
+                nub = np.zeros_like(gu)
+                gub[:, sl] = Db[0][:, sl] * cs[0] * nu[:, sl]
+                gvb[:, sl] = Db[1][:, sl] * cs[1] * nu[:, sl]
+                gTb[:, sl] = Db[2][:, sl] * cs[2] * nu[:, sl] / c.Pr
+                nub[:, sl] = (Db[0][:, sl] * cs[0] * gu[:, sl] + Db[1][:, sl] * cs[1] * gv[:, sl]
+                              + Db[2][:, sl] * cs[2] * gT[:, sl] / c.Pr)
+                Ribs = nub * (-c.nu_minus / (2 * c.dRi)) * (1 - th * th)
+                Rib = Ribs @ self.F_face if c.smooth_Ri else Ribs
+                gTb[:, sl] += Rib[:, sl] * B / S2[:, sl]
+                gub[:, sl] += Rib[:, sl] * (-Ri[:, sl] / S2[:, sl]) * 2 * s_u ** 2 * (gu[:, sl] + eps)
+                gvb[:, sl] += Rib[:, sl] * (-Ri[:, sl] / S2[:, sl]) * 2 * s_v ** 2 * (gv[:, sl] + eps)
+                xb_u = xb_u + _face_grad_T(gub, Nz)
+                xb_v = xb_v + _face_grad_T(gvb, Nz)
+                xb_T = xb_T + _face_grad_T(gTb, Nz)
+            elif c.convective_adjustment:
+                gT = save["gT"]
+                gTb = -Fbar[2] * cs[2] * c.kappa * (gT < 0)
+                xb_T = xb_T + _face_grad_T(gTb, Nz)
+            xbar = np.concatenate([xb_u, xb_v, xb_T], axis=1)
+            grads = []
+            for k in range(3):
+                ob = Fbar[k][:, 1:Nz]
+                if c.smooth_NN:
+                    ob = ob @ self.F_int
+                xb, g = mlp_vjp(nets[k], self.acts, tapes[k], ob)
+                xbar = xbar + xb
+                grads.append(g)
+            return xbar, grads
+
+        return dx, vjp
+
+    # -- free convection: ∂T∂t (free_convection_nde.jl:29-38) and convective-adjustment NDE
+    #    (convective_adjustment_nde.jl:33-48) ----------------------------------------------------
+    def fc_rhs(self, x, bcs, nets, t=0.0, want_vjp=False):
+        c, Nz = self.cfg, self.Nz
+        C = (self.s_wT / self.s_T) * (c.tau / c.H)
+        n = x.shape[0]
+        o, tape = mlp_forward(nets[0], self.acts, x)
+        w = np.zeros((n, Nz + 1), dtype=x.dtype)
+        w[:, 0], w[:, Nz], w[:, 1:Nz] = bcs[:, 0], bcs[:, 1], o
+        dT = -C * Nz * (w[:, 1:] - w[:, :-1])
+        ca = c.model == CONVECTIVE_ADJUSTMENT_NDE
+        if ca:
+            gT = _face_grad(x, Nz)
+            q = np.minimum(0.0, c.ca_K * gT)
+            dT = dT + C * Nz * (q[:, 1:] - q[:, :-1])
+        if not want_vjp:
+            return dT
+
+        def vjp(dbar):
+            wb = np.zeros((n, Nz + 1), dtype=x.dtype)
+            wb[:, 1:] += -C * Nz * dbar
+            wb[:, :-1] += C * Nz * dbar
+            xbar, g = mlp_vjp(nets[0], self.acts, tape, wb[:, 1:Nz])
+            if ca:
+                qb = -wb
+                gTb = qb * c.ca_K * (gT < 0)
+                xbar = xbar + _face_grad_T(gTb, Nz)
+            return xbar, [g]
+
+        return dT, vjp
+
+    def rhs(self, x, bcs, nets, t=0.0, want_vjp=False):
+        if self.cfg.model == WIND_MIXING:
+            return self.wm_rhs(x, bcs, nets, t, want_vjp)
+        return self.fc_rhs(x, bcs, nets, t, want_vjp)
+
+
+def rhs(cfg, x, bcs, theta, t=0.0, dtype=np.float64):
+    """One RHS evaluation — the `NDE(x,p,t)` / `NDE!(dx,x,p,t)` / `∂T∂t(T,p,t)` closures."""
+    m = Model(cfg, dtype)
+    return m.rhs(np.asarray(x, dtype), np.asarray(bcs, dtype), m.unpack(theta), t)
+
+
+# ----------------------------------------------------------------------------------------------
+# fixed-step RK4 solve with `saveat` (stand-in for solve(prob, ROCK4(); saveat=t_train): NDE_training.jl:291)
+# ----------------------------------------------------------------------------------------------
+def _step_times(cfg):
+    ts = np.asarray(cfg.save_times, dtype=np.float64)
+    S = cfg.substeps
+    out = []
+    for i in range(len(ts) - 1):
+        dt = (ts[i + 1] - ts[i]) / S
+        for s in range(S):
+            out.append((ts[i] + s * dt, dt, i + 1 if s == S - 1 else -1))
+    return out
+
+
+def solve(cfg, x0, bcs, theta, dtype=np.float64, return_tape=False):
+    """Returns sol [n_col, n_save, n_state]; save point 0 is x0 (as `saveat` includes t_train[1])."""
+    m = Model(cfg, dtype)
+    nets = m.unpack(theta)
+    x = np.array(x0, dtype=dtype)
+    bcs = np.asarray(bcs, dtype=dtype)
+    sol = np.zeros((x.shape[0], len(cfg.save_times), x.shape[1]), dtype=dtype)
+    sol[:, 0] = x
+    tape = []
+    for (t, dt, save_idx) in _step_times(cfg):
+        dt = dtype(dt)
+        if return_tape:
+            tape.append(x.copy())
+        k1 = m.rhs(x, bcs, nets, t)
+        k2 = m.rhs(x + dt / 2 * k1, bcs, nets, t + dt / 2)
+        k3 = m.rhs(x + dt / 2 * k2, bcs, nets, t + dt / 2)
+        k4 = m.rhs(x + dt * k3, bcs, nets, t + dt)
+        x = x + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+        if save_idx >= 0:
+            sol[:, save_idx] = x
+    if return_tape:
+        return sol, tape
+    return sol
+
+
+# ----------------------------------------------------------------------------------------------
+# losses (wind_mixing/src/loss.jl:1-42, NDE_training.jl:290-323; free_convection/src/training.jl:55-62)
+# ----------------------------------------------------------------------------------------------
+def loss_terms(cfg, sol, truth):
+    """Unscaled terms.  Wind mixing: (u, v, T, ∂u∂z, ∂v∂z, ∂T∂z) each `mean over sims of Flux.mse`;
+    gradient terms use Dᶠ per snapshot, i.e. Nz+1 rows *including the two all-zero ones* (loss.jl:9).
+    Free convection: a single Flux.mse over the concatenated trajectories (training.jl:58-60) in slot 2."""
+    sol, truth = np.asarray(sol, np.float64), np.asarray(truth, np.float64)
+    Nz = cfg.Nz
+    terms = np.zeros(6)
+    if cfg.model != WIND_MIXING:
+        terms[2] = np.mean((sol - truth) ** 2)
+        return terms
+    d = truth - sol
+    for k in range(3):
+        dk = d[:, :, k * Nz:(k + 1) * Nz]
+        terms[k] = np.mean(dk ** 2)
+        gk = _face_grad(dk, Nz)
+        terms[3 + k] = np.mean(gk ** 2)          # mean over (Nz+1)·Nt per sim, then over sims
+    return terms
+
+
+def default_loss_scalings(cfg, gradient_scaling=5e-3):
+    """`training_fractions === nothing` branch (NDE_training.jl:257-258); loss_NDE zeroes the gradient terms (:298)."""
+    if cfg.model != WIND_MIXING:
+        return np.array([0, 0, 1.0, 0, 0, 0])
+    g = gradient_scaling if cfg.train_gradient else 0.0
+    return np.array([1.0, 1.0, 1.0, g, g, g])
+
+
+def calculate_loss_scalings(losses, fractions, train_gradient):
+    """wind_mixing/src/loss.jl:11-31; `losses` = (u,v,T,∂u∂z,∂v∂z,∂T∂z), fractions = dict(T, dTdz, profile)."""
+    Lu, Lv, LT, Lgu, Lgv, LgT = losses
+    vel = (1 - fractions["T"]) / fractions["T"] * LT / (Lu + Lv)
+    profile_loss = vel * (Lu + Lv) + LT
+    if train_gradient:
+        velg = (1 - fractions["dTdz"]) / fractions["dTdz"] * LgT / (Lgu + Lgv)
+        gradient_loss = velg * (Lgu + Lgv) + LgT
+        tot = (1 - fractions["profile"]) / fractions["profile"] * profile_loss / gradient_loss
+    else:
+        velg = gradient_loss = tot = 0.0
+    return np.array([vel, vel, 1.0, tot * velg, tot * velg, tot])
+
+
+def loss(cfg, sol, truth, scalings):
+    """(total, scaled terms) = `sum(apply_loss_scalings(losses, loss_scalings))` (NDE_training.jl:319-322)."""
+    t = loss_terms(cfg, sol, truth) * np.asarray(scalings, np.float64)
+    return t.sum(), t
+
+
+def _loss_injection(cfg, sol_n, truth_n, scalings, n_col_total, n_save):
+    """∂(total loss)/∂sol[:, n, :] for one save point; n_col_total = global column count."""
+    Nz = cfg.Nz
+    d = sol_n - truth_n
+    if cfg.model != WIND_MIXING:
+        return scalings[2] * 2.0 * d / (n_col_total * n_save * Nz)
+    out = np.zeros_like(d)
+    for k in range(3):
+        dk = d[:, k * Nz:(k + 1) * Nz]
+        out[:, k * Nz:(k + 1) * Nz] = scalings[k] * 2.0 * dk / (n_col_total * n_save * Nz)
+        if scalings[3 + k] != 0:
+            gk = _face_grad(dk, Nz)
+            out[:, k * Nz:(k + 1) * Nz] += scalings[3 + k] * 2.0 * _face_grad_T(gk, Nz) / (n_col_total * n_save * (Nz + 1))
+    return out
+
+
+def loss_and_grad(cfg, x0, bcs, theta, truth, scalings, dtype=np.float64, n_col_total=None):
+    """Discrete adjoint of `solve` + `loss`: returns (total, scaled terms[6], grad[n_params], sol).
+
+    Stand-in for Zygote through `solve(...; sensealg=InterpolatingAdjoint(autojacvec=ZygoteVJP()))`
+    (NDE_training.jl:303-333); the reference's adjoint is continuous, so agreement is to solver
+    tolerance only (SURVEY §7 "Time stepper mismatch")."""
+    m = Model(cfg, dtype)
+    nets = m.unpack(theta)
+    bcs = np.asarray(bcs, dtype=dtype)
+    truth = np.asarray(truth, dtype=dtype)
+    scalings = np.asarray(scalings, dtype=np.float64)
+    sol, tape = solve(cfg, x0, bcs, theta, dtype, return_tape=True)
+    n_col = sol.shape[0]
+    if n_col_total is None:
+        n_col_total = n_col
+    n_save = sol.shape[1]
+    total, terms = loss(cfg, sol, truth, scalings)
+    if n_col_total != n_col:
+        total, terms = total * n_col / n_col_total, terms * n_col / n_col_total
+    lam = np.zeros_like(sol[:, 0])
+    gacc = None
+    steps = _step_times(cfg)
+    for si in range(len(steps) - 1, -1, -1):
+        t, dt, save_idx = steps[si]
+        dt = dtype(dt)
+        if save_idx >= 0:
+            lam = lam + _loss_injection(cfg, sol[:, save_idx], truth[:, save_idx], scalings, n_col_total, n_save)
+        x = tape[si]
+        k1, v1 = m.rhs(x, bcs, nets, t, True)
+        X2 = x + dt / 2 * k1
+        k2, v2 = m.rhs(X2, bcs, nets, t + dt / 2, True)
+        X3 = x + dt / 2 * k2
+        k3, v3 = m.rhs(X3, bcs, nets, t + dt / 2, True)
+        X4 = x + dt * k3
+        k4, v4 = m.rhs(X4, bcs, nets, t + dt, True)
+        k4b = dt / 6 * lam
+        x4b, g4 = v4(k4b)
+        k3b = dt / 3 * lam + dt * x4b
+        x3b, g3 = v3(k3b)
+        k2b = dt / 3 * lam + dt / 2 * x3b
+        x2b, g2 = v2(k2b)
+        k1b = dt / 6 * lam + dt / 2 * x2b
+        x1b, g1 = v1(k1b)
+        lam = lam + x1b + x2b + x3b + x4b
+        gs = pack_grads(g1) + pack_grads(g2) + pack_grads(g3) + pack_grads(g4)
+        gacc = gs if gacc is None else gacc + gs
+    return total, terms, gacc, sol
+
+
+# ----------------------------------------------------------------------------------------------
+# embedded inference (free_convection/double_gyre_nn.jl:149-168, :135,:140-147)
+# ----------------------------------------------------------------------------------------------
+def infer_forcing(cfg, T, top_flux, theta, Lz, dtype=np.float64):
+    """T [n_col, Nz] in model units → forcing = −∂z wT on cell centres (Δz = Lz/Nz).
+    `T̃ = 19.65 + T/20` (:156); `wT_int = unscale_wT(NN(scale_T(T̃)))` (:158-159); `wT = [0; wT_int; top]` (:160)."""
+    m = Model(cfg, dtype)
+    nets = m.unpack(theta)
+    T = np.asarray(T, dtype)
+    Tt = 19.65 + T / 20.0
+    o, _ = mlp_forward(nets[0], m.acts, (Tt - m.mu_T) / m.s_T)
+    wT = np.zeros((T.shape[0], cfg.Nz + 1), dtype)
+    wT[:, 1:cfg.Nz] = m.s_wT * o + m.mu_wT
+    wT[:, cfg.Nz] = np.asarray(top_flux, dtype)
+    dz = Lz / cfg.Nz
+    return -(wT[:, 1:] - wT[:, :-1]) / dz

@@ -1,0 +1,287 @@
+"""Pins oracle/nde_oracle.py (CPU, no GPU): element-wise definitions, analytic known-answer cases
+(SURVEY §8c (i)-(v)), a literal dense-matrix torch restatement with autograd, finite differences,
+and a SciPy adaptive solve that *measures* the fixed-RK4-vs-adaptive gap.
+The reference holds no golden vectors for this path (parity unpinned) — these are the substitutes."""
+import numpy as np
+import pytest
+import torch
+
+import colnde
+from colnde import synthetic
+from colnde.config import NDEConfig
+from oracle import nde_oracle as O
+from tests import literal_torch as LT
+
+
+# ---------------------------------------------------------------- element-wise definitions (iv)
+def test_difference_operators_match_definitions():
+    N = 6
+    dc, df = O.Dc(N, 1 / N), O.Df(N, 1 / N)
+    assert dc.shape == (N, N + 1) and df.shape == (N + 1, N)
+    w = np.arange(N + 1.0) ** 2
+    np.testing.assert_allclose(dc @ w, (w[1:] - w[:-1]) * N)
+    x = np.sin(np.arange(N))
+    g = df @ x
+    assert g[0] == 0 and g[-1] == 0
+    np.testing.assert_allclose(g[1:-1], (x[1:] - x[:-1]) * N)
+    # stencil helpers used by the oracle agree with the matrices and are mutual transposes
+    np.testing.assert_allclose(O._face_grad(x[None], N)[0], g)
+    gb = np.random.default_rng(0).standard_normal(N + 1)
+    np.testing.assert_allclose(O._face_grad_T(gb[None], N)[0], df.T @ gb)
+
+
+def test_smoothing_filter_rows():
+    F = O.smoothing_filter(7, 3)
+    np.testing.assert_allclose(F.sum(axis=1), 1.0)
+    np.testing.assert_allclose(F[0, :3], [0.5, 0.5, 0])
+    np.testing.assert_allclose(F[-1, -3:], [0, 0.5, 0.5])
+    np.testing.assert_allclose(F[3, 2:5], [1 / 3] * 3)
+    assert np.count_nonzero(F[3]) == 3
+
+
+def test_activations_and_derivatives():
+    z = np.linspace(-6, 6, 41)
+    np.testing.assert_allclose(O.act("mish", z), z * np.tanh(np.log1p(np.exp(z))), rtol=1e-12)
+    np.testing.assert_allclose(O.act("swish", z), z / (1 + np.exp(-z)), rtol=1e-12)
+    np.testing.assert_allclose(O.act("leakyrelu", z), np.maximum(0.01 * z, z))
+    h = 1e-6
+    for name in ("mish", "swish", "tanh", "identity"):
+        fd = (O.act(name, z + h) - O.act(name, z - h)) / (2 * h)
+        np.testing.assert_allclose(O.act_grad(name, z), fd, rtol=1e-6, atol=1e-8)
+
+
+def test_feature_scaling_roundtrip():
+    # mirrors /root/reference/test/test_feature_scaling.jl:1-15 (zero mean, unit variance, inverse)
+    rng = np.random.default_rng(1)
+    data = rng.standard_normal(1000) * 3 + 7
+    s = colnde.ZeroMeanUnitVarianceScaling.fit(data)
+    y = s(data)
+    assert abs(y.mean()) < 1e-12 and abs(y.std(ddof=1) - 1) < 1e-12
+    np.testing.assert_allclose(s.inv()(y), data, rtol=1e-12)
+
+
+def test_destructure_order():
+    from colnde.flux_compat import destructure, restructure
+    W = np.arange(6.0).reshape(2, 3)          # out=2, in=3
+    b = np.array([10.0, 11.0])
+    th = destructure([(W, b)])
+    np.testing.assert_allclose(th, [0, 3, 1, 4, 2, 5, 10, 11])   # column-major vec(W), then b
+    (W2, b2), = restructure(th, (3, 2))
+    np.testing.assert_allclose(W2, W)
+    nets = O.unpack(th, (3, 2), 1)
+    np.testing.assert_allclose(nets[0][0][0], W)
+
+
+def test_loss_scaling_ratio_identities():
+    # the identities /root/reference/wind_mixing/test/test_training_scaling.jl:17-19 asserts
+    L = np.array([0.3, 0.2, 0.05, 4.0, 3.0, 0.7])
+    fr = dict(T=0.8, dTdz=0.8, profile=0.5)
+    s = O.calculate_loss_scalings(L, fr, True)
+    sc = s * L
+    assert np.isclose(sc[2] / (sc[0] + sc[1]), fr["T"] / (1 - fr["T"]))
+    assert np.isclose(sc[5] / (sc[3] + sc[4]), fr["dTdz"] / (1 - fr["dTdz"]))
+    assert np.isclose(sc[:3].sum() / sc[3:].sum(), fr["profile"] / (1 - fr["profile"]))
+
+
+# ---------------------------------------------------------------- literal restatement: RHS values
+VARIANTS = {
+    "mpp_zero_weights": {},
+    "mpp_bc_faces": dict(zero_weights=False),
+    "conv_adj_branch": dict(modified_pacanowski_philander=False, zero_weights=False, convective_adjustment=True),
+    "raw": dict(modified_pacanowski_philander=False, zero_weights=False),
+    "smooth_NN": dict(smooth_NN=True),
+    "smooth_Ri": dict(smooth_Ri=True),
+    "diurnal": dict(diurnal=True),
+    "swish": dict(activations=("swish", "swish", "identity")),
+    "dRi_small": dict(dRi=0.1),
+}
+
+
+def _wm(n, **kw):
+    return synthetic.wind_mixing_problem(n, n_frames=3, weight_divisor=10.0, **kw)
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_wind_mixing_rhs_matches_literal(name):
+    p = _wm(3, **VARIANTS[name])
+    t = 0.013
+    dx = O.rhs(p.cfg, p.x0, p.bcs, p.weights, t)
+    th = torch.tensor(p.weights.astype(np.float64))
+    for c in range(3):
+        ref = LT.wm_rhs(p.cfg, torch.tensor(p.x0[c].astype(np.float64)),
+                        torch.tensor(p.bcs[c].astype(np.float64)), th, t).numpy()
+        np.testing.assert_allclose(dx[c], ref, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("ca", [False, True])
+def test_free_convection_rhs_matches_literal(ca):
+    p = synthetic.free_convection_problem(3, Nz=16, n_save=3, convective_adjustment=ca)
+    x0 = p.x0.copy()
+    x0[:, 8:12] = x0[:, 8:12][:, ::-1]      # force some unstable faces
+    dx = O.rhs(p.cfg, x0, p.bcs, p.weights)
+    th = torch.tensor(p.weights.astype(np.float64))
+    for c in range(3):
+        ref = LT.fc_rhs(p.cfg, torch.tensor(x0[c].astype(np.float64)),
+                        torch.tensor(p.bcs[c].astype(np.float64)), th).numpy()
+        np.testing.assert_allclose(dx[c], ref, rtol=1e-10, atol=1e-10)
+
+
+def test_inplace_variant_differs_only_at_eps():
+    p = _wm(2)
+    a = O.rhs(p.cfg, p.x0, p.bcs, p.weights)
+    b = O.rhs(p.cfg.with_(inplace_variant=True), p.x0, p.bcs, p.weights)
+    assert np.abs(a - b).max() < 1e-4 * np.abs(a).max()
+
+
+# ---------------------------------------------------------------- adjoint vs torch autograd
+def _autograd_case(p, scal):
+    cfg = p.cfg
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth)
+    tot, terms, g, sol = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, scal)
+    th = torch.tensor(p.weights.astype(np.float64), requires_grad=True)
+    sols = [LT.solve_rk4(cfg, torch.tensor(p.x0[c].astype(np.float64)),
+                         torch.tensor(p.bcs[c].astype(np.float64)), th) for c in range(p.n_columns)]
+    L = LT.total_loss(cfg, sols, [torch.tensor(truth[c]) for c in range(p.n_columns)], scal)
+    L.backward()
+    np.testing.assert_allclose(sol, torch.stack(sols).detach().numpy(), rtol=1e-9, atol=1e-10)
+    assert np.isclose(tot, L.item(), rtol=1e-10)
+    gref = th.grad.numpy()
+    assert np.linalg.norm(g - gref) <= 1e-8 * np.linalg.norm(gref) + 1e-14
+    return tot, g
+
+
+@pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "conv_adj_branch", "smooth_NN",
+                                  "smooth_Ri", "diurnal"])
+def test_wind_mixing_adjoint_matches_autograd(name):
+    p = _wm(2, **VARIANTS[name])
+    tot, g = _autograd_case(p, np.array([1.0, 0.7, 1.3, 5e-3, 4e-3, 6e-3]))
+    assert tot > 0 and np.linalg.norm(g) > 0
+
+
+@pytest.mark.parametrize("ca", [False, True])
+def test_free_convection_adjoint_matches_autograd(ca):
+    p = synthetic.free_convection_problem(2, Nz=16, n_save=3, substeps=8 if ca else 2,
+                                          convective_adjustment=ca, t_end=0.01)
+    _autograd_case(p, np.array([0, 0, 1.0, 0, 0, 0]))
+
+
+def test_adjoint_finite_differences_long_horizon():
+    p = synthetic.wind_mixing_problem(3, n_frames=17, weight_divisor=1e2)
+    cfg = p.cfg
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth)
+    sc = O.default_loss_scalings(cfg)
+    tot, _, g, _ = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc)
+    rng = np.random.default_rng(3)
+    w = p.weights.astype(np.float64)
+    for _ in range(4):
+        d = rng.standard_normal(w.shape)
+        d /= np.linalg.norm(d)
+        h = 1e-6
+        lp = O.loss(cfg, O.solve(cfg, p.x0, p.bcs, w + h * d), truth, sc)[0]
+        lm = O.loss(cfg, O.solve(cfg, p.x0, p.bcs, w - h * d), truth, sc)[0]
+        assert np.isclose((lp - lm) / (2 * h), g @ d, rtol=2e-5, atol=1e-12)
+
+
+# ---------------------------------------------------------------- analytic known answers
+def _zero_nets(cfg):
+    return np.zeros(cfg.n_params, dtype=np.float64)
+
+
+def test_kat_inertial_oscillation():
+    """(i) zero weights, ν₀=ν₋=0, zero boundary flux ⇒ (σ_u u+μ_u, σ_v v+μ_v) rotates by −fτ·t̂, T constant."""
+    p = synthetic.wind_mixing_problem(2, n_frames=33, substeps=4, nu0=0.0, nu_minus=0.0)
+    cfg = p.cfg
+    s0 = [-cfg.mu[3 + k] / cfg.sigma[3 + k] for k in range(3)]
+    bcs = np.tile(np.array([s0[0], s0[0], s0[1], s0[1], s0[2], s0[2]]), (2, 1))
+    sol = O.solve(cfg, p.x0, bcs, _zero_nets(cfg))
+    Nz = cfg.Nz
+    U0 = cfg.sigma[0] * p.x0[:, :Nz] + cfg.mu[0]
+    V0 = cfg.sigma[1] * p.x0[:, Nz:2 * Nz] + cfg.mu[1]
+    th = cfg.f * cfg.tau * cfg.save_times[-1]
+    U = U0 * np.cos(th) + V0 * np.sin(th)
+    V = -U0 * np.sin(th) + V0 * np.cos(th)
+    np.testing.assert_allclose(cfg.sigma[0] * sol[:, -1, :Nz] + cfg.mu[0], U, atol=2e-7)
+    np.testing.assert_allclose(cfg.sigma[1] * sol[:, -1, Nz:2 * Nz] + cfg.mu[1], V, atol=2e-7)
+    np.testing.assert_allclose(sol[:, -1, 2 * Nz:], p.x0[:, 2 * Nz:], atol=1e-13)
+
+
+def test_kat_free_convection_zero_weights_linear():
+    """(ii) zero weights ⇒ only cells 0 and Nz-1 change, linearly in t̂ (exact for any RK)."""
+    p = synthetic.free_convection_problem(3, Nz=16, n_save=5, substeps=1, t_end=0.3)
+    cfg = p.cfg
+    sol = O.solve(cfg, p.x0, p.bcs, _zero_nets(cfg))
+    C = cfg.sigma[5] / cfg.sigma[2] * cfg.tau / cfg.H
+    t = np.asarray(cfg.save_times)
+    x0 = p.x0.astype(np.float64)
+    np.testing.assert_allclose(sol[:, :, 1:-1], np.repeat(x0[:, None, 1:-1], 5, 1), atol=1e-13)
+    np.testing.assert_allclose(sol[:, :, -1], x0[:, -1:] - C * cfg.Nz * p.bcs[:, 1:2] * t[None], rtol=1e-12)
+    np.testing.assert_allclose(sol[:, :, 0], x0[:, :1] + C * cfg.Nz * p.bcs[:, 0:1] * t[None], rtol=1e-12)
+
+
+def test_kat_linear_diffusion_modes():
+    """(iii) zero weights, ν≡ν₀+ν₋ (Riᶜ→∞), f=0, zero flux ⇒ cosine modes decay by the RK4 stability
+    polynomial R(−κ̂λ_k Δt) per step, κ̂=τν/H², λ_k=4Nz² sin²(kπ/2Nz) — exact for the discrete scheme."""
+    p = synthetic.wind_mixing_problem(1, n_frames=9, substeps=2, Ric=1e30, f=0.0)
+    cfg = p.cfg
+    Nz = cfg.Nz
+    s0 = [-cfg.mu[3 + k] / cfg.sigma[3 + k] for k in range(3)]
+    bcs = np.array([[s0[0], s0[0], s0[1], s0[1], s0[2], s0[2]]])
+    kk = 5
+    mode = np.cos(kk * np.pi * (np.arange(Nz) + 0.5) / Nz)
+    x0 = np.concatenate([0.3 * mode, -0.2 * mode, 0.1 + 0.0 * mode])[None]
+    sol = O.solve(cfg, x0, bcs, _zero_nets(cfg))
+    kap = cfg.tau * (cfg.nu0 + cfg.nu_minus) / cfg.H ** 2
+    lam = 4 * Nz ** 2 * np.sin(kk * np.pi / (2 * Nz)) ** 2
+    dt = (cfg.save_times[1] - cfg.save_times[0]) / cfg.substeps
+    z = -kap * lam * dt
+    R = 1 + z + z ** 2 / 2 + z ** 3 / 6 + z ** 4 / 24
+    amp = R ** cfg.n_steps
+    np.testing.assert_allclose(sol[0, -1, :Nz], 0.3 * mode * amp, atol=1e-12)
+    np.testing.assert_allclose(sol[0, -1, Nz:2 * Nz], -0.2 * mode * amp, atol=1e-12)
+    assert abs(amp - np.exp(-kap * lam * cfg.save_times[-1])) < 1e-3
+
+
+def test_kat_column_sum_conservation():
+    """(v) zero boundary fluxes ⇒ Σ_k ∂T∂t = 0 (telescoping Dᶜ), with non-trivial nets."""
+    p = _wm(4)
+    cfg = p.cfg
+    s0 = [-cfg.mu[3 + k] / cfg.sigma[3 + k] for k in range(3)]
+    bcs = np.tile(np.array([s0[0], s0[0], s0[1], s0[1], s0[2], s0[2]]), (4, 1))
+    dx = O.rhs(cfg, p.x0, bcs, p.weights)
+    assert np.abs(dx[:, 2 * cfg.Nz:].sum(axis=1)).max() < 1e-9 * np.abs(dx).max()
+
+
+def test_loss_terms_include_zero_rows():
+    """∂/∂z terms average over Nz+1 rows including the two all-zero ones (loss.jl:9, NDE_training.jl:315-317)."""
+    cfg = _wm(1).cfg
+    Nz = cfg.Nz
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal((2, 2, 4, 3 * Nz))
+    t = O.loss_terms(cfg, a, b)
+    Dfm = O.Df(Nz, 1 / Nz)
+    d = (b - a)[:, :, Nz:2 * Nz]
+    ref = np.mean([np.mean((d[i] @ Dfm.T) ** 2) for i in range(2)])
+    assert np.isclose(t[4], ref) and (d[0] @ Dfm.T).shape[1] == Nz + 1
+
+
+# ---------------------------------------------------------------- fixed RK4 vs adaptive solver
+def test_fixed_rk4_vs_adaptive_gap_is_below_reference_tolerance():
+    """Measures the gap between 2-substep RK4 and an adaptive solve at the reference's reltol=1e-3
+    (NDE_training.jl:291); the build's trajectories agree with "the reference CPU solve" to this level only."""
+    from scipy.integrate import solve_ivp
+    p = synthetic.wind_mixing_problem(1, n_frames=49, weight_divisor=1e2)
+    cfg = p.cfg
+    sol = O.solve(cfg, p.x0, p.bcs, p.weights)
+    m = O.Model(cfg)
+    nets = m.unpack(p.weights)
+    bc = p.bcs.astype(np.float64)
+    f = lambda t, x: m.rhs(x[None], bc, nets, t)[0]
+    tight = solve_ivp(f, (0, cfg.save_times[-1]), p.x0[0].astype(np.float64), method="LSODA",
+                      t_eval=cfg.save_times, rtol=1e-9, atol=1e-11).y.T
+    loose = solve_ivp(f, (0, cfg.save_times[-1]), p.x0[0].astype(np.float64), method="RK45",
+                      t_eval=cfg.save_times, rtol=1e-3, atol=1e-6).y.T
+    gap_fixed = np.abs(sol[0] - tight).max()
+    gap_adaptive = np.abs(loose - tight).max()
+    print("max |RK4(S=2) - tight| = %.3e ; max |RK45(rtol=1e-3) - tight| = %.3e" % (gap_fixed, gap_adaptive))
+    assert gap_fixed < 5e-3
+    assert gap_fixed < 10 * max(gap_adaptive, 1e-4)
