@@ -1,0 +1,132 @@
+/* colnde.h — C ABI of the MI355X-native NDE column-model hot path.
+ *
+ * The reference (CliMA/ClimateParameterizations.jl, pure Julia) has no FFI for this path: it is reached
+ * through Julia closures handed to ODEProblem / OptimizationFunction / Flux.train!.  Each entry
+ * point below names the reference closure it replaces (paths relative to /root/reference); INTEGRATION.md
+ * shows the `ccall` stubs that give them the reference's names and arities.
+ *
+ * Conventions: every call returns 0 on success, non-zero on error with colnde_last_error() holding a
+ * thread-local message; no exceptions cross the boundary.  One handle = one GPU = one host thread at a
+ * time.  Host pointers are borrowed for the duration of the call; device memory is owned by the handle.
+ * All arrays are float32, C order.  `weights` is in Flux.destructure order — per net, per Dense layer,
+ * column-major vec(W[out x in]) then b — nets concatenated uw; vw; wT
+ * (wind_mixing/src/NDE_training.jl:11-21,37).  There is NO CPU fallback: without a visible gfx950 device
+ * colnde_create fails.
+ */
+#ifndef COLNDE_H
+#define COLNDE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COLNDE_VERSION 100
+#define COLNDE_MAX_LAYERS 8
+
+enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_training.jl:56-165 */
+       COLNDE_MODEL_FREE_CONVECTION = 1,    /* FreeConvectionNDE: free_convection/src/free_convection_nde.jl:29-38 */
+       COLNDE_MODEL_CONV_ADJ_NDE = 2 };     /* ConvectiveAdjustmentNDE: free_convection/src/convective_adjustment_nde.jl:33-48 */
+
+enum { COLNDE_ACT_IDENTITY = 0, COLNDE_ACT_RELU = 1, COLNDE_ACT_MISH = 2, COLNDE_ACT_SWISH = 3,
+       COLNDE_ACT_TANH = 4, COLNDE_ACT_LEAKYRELU = 5 };
+
+enum { COLNDE_ENGINE_AUTO = 0,      /* MFMA tile engine when the configuration is one it is built for, else generic */
+       COLNDE_ENGINE_GENERIC = 1,   /* one wavefront per column, any layer sizes */
+       COLNDE_ENGINE_MFMA = 2 };    /* 32-column MFMA tiles (fails at create if the configuration is not covered) */
+
+/* Mirrors the `constants`, `scalings`, `conditions` NamedTuples of prepare_parameters_NDE_training
+ * (wind_mixing/src/NDE_training.jl:1-44, :205-207) and the parameter tail of the free-convection NDEs
+ * (free_convection/src/free_convection_nde.jl:49-62). */
+typedef struct colnde_config {
+    int32_t model;                               /* COLNDE_MODEL_* */
+    int32_t Nz;                                  /* cells per column; state = 3*Nz (wind mixing) or Nz */
+    int32_t n_layers;                            /* Dense layers per net */
+    int32_t layer_sizes[COLNDE_MAX_LAYERS + 1];  /* in, h1, ..., out (= Nz-1 interior faces) */
+    int32_t activations[COLNDE_MAX_LAYERS];      /* COLNDE_ACT_* per layer */
+    int32_t modified_pacanowski_philander;       /* conditions.* */
+    int32_t convective_adjustment;
+    int32_t zero_weights;
+    int32_t smooth_NN;
+    int32_t smooth_Ri;
+    int32_t diurnal;                             /* bcs[5] then holds Q^b; wT_top(t) as NDE_training.jl:73 */
+    int32_t train_gradient;
+    int32_t inplace_variant;                     /* NDE! arithmetic of training_postprocessing.jl:105-153 */
+    float H, tau, f, g, alpha, nu0, nu_minus, Ric, dRi, Pr, kappa, eps;
+    float mu[6];                                 /* scalings u, v, T, uw, vw, wT */
+    float sigma[6];
+    float ca_K;                                  /* convective_adjustment_nde.jl:43 (10) */
+    int32_t n_save;                              /* number of `saveat` times, >= 2 */
+    int32_t substeps;                            /* classical RK4 steps per save interval */
+    const float* save_times;                     /* [n_save] nondimensional t_train ./ tau (borrowed during create) */
+    int32_t n_columns;                           /* columns (simulations) held by this handle */
+    int32_t device;                              /* HIP device ordinal */
+    int32_t engine;                              /* COLNDE_ENGINE_* */
+} colnde_config;
+
+typedef struct colnde_handle colnde_handle;
+
+const char* colnde_last_error(void);
+int colnde_version(void);
+
+int  colnde_create(const colnde_config* cfg, colnde_handle** out);
+void colnde_destroy(colnde_handle* h);
+int  colnde_n_params(const colnde_handle* h);
+int  colnde_engine(const colnde_handle* h);                  /* engine actually selected */
+int  colnde_set_stream(colnde_handle* h, void* hip_stream);  /* default: the null stream */
+/* Global column count when columns are sharded over ranks: losses and gradients are normalised by it so
+ * that a SUM all-reduce of the per-rank results is the global mean (NDE_training.jl:312-317). */
+int  colnde_set_global_columns(colnde_handle* h, int64_t n_columns_total);
+
+/* x0 [n_col][n_state], bcs [n_col][n_bc] (wind mixing: uw_b,uw_t,vw_b,vw_t,wT_b,wT_t — the tail of `p`,
+ * NDE_training.jl:60; free convection: bottom, top — free_convection_nde.jl:31), truth
+ * [n_col][n_save][n_state] or NULL.  Replaces uvT₀s / BCs / uvT_trains (NDE_training.jl:220-243). */
+int colnde_set_problem(colnde_handle* h, const float* x0, const float* bcs, const float* truth);
+
+/* One RHS evaluation for n_columns columns — NDE(x,p,t) (NDE_training.jl:56-81), NDE!(dx,x,p,t)
+ * (training_postprocessing.jl:131-153), ∂T∂t(T,p,t) (free_convection_nde.jl:29-38). */
+int colnde_rhs(colnde_handle* h, const float* x, const float* weights, const float* bcs, float t,
+               float* dx, int n_columns);
+
+/* solve(prob, alg; p=[weights;BCs], saveat=t_train) — NDE_training.jl:291,403; training_postprocessing.jl:157;
+ * free_convection/src/solve.jl:1-6.  sol [n_col][n_save][n_state] (NULL: keep on device only). */
+int colnde_forward(colnde_handle* h, const float* weights, float* sol);
+
+/* loss_NDE / loss_gradient_NDE value (NDE_training.jl:290-323), nde_loss (training.jl:55-62).
+ * scalings[6] = loss_scalings (u,v,T,dudz,dvdz,dTdz); terms[6] = scaled losses; total = their sum. */
+int colnde_loss(colnde_handle* h, const float* weights, const float scalings[6], float terms[6], float* total);
+
+/* Value and d(total)/d(weights): replaces Zygote through the sensitivity solve
+ * (OptimizationFunction(loss_gradient_NDE, AutoZygote()), NDE_training.jl:327-333; Flux.train!, training.jl:71). */
+int colnde_loss_grad(colnde_handle* h, const float* weights, const float scalings[6], float terms[6],
+                     float* total, float* grad);
+
+/* compute_neural_network_forcing! (free_convection/double_gyre_nn.jl:149-168): T [n_col][Nz] model units,
+ * top_flux [n_col]; out [n_col][Nz] = -dz(wT) on cell centres with dz = Lz/Nz. */
+int colnde_infer_forcing(colnde_handle* h, const float* weights, const float* T, const float* top_flux,
+                         float Lz, float* out, int n_columns);
+
+/* ---- device-pointer twins: every pointer is device memory on cfg.device; work is enqueued on the
+ * handle's stream and NOT synchronised.  d_out of loss_grad_dev has n_params + 8 floats:
+ * [grad(n_params); scaled terms(6); total; 0] — the buffer a caller all-reduces (RCCL) when sharded. */
+int colnde_set_problem_dev(colnde_handle* h, const float* d_x0, const float* d_bcs, const float* d_truth);
+int colnde_rhs_dev(colnde_handle* h, const float* d_x, const float* d_weights, const float* d_bcs, float t,
+                   float* d_dx, int n_columns);
+int colnde_forward_dev(colnde_handle* h, const float* d_weights, float* d_sol);
+int colnde_loss_dev(colnde_handle* h, const float* d_weights, const float scalings[6], float* d_out8);
+int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, const float scalings[6], float* d_out);
+int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux,
+                             float Lz, float* d_out, int n_columns);
+
+/* ---- measurement: HIP-event timing of the handle's kernels on its stream.
+ * which: 0 = forward solve kernel, 1 = adjoint kernel, 2 = gradient reduce, 3 = rhs, 4 = inference.
+ * Returns accumulated milliseconds and launch count since the last reset (synchronises the stream). */
+int colnde_set_profiling(colnde_handle* h, int enabled);
+int colnde_kernel_time(colnde_handle* h, int which, float* ms_total, int* n_launches);
+int colnde_reset_kernel_times(colnde_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLNDE_H */
