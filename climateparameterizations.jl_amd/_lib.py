@@ -1,0 +1,76 @@
+"""ctypes binding of libcolnde.so (include/colnde.h).  Loading fails loudly: there is no Python or CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcolnde.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_F = ctypes.POINTER(ctypes.c_float)
+_V = ctypes.c_void_p
+
+# every symbol include/colnde.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("colnde_last_error", ctypes.c_char_p, []),
+    ("colnde_version", ctypes.c_int, []),
+    ("colnde_create", ctypes.c_int, [_V, ctypes.POINTER(_V)]),
+    ("colnde_destroy", None, [_V]),
+    ("colnde_n_params", ctypes.c_int, [_V]),
+    ("colnde_engine", ctypes.c_int, [_V]),
+    ("colnde_set_stream", ctypes.c_int, [_V, _V]),
+    ("colnde_set_global_columns", ctypes.c_int, [_V, ctypes.c_int64]),
+    ("colnde_set_problem", ctypes.c_int, [_V, _V, _V, _V]),
+    ("colnde_rhs", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_forward", ctypes.c_int, [_V, _V, _V]),
+    ("colnde_loss", ctypes.c_int, [_V, _V, _F, _F, _F]),
+    ("colnde_loss_grad", ctypes.c_int, [_V, _V, _F, _F, _F, _V]),
+    ("colnde_infer_forcing", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_set_problem_dev", ctypes.c_int, [_V, _V, _V, _V]),
+    ("colnde_rhs_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_forward_dev", ctypes.c_int, [_V, _V, _V]),
+    ("colnde_loss_dev", ctypes.c_int, [_V, _V, _F, _V]),
+    ("colnde_loss_grad_dev", ctypes.c_int, [_V, _V, _F, _V]),
+    ("colnde_infer_forcing_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_set_profiling", ctypes.c_int, [_V, ctypes.c_int]),
+    ("colnde_kernel_time", ctypes.c_int, [_V, ctypes.c_int, _F, ctypes.POINTER(ctypes.c_int)]),
+    ("colnde_reset_kernel_times", ctypes.c_int, [_V]),
+]
+
+_lib = None
+
+
+class ColndeError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libcolnde.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    if not os.path.exists(LIB_PATH):
+        raise ColndeError("build did not produce %s" % LIB_PATH)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ColndeError(
+                "%s is missing: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; g.build()'`"
+                " or `make -C %s`). colnde has no CPU fallback." % (LIB_PATH, CSRC))
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise ColndeError(lib().colnde_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,566 @@
+// api.hip — the C ABI of include/colnde.h on top of the MFMA tile engine.  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "engine_tile16.h"
+
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+enum { K_FORWARD = 0, K_ADJOINT = 1, K_REDUCE = 2, K_RHS = 3, K_INFER = 4, K_COUNT = 5 };
+
+struct PendingEvent { hipEvent_t a, b; int which; };
+
+struct colnde_handle {
+    colnde_config cfg;
+    std::vector<float> save_times;
+    DevModel m;
+    PackInfo pk;
+    AdjointGeom geo;
+    bool geo_ok = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_col = 0, n_tiles = 0;
+    int64_t n_col_total = 0;
+    size_t lds_fwd = 0, lds_adj = 0;
+    float *d_w = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_x0 = nullptr, *d_bcs = nullptr, *d_truth = nullptr,
+          *d_sol = nullptr, *d_tape = nullptr, *d_slab = nullptr, *d_out = nullptr, *d_times = nullptr,
+          *d_partial = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
+    size_t tmp_cols = 0;
+    TileDesc* d_tiles = nullptr;
+    int *d_bias_zoff = nullptr, *d_bias_goff = nullptr;
+    bool have_problem = false, have_truth = false;
+    bool prof = false;
+    std::vector<PendingEvent> pending;
+    double ms[K_COUNT] = {0, 0, 0, 0, 0};
+    int launches[K_COUNT] = {0, 0, 0, 0, 0};
+};
+
+extern "C" const char* colnde_last_error(void) { return g_err.c_str(); }
+extern "C" int colnde_version(void) { return COLNDE_VERSION; }
+
+// ---- model construction -----------------------------------------------------------------------------
+static int validate(const colnde_config* c) {
+    if (!c) return fail("null config");
+    if (c->model < 0 || c->model > 2) return fail("unknown model %d", c->model);
+    if (c->Nz < 4 || c->Nz > 128) return fail("Nz = %d outside 4..128", c->Nz);
+    if (c->n_layers < 1 || c->n_layers > COLNDE_MAX_LAYERS) return fail("n_layers = %d outside 1..%d", c->n_layers, COLNDE_MAX_LAYERS);
+    const int ns = c->model == COLNDE_MODEL_WIND_MIXING ? 3 * c->Nz : c->Nz;
+    if (c->layer_sizes[0] != ns) return fail("first layer input %d != state size %d", c->layer_sizes[0], ns);
+    if (c->layer_sizes[c->n_layers] != c->Nz - 1)
+        return fail("last layer output %d != Nz-1 = %d interior faces", c->layer_sizes[c->n_layers], c->Nz - 1);
+    for (int l = 0; l <= c->n_layers; l++)
+        if (c->layer_sizes[l] < 1 || c->layer_sizes[l] > 4096) return fail("layer size %d out of range", c->layer_sizes[l]);
+    for (int l = 0; l < c->n_layers; l++)
+        if (c->activations[l] < 0 || c->activations[l] > COLNDE_ACT_LEAKYRELU) return fail("unknown activation %d", c->activations[l]);
+    if (c->model == COLNDE_MODEL_WIND_MIXING) {
+        if (c->modified_pacanowski_philander && c->convective_adjustment && !c->inplace_variant)
+            return fail("modified_pacanowski_philander and convective_adjustment are exclusive (NDE_training.jl:171)");
+        if (c->zero_weights && !c->modified_pacanowski_philander)
+            return fail("zero_weights requires modified_pacanowski_philander (NDE_training.jl:192-194)");
+    }
+    if (c->n_save < 2 || !c->save_times) return fail("need >= 2 save times");
+    if (c->substeps < 1) return fail("substeps must be >= 1");
+    for (int i = 1; i < c->n_save; i++)
+        if (!(c->save_times[i] > c->save_times[i - 1])) return fail("save_times must be strictly increasing");
+    if (c->n_columns < 1) return fail("n_columns must be >= 1");
+    if (c->engine != COLNDE_ENGINE_AUTO && c->engine != COLNDE_ENGINE_GENERIC && c->engine != COLNDE_ENGINE_MFMA)
+        return fail("unknown engine %d", c->engine);
+    return 0;
+}
+
+static void build_model(const colnde_config* c, DevModel* m, PackInfo* pk) {
+    memset(m, 0, sizeof(*m));
+    memset(pk, 0, sizeof(*pk));
+    const bool wm = c->model == COLNDE_MODEL_WIND_MIXING;
+    m->model = c->model;
+    m->Nz = c->Nz;
+    m->ns = wm ? 3 * c->Nz : c->Nz;
+    m->n_nets = wm ? 3 : 1;
+    m->n_bc = wm ? 6 : 2;
+    m->n_layers = c->n_layers;
+    int woff = 0, aoff = 0, nb = 0, pf = 0, pb = 0;
+    for (int l = 0; l <= c->n_layers; l++) m->sizes[l] = c->layer_sizes[l];
+    for (int l = 0; l < c->n_layers; l++) {
+        const int ni = c->layer_sizes[l], no = c->layer_sizes[l + 1];
+        m->acts[l] = c->activations[l];
+        m->w_off[l] = woff;
+        m->b_off[l] = woff + ni * no;
+        woff += ni * no + no;
+        m->act_off[l] = aoff;
+        aoff += (no + 3) & ~3;
+        nb += no;
+        pk->pf_off[l] = pf;
+        pk->pb_off[l] = pb;
+        pf += ((no + 15) / 16) * ((ni + 3) / 4) * 64;
+        pb += ((ni + 15) / 16) * ((no + 3) / 4) * 64;
+    }
+    pk->pf_off[c->n_layers] = pf;
+    pk->pb_off[c->n_layers] = pb;
+    pk->pf_net = pf;
+    pk->pb_net = pb;
+    m->net_size = woff;
+    m->n_params = woff * m->n_nets;
+    m->act_total = aoff;
+    m->n_bias = nb * m->n_nets;
+    // tile reads may overrun a feature block by up to 15 floats: keep that inside the row
+    m->ld_x = lds_pad(((m->ns + 15) / 16) * 16);
+    m->ld_a = lds_pad(aoff + 16);
+    m->ld_f = lds_pad(c->Nz + 1);
+    m->mpp = wm && c->modified_pacanowski_philander;
+    m->ca = wm && c->convective_adjustment;
+    m->zero_w = wm && c->zero_weights;
+    m->smooth_NN = wm && c->smooth_NN;
+    m->smooth_Ri = wm && c->smooth_Ri;
+    m->diurnal = wm && c->diurnal;
+    m->inplace = wm && c->inplace_variant;
+    const float* sg = c->sigma;
+    const float* mu = c->mu;
+    m->cs[0] = sg[0] / sg[3] / c->H;
+    m->cs[1] = sg[1] / sg[4] / c->H;
+    m->cs[2] = sg[2] / sg[5] / c->H;
+    m->A[0] = c->tau / c->H * sg[3] / sg[0] * (float)c->Nz;
+    m->A[1] = c->tau / c->H * sg[4] / sg[1] * (float)c->Nz;
+    m->A[2] = c->tau / c->H * sg[5] / sg[2] * (float)c->Nz;
+    for (int k = 0; k < 3; k++) m->s0[k] = -mu[3 + k] / sg[3 + k];
+    m->B = c->H * c->g * c->alpha * sg[2];
+    m->cor_u = c->f * c->tau / sg[0];
+    m->cor_v = c->f * c->tau / sg[1];
+    m->C_fc = (sg[5] / sg[2]) * (c->tau / c->H);
+    m->sig_u = sg[0]; m->sig_v = sg[1]; m->mu_u = mu[0]; m->mu_v = mu[1];
+    m->mu_wT = mu[5]; m->sig_wT = sg[5]; m->mu_T = mu[2]; m->sig_T = sg[2];
+    m->nu0 = c->nu0; m->nu_minus = c->nu_minus; m->Ric = c->Ric; m->dRi = c->dRi; m->Pr = c->Pr;
+    m->kappa = c->kappa; m->eps = c->eps; m->ca_K = c->ca_K; m->tau = c->tau; m->alpha_g = c->alpha * c->g;
+}
+
+static void build_tables(const DevModel& m, std::vector<TileDesc>* tiles, std::vector<int>* bz, std::vector<int>* bg) {
+    for (int net = 0; net < m.n_nets; net++)
+        for (int l = 0; l < m.n_layers; l++) {
+            const int ni = m.sizes[l], no = m.sizes[l + 1];
+            for (int it = 0; it < (ni + 15) / 16; it++)
+                for (int jt = 0; jt < (no + 15) / 16; jt++) {
+                    TileDesc d;
+                    d.a_src = l == 0 ? 0 : 1;
+                    d.a_off = (l == 0 ? 0 : m.act_off[l - 1]) + it * 16;
+                    d.d_off = m.act_off[l] + jt * 16;
+                    d.net = net;
+                    d.ni_rem = ni - it * 16 < 16 ? ni - it * 16 : 16;
+                    d.no_rem = no - jt * 16 < 16 ? no - jt * 16 : 16;
+                    d.g_off = net * m.net_size + m.w_off[l] + it * 16 * no + jt * 16;
+                    d.no = no;
+                    tiles->push_back(d);
+                }
+            for (int j = 0; j < no; j++) {
+                bz->push_back(net * CT * m.ld_a + m.act_off[l] + j);
+                bg->push_back(net * m.net_size + m.b_off[l] + j);
+            }
+        }
+}
+
+extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
+    if (!out) return fail("null out pointer");
+    *out = nullptr;
+    if (validate(cfg)) return 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail("no HIP device visible: colnde has no CPU fallback (the product path is the gfx950 HIP engine)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not in 0..%d", cfg->device, ndev - 1);
+    HIPCHK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+
+    colnde_handle* h = new (std::nothrow) colnde_handle();
+    if (!h) return fail("out of host memory");
+    h->cfg = *cfg;
+    h->save_times.assign(cfg->save_times, cfg->save_times + cfg->n_save);
+    h->cfg.save_times = h->save_times.data();
+    h->device = cfg->device;
+    h->n_col = cfg->n_columns;
+    h->n_col_total = cfg->n_columns;
+    h->n_tiles = (cfg->n_columns + CT - 1) / CT;
+    build_model(cfg, &h->m, &h->pk);
+    std::vector<TileDesc> tiles;
+    std::vector<int> bz, bg;
+    build_tables(h->m, &tiles, &bz, &bg);
+    h->m.n_tiles = (int)tiles.size();
+    h->geo_ok = pick_adjoint_geom(h->m, &h->geo);
+    h->lds_fwd = lds_floats_forward(h->m) * sizeof(float);
+    h->lds_adj = lds_floats_adjoint(h->m) * sizeof(float);
+    const size_t lds_cap = 160 * 1024;
+    if (h->lds_fwd > lds_cap) {
+        const size_t need = h->lds_fwd;
+        delete h;
+        return fail("network too large for the tile engine: forward needs %zu B of LDS (> %zu)", need, lds_cap);
+    }
+    if (h->lds_adj > lds_cap) h->geo_ok = false;
+    {
+        hipError_t e = set_kernel_attributes(lds_cap);
+        if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); }
+    }
+    const DevModel& m = h->m;
+#define ALLOC(ptr, n, T)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(n) * sizeof(T));                \
+        if (e_ != hipSuccess) {                                                            \
+            colnde_destroy(h);                                                             \
+            return fail("hipMalloc of %zu bytes failed: %s", (size_t)(n) * sizeof(T), hipGetErrorString(e_)); \
+        }                                                                                  \
+    } while (0)
+    ALLOC(h->d_w, m.n_params, float);
+    ALLOC(h->d_wf, (size_t)h->pk.pf_net * m.n_nets, float);
+    ALLOC(h->d_wb, (size_t)h->pk.pb_net * m.n_nets, float);
+    ALLOC(h->d_x0, (size_t)h->n_col * m.ns, float);
+    ALLOC(h->d_bcs, (size_t)h->n_col * m.n_bc, float);
+    ALLOC(h->d_sol, (size_t)h->n_col * cfg->n_save * m.ns, float);
+    ALLOC(h->d_out, m.n_params + 8, float);
+    ALLOC(h->d_times, cfg->n_save, float);
+    ALLOC(h->d_partial, 1024 * 8, float);
+    ALLOC(h->d_tiles, tiles.size(), TileDesc);
+    ALLOC(h->d_bias_zoff, bz.size(), int);
+    ALLOC(h->d_bias_goff, bg.size(), int);
+#undef ALLOC
+    hipError_t e = hipMemcpy(h->d_times, h->save_times.data(), sizeof(float) * cfg->n_save, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_bias_zoff, bz.data(), sizeof(int) * bz.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_bias_goff, bg.data(), sizeof(int) * bg.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { colnde_destroy(h); return fail("table upload failed: %s", hipGetErrorString(e)); }
+    *out = h;
+    return 0;
+}
+
+static void drain_events(colnde_handle* h) {
+    for (PendingEvent& p : h->pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->ms[p.which] += ms;
+            h->launches[p.which] += 1;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    h->pending.clear();
+}
+
+extern "C" void colnde_destroy(colnde_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    drain_events(h);
+    void* ptrs[] = {h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
+                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int colnde_n_params(const colnde_handle* h) { return h ? h->m.n_params : -1; }
+extern "C" int colnde_engine(const colnde_handle* h) { return h ? COLNDE_ENGINE_MFMA : -1; }
+
+extern "C" int colnde_set_stream(colnde_handle* h, void* s) {
+    if (!h) return fail("null handle");
+    h->stream = (hipStream_t)s;
+    return 0;
+}
+
+extern "C" int colnde_set_global_columns(colnde_handle* h, int64_t n) {
+    if (!h) return fail("null handle");
+    if (n < h->n_col) return fail("global column count %lld < local %d", (long long)n, h->n_col);
+    h->n_col_total = n;
+    return 0;
+}
+
+// ---- profiling -----------------------------------------------------------------------------------------
+struct Timed {
+    colnde_handle* h;
+    PendingEvent p;
+    bool on;
+    Timed(colnde_handle* h_, int which) : h(h_), on(h_->prof) {
+        if (!on) return;
+        p.which = which;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(p.a, h->stream);
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(p.b, h->stream);
+        h->pending.push_back(p);
+        if (h->pending.size() > 2048) drain_events(h);
+    }
+};
+
+extern "C" int colnde_set_profiling(colnde_handle* h, int enabled) {
+    if (!h) return fail("null handle");
+    h->prof = enabled != 0;
+    return 0;
+}
+extern "C" int colnde_kernel_time(colnde_handle* h, int which, float* ms_total, int* n_launches) {
+    if (!h) return fail("null handle");
+    if (which < 0 || which >= K_COUNT) return fail("kernel id %d outside 0..%d", which, K_COUNT - 1);
+    HIPCHK(hipSetDevice(h->device));
+    drain_events(h);
+    if (ms_total) *ms_total = (float)h->ms[which];
+    if (n_launches) *n_launches = h->launches[which];
+    return 0;
+}
+extern "C" int colnde_reset_kernel_times(colnde_handle* h) {
+    if (!h) return fail("null handle");
+    drain_events(h);
+    for (int i = 0; i < K_COUNT; i++) { h->ms[i] = 0; h->launches[i] = 0; }
+    return 0;
+}
+
+// ---- problem data --------------------------------------------------------------------------------------
+static int set_problem_impl(colnde_handle* h, const float* x0, const float* bcs, const float* truth, hipMemcpyKind kind) {
+    if (!h) return fail("null handle");
+    if (!x0 || !bcs) return fail("x0 and bcs must not be null");
+    HIPCHK(hipSetDevice(h->device));
+    const DevModel& m = h->m;
+    HIPCHK(hipMemcpyAsync(h->d_x0, x0, sizeof(float) * (size_t)h->n_col * m.ns, kind, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_bcs, bcs, sizeof(float) * (size_t)h->n_col * m.n_bc, kind, h->stream));
+    if (truth) {
+        const size_t n = (size_t)h->n_col * h->cfg.n_save * m.ns;
+        if (!h->d_truth) HIPCHK(hipMalloc((void**)&h->d_truth, n * sizeof(float)));
+        HIPCHK(hipMemcpyAsync(h->d_truth, truth, n * sizeof(float), kind, h->stream));
+    }
+    h->have_truth = truth != nullptr;
+    h->have_problem = true;
+    if (kind == hipMemcpyHostToDevice) HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int colnde_set_problem(colnde_handle* h, const float* x0, const float* bcs, const float* truth) {
+    return set_problem_impl(h, x0, bcs, truth, hipMemcpyHostToDevice);
+}
+extern "C" int colnde_set_problem_dev(colnde_handle* h, const float* x0, const float* bcs, const float* truth) {
+    return set_problem_impl(h, x0, bcs, truth, hipMemcpyDeviceToDevice);
+}
+
+static int pack(colnde_handle* h, const float* d_weights) {
+    hipError_t e = launch_pack(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->stream);
+    if (e != hipSuccess) return fail("pack_weights launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+static void loss_weights(const colnde_handle* h, const float scalings[6], LossWeights* lw) {
+    const double np = (double)h->n_col_total * h->cfg.n_save * h->m.Nz;
+    const double ng = (double)h->n_col_total * h->cfg.n_save * (h->m.Nz + 1);
+    for (int q = 0; q < 8; q++) lw->w[q] = 0.0f;
+    if (h->m.model == COLNDE_MODEL_WIND_MIXING) {
+        for (int k = 0; k < 3; k++) {
+            lw->w[k] = (float)(scalings[k] / np);
+            lw->w[3 + k] = (float)(scalings[3 + k] / ng);
+        }
+    } else {
+        lw->w[2] = (float)(scalings[2] / np);
+    }
+}
+
+// ---- rhs -----------------------------------------------------------------------------------------------
+extern "C" int colnde_rhs_dev(colnde_handle* h, const float* d_x, const float* d_weights, const float* d_bcs, float t,
+                              float* d_dx, int n_columns) {
+    if (!h) return fail("null handle");
+    if (!d_x || !d_weights || !d_bcs || !d_dx) return fail("null pointer argument");
+    if (n_columns < 1) return fail("n_columns must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    if (pack(h, d_weights)) return 1;
+    Timed tm(h, K_RHS);
+    hipError_t e = launch_rhs(h->m, h->pk, d_weights, h->d_wf, d_x, d_bcs, t, d_dx, n_columns, 256, h->lds_fwd, h->stream);
+    if (e != hipSuccess) return fail("rhs launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+static int ensure_tmp(colnde_handle* h, size_t n_columns) {
+    if (h->tmp_cols >= n_columns) return 0;
+    for (float** p : {&h->d_tmp_a, &h->d_tmp_b, &h->d_tmp_c})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    h->tmp_cols = 0;
+    HIPCHK(hipMalloc((void**)&h->d_tmp_a, n_columns * h->m.ns * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&h->d_tmp_b, n_columns * 8 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&h->d_tmp_c, n_columns * h->m.ns * sizeof(float)));
+    h->tmp_cols = n_columns;
+    return 0;
+}
+
+extern "C" int colnde_rhs(colnde_handle* h, const float* x, const float* weights, const float* bcs, float t, float* dx,
+                          int n_columns) {
+    if (!h) return fail("null handle");
+    if (!x || !weights || !bcs || !dx) return fail("null pointer argument");
+    if (n_columns < 1) return fail("n_columns must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    if (ensure_tmp(h, (size_t)n_columns)) return 1;
+    const DevModel& m = h->m;
+    HIPCHK(hipMemcpyAsync(h->d_w, weights, sizeof(float) * m.n_params, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_tmp_a, x, sizeof(float) * (size_t)n_columns * m.ns, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_tmp_b, bcs, sizeof(float) * (size_t)n_columns * m.n_bc, hipMemcpyHostToDevice, h->stream));
+    if (colnde_rhs_dev(h, h->d_tmp_a, h->d_w, h->d_tmp_b, t, h->d_tmp_c, n_columns)) return 1;
+    HIPCHK(hipMemcpyAsync(dx, h->d_tmp_c, sizeof(float) * (size_t)n_columns * m.ns, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- forward solve -------------------------------------------------------------------------------------
+static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape) {
+    if (!h->have_problem) return fail("colnde_set_problem has not been called");
+    if (pack(h, d_weights)) return 1;
+    if (with_tape && !h->d_tape) {
+        const size_t n = (size_t)h->n_tiles * (h->cfg.n_save - 1) * h->cfg.substeps * 4 * CT * h->m.ns;
+        hipError_t e = hipMalloc((void**)&h->d_tape, n * sizeof(float));
+        if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tape failed: %s", n * sizeof(float), hipGetErrorString(e));
+    }
+    Timed tm(h, K_FORWARD);
+    hipError_t e = launch_forward(h->m, h->pk, d_weights, h->d_wf, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save,
+                                  h->cfg.substeps, d_sol, with_tape ? h->d_tape : nullptr, h->n_col, 256, h->lds_fwd, h->stream);
+    if (e != hipSuccess) return fail("forward launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_forward_dev(colnde_handle* h, const float* d_weights, float* d_sol) {
+    if (!h) return fail("null handle");
+    if (!d_weights) return fail("null weights");
+    HIPCHK(hipSetDevice(h->device));
+    return forward_impl(h, d_weights, d_sol ? d_sol : h->d_sol, false);
+}
+
+extern "C" int colnde_forward(colnde_handle* h, const float* weights, float* sol) {
+    if (!h) return fail("null handle");
+    if (!weights) return fail("null weights");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_w, weights, sizeof(float) * h->m.n_params, hipMemcpyHostToDevice, h->stream));
+    if (forward_impl(h, h->d_w, h->d_sol, false)) return 1;
+    if (sol)
+        HIPCHK(hipMemcpyAsync(sol, h->d_sol, sizeof(float) * (size_t)h->n_col * h->cfg.n_save * h->m.ns, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- loss / loss + gradient ----------------------------------------------------------------------------
+extern "C" int colnde_loss_dev(colnde_handle* h, const float* d_weights, const float scalings[6], float* d_out8) {
+    if (!h) return fail("null handle");
+    if (!d_weights || !scalings || !d_out8) return fail("null pointer argument");
+    if (!h->have_truth) return fail("no truth trajectories: pass truth to colnde_set_problem");
+    HIPCHK(hipSetDevice(h->device));
+    if (forward_impl(h, d_weights, h->d_sol, false)) return 1;
+    LossWeights lw;
+    loss_weights(h, scalings, &lw);
+    const int nblk = 256;
+    hipError_t e = launch_loss(h->m, h->d_sol, h->d_truth, h->cfg.n_save, h->n_col, h->d_partial, nblk, h->stream);
+    if (e == hipSuccess) e = launch_reduce(h->d_partial, nblk, 0, 8, lw, d_out8, h->stream);
+    if (e != hipSuccess) return fail("loss launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_loss(colnde_handle* h, const float* weights, const float scalings[6], float terms[6], float* total) {
+    if (!h) return fail("null handle");
+    if (!weights || !scalings || !terms || !total) return fail("null pointer argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_w, weights, sizeof(float) * h->m.n_params, hipMemcpyHostToDevice, h->stream));
+    if (colnde_loss_dev(h, h->d_w, scalings, h->d_out)) return 1;
+    float o[8];
+    HIPCHK(hipMemcpyAsync(o, h->d_out, sizeof(o), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int q = 0; q < 6; q++) terms[q] = o[q];
+    *total = o[6];
+    return 0;
+}
+
+extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, const float scalings[6], float* d_out) {
+    if (!h) return fail("null handle");
+    if (!d_weights || !scalings || !d_out) return fail("null pointer argument");
+    if (!h->have_truth) return fail("no truth trajectories: pass truth to colnde_set_problem");
+    if (h->m.inplace) return fail("the in-place NDE! variant is an evaluation RHS; gradients use the training RHS (inplace_variant = 0)");
+    if (!h->geo_ok)
+        return fail("network too large for the tile engine's adjoint: %d weight-gradient tiles, %zu B of LDS", h->m.n_tiles, h->lds_adj);
+    HIPCHK(hipSetDevice(h->device));
+    if (forward_impl(h, d_weights, h->d_sol, true)) return 1;
+    const int stride = h->m.n_params + 8;
+    if (!h->d_slab) {
+        hipError_t e = hipMalloc((void**)&h->d_slab, (size_t)h->n_tiles * stride * sizeof(float));
+        if (e != hipSuccess) return fail("hipMalloc of the partial-gradient slab failed: %s", hipGetErrorString(e));
+    }
+    LossWeights lw;
+    loss_weights(h, scalings, &lw);
+    {
+        Timed tm(h, K_ADJOINT);
+        hipError_t e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
+                                      h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol, h->d_truth, h->d_tape,
+                                      lw, h->d_slab, h->n_col, h->geo, h->lds_adj, h->stream);
+        if (e != hipSuccess) return fail("adjoint launch failed: %s", hipGetErrorString(e));
+    }
+    {
+        Timed tm(h, K_REDUCE);
+        hipError_t e = launch_reduce(h->d_slab, h->n_tiles, h->m.n_params, stride, lw, d_out, h->stream);
+        if (e != hipSuccess) return fail("reduce launch failed: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+extern "C" int colnde_loss_grad(colnde_handle* h, const float* weights, const float scalings[6], float terms[6],
+                                float* total, float* grad) {
+    if (!h) return fail("null handle");
+    if (!weights || !scalings || !terms || !total || !grad) return fail("null pointer argument");
+    HIPCHK(hipSetDevice(h->device));
+    const int np = h->m.n_params;
+    HIPCHK(hipMemcpyAsync(h->d_w, weights, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
+    if (colnde_loss_grad_dev(h, h->d_w, scalings, h->d_out)) return 1;
+    float o[8];
+    HIPCHK(hipMemcpyAsync(grad, h->d_out, sizeof(float) * np, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(o, h->d_out + np, sizeof(o), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int q = 0; q < 6; q++) terms[q] = o[q];
+    *total = o[6];
+    return 0;
+}
+
+// ---- embedded inference --------------------------------------------------------------------------------
+extern "C" int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux,
+                                        float Lz, float* d_out, int n_columns) {
+    if (!h) return fail("null handle");
+    if (!d_weights || !d_T || !d_top_flux || !d_out) return fail("null pointer argument");
+    if (h->m.model == COLNDE_MODEL_WIND_MIXING) return fail("infer_forcing needs a single T-only network (free-convection model)");
+    if (n_columns < 1 || !(Lz > 0.0f)) return fail("n_columns >= 1 and Lz > 0 required");
+    HIPCHK(hipSetDevice(h->device));
+    if (pack(h, d_weights)) return 1;
+    Timed tm(h, K_INFER);
+    hipError_t e = launch_infer(h->m, h->pk, d_weights, h->d_wf, d_T, d_top_flux, (float)h->m.Nz / Lz, d_out, n_columns, 256,
+                                h->lds_fwd, h->stream);
+    if (e != hipSuccess) return fail("infer launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_infer_forcing(colnde_handle* h, const float* weights, const float* T, const float* top_flux, float Lz,
+                                    float* out, int n_columns) {
+    if (!h) return fail("null handle");
+    if (!weights || !T || !top_flux || !out) return fail("null pointer argument");
+    if (n_columns < 1) return fail("n_columns must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    if (ensure_tmp(h, (size_t)n_columns)) return 1;
+    const int Nz = h->m.Nz;
+    HIPCHK(hipMemcpyAsync(h->d_w, weights, sizeof(float) * h->m.n_params, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_tmp_a, T, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_tmp_b, top_flux, sizeof(float) * (size_t)n_columns, hipMemcpyHostToDevice, h->stream));
+    if (colnde_infer_forcing_dev(h, h->d_w, h->d_tmp_a, h->d_tmp_b, Lz, h->d_tmp_c, n_columns)) return 1;
+    HIPCHK(hipMemcpyAsync(out, h->d_tmp_c, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}

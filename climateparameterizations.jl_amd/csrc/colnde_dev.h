@@ -1,0 +1,69 @@
+// colnde_dev.h — device-side model description shared by the kernels and the host API (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/colnde.h"
+
+#define CT 16            // columns per workgroup tile = N of v_mfma_f32_16x16x4_f32
+#define MAX_TILE_DESC 4096
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One 16x16 weight-gradient tile owned by one wave for the whole adjoint kernel.
+struct TileDesc {
+    int a_off;    // offset (floats) of the A-operand feature block inside a column's input row
+    int a_src;    // 0: layer input is the state row xs; 1: activation row of `net`
+    int d_off;    // offset of the delta (dz) feature block inside the column's Z row
+    int net;
+    int ni_rem;   // valid input features in this tile (<=16)
+    int no_rem;   // valid output features in this tile (<=16)
+    int g_off;    // offset in the flat gradient of W[out j0][in i0] (element (i,j) at g_off + i*no + j)
+    int no;       // leading dimension (layer outputs)
+};
+
+struct DevModel {
+    int model, Nz, ns, n_nets, n_bc, n_layers;
+    int sizes[COLNDE_MAX_LAYERS + 1];
+    int acts[COLNDE_MAX_LAYERS];
+    int w_off[COLNDE_MAX_LAYERS], b_off[COLNDE_MAX_LAYERS];   // inside one net, Flux.destructure order
+    int act_off[COLNDE_MAX_LAYERS + 1];                       // act_off[l]: layer l (1-based) output offset in a row
+    int net_size, n_params, act_total, n_bias;
+    int ld_x, ld_a, ld_f;                                     // LDS row strides (floats), == 2 (mod 4)
+    int mpp, ca, zero_w, smooth_NN, smooth_Ri, diurnal, inplace;
+    int n_tiles, tiles_per_wave;
+    float cs[3], A[3], s0[3], B, cor_u, cor_v, C_fc;
+    float sig_u, sig_v, mu_u, mu_v, mu_wT, sig_wT, mu_T, sig_T;
+    float nu0, nu_minus, Ric, dRi, Pr, kappa, eps, ca_K, tau, alpha_g;
+};
+
+// ---- activations (NNlib 0.7: relu, mish, swish, tanh, leakyrelu) ------------------------------------
+__device__ __forceinline__ float dev_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// mish(x) = x tanh(softplus(x));  tanh(log(1+e^x)) = ((1+e^x)^2 - 1)/((1+e^x)^2 + 1) = n/(n+2), n = e^x (e^x + 2)
+__device__ __forceinline__ float dev_mish_t(float x) {
+    float e = __expf(fminf(x, 20.0f));
+    float n = e * (e + 2.0f);
+    return n / (n + 2.0f);
+}
+
+__device__ __forceinline__ float dev_act(int a, float z) {
+    switch (a) {
+        case COLNDE_ACT_RELU: return fmaxf(z, 0.0f);
+        case COLNDE_ACT_MISH: return z * dev_mish_t(z);
+        case COLNDE_ACT_SWISH: return z * dev_sigmoid(z);
+        case COLNDE_ACT_TANH: return tanhf(z);
+        case COLNDE_ACT_LEAKYRELU: return z > 0.0f ? z : 0.01f * z;
+        default: return z;
+    }
+}
+
+__device__ __forceinline__ float dev_act_grad(int a, float z) {
+    switch (a) {
+        case COLNDE_ACT_RELU: return z > 0.0f ? 1.0f : 0.0f;
+        case COLNDE_ACT_MISH: { float t = dev_mish_t(z); return t + z * (1.0f - t * t) * dev_sigmoid(z); }
+        case COLNDE_ACT_SWISH: { float s = dev_sigmoid(z); return s + z * s * (1.0f - s); }
+        case COLNDE_ACT_TANH: { float t = tanhf(z); return 1.0f - t * t; }
+        case COLNDE_ACT_LEAKYRELU: return z > 0.0f ? 1.0f : 0.01f;
+        default: return 1.0f;
+    }
+}

@@ -1,0 +1,44 @@
+// engine_tile16.h — host/device interface of the MFMA tile engine.
+#pragma once
+#include "colnde_dev.h"
+
+struct PackInfo {
+    int pf_off[COLNDE_MAX_LAYERS + 1];   // per-layer offsets inside one net's forward A-operand image
+    int pb_off[COLNDE_MAX_LAYERS + 1];   // ... backward (transposed) image
+    int pf_net, pb_net;                  // floats per net
+};
+
+struct LossWeights { float w[8]; };       // w[q] = loss_scaling[q] / (global element count of term q)
+
+// launch geometry chosen by the host for the adjoint kernel
+struct AdjointGeom { int nthreads, maxt, maxr; };
+
+static inline int lds_pad(int n) { int p = (n + 3) & ~3; return p + 2; }   // == 2 (mod 4)
+
+static inline size_t lds_floats_forward(const DevModel& m) {
+    return (size_t)2 * CT * m.ld_x + (size_t)m.n_nets * CT * m.ld_a + (size_t)4 * CT * m.ld_f + CT * 8;
+}
+static inline size_t lds_floats_adjoint(const DevModel& m) {
+    return (size_t)3 * CT * m.ld_x + (size_t)2 * m.n_nets * CT * m.ld_a + (size_t)5 * CT * m.ld_f + CT * 8 + 16 * 8;
+}
+
+hipError_t set_kernel_attributes(size_t max_lds_bytes);
+hipError_t launch_pack(const DevModel& m, const PackInfo& pk, const float* w, float* wf, float* wb, hipStream_t stream);
+hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x,
+                      const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x0,
+                          const float* bcs, const float* save_times, int n_save, int substeps, float* sol, float* tape,
+                          int n_col, int nthreads, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_loss(const DevModel& m, const float* sol, const float* truth, int n_save, int n_col, float* partial,
+                       int n_blocks, hipStream_t stream);
+hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* wb,
+                          const TileDesc* tiles, const int* bias_zoff, const int* bias_goff, const float* bcs,
+                          const float* save_times, int n_save, int substeps, const float* sol, const float* truth,
+                          const float* tape, const LossWeights& lw, float* slab, int n_col, const AdjointGeom& geo,
+                          size_t lds_bytes, hipStream_t stream);
+hipError_t launch_reduce(const float* slab, int n_tiles, int n_params, int stride, const LossWeights& lw, float* out,
+                         hipStream_t stream);
+hipError_t launch_infer(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* T,
+                        const float* top_flux, float inv_dz, float* out, int n_col, int nthreads, size_t lds_bytes,
+                        hipStream_t stream);
+bool pick_adjoint_geom(const DevModel& m, AdjointGeom* geo);

@@ -1,0 +1,214 @@
+"""`ColumnNDE` — one handle on the HIP tile engine for a set of columns (simulations).
+
+Thin, typed front-end of the C ABI (include/colnde.h).  NumPy arrays go through the host-pointer entry
+points; torch CUDA(ROCm) tensors go through the `_dev` twins on torch's current stream (PyTorch is used
+for device memory, streams and torch.distributed only).  The reference-named closures
+(`NDE`, `NDE!`, `loss_NDE`, `loss_gradient_NDE`, `solve_nde`, …) live in wind_mixing.py / free_convection.py.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .config import NDEConfig, to_c_config
+
+KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4}
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(a.shape)))
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class ColumnNDE:
+    def __init__(self, cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0):
+        cfg.validate()
+        self.cfg = cfg
+        self.n_columns = int(n_columns)
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        c, keep = to_c_config(cfg, n_columns, device, engine)
+        _lib.check(L.colnde_create(ctypes.byref(c), ctypes.byref(self._h)))
+        self._L = L
+        self.n_params = L.colnde_n_params(self._h)
+        assert self.n_params == cfg.n_params
+        self.n_columns_total = self.n_columns
+
+    # ---- lifetime -------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.colnde_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- configuration --------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr: int):
+        _lib.check(self._L.colnde_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_global_columns(self, n_total: int):
+        _lib.check(self._L.colnde_set_global_columns(self._h, int(n_total)))
+        self.n_columns_total = int(n_total)
+
+    def set_profiling(self, on: bool = True):
+        _lib.check(self._L.colnde_set_profiling(self._h, int(bool(on))))
+
+    def kernel_time(self, which: str):
+        ms = ctypes.c_float(0)
+        n = ctypes.c_int(0)
+        _lib.check(self._L.colnde_kernel_time(self._h, KERNEL_IDS[which], ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def reset_kernel_times(self):
+        _lib.check(self._L.colnde_reset_kernel_times(self._h))
+
+    # ---- problem data ---------------------------------------------------------------------------------
+    def set_problem(self, x0, bcs, truth=None):
+        c = self.cfg
+        if _is_torch(x0):
+            self._chk_dev(x0, (self.n_columns, c.n_state))
+            self._chk_dev(bcs, (self.n_columns, c.n_bc))
+            if truth is not None:
+                self._chk_dev(truth, (self.n_columns, c.n_save, c.n_state))
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_set_problem_dev(self._h, x0.data_ptr(), bcs.data_ptr(),
+                                                      truth.data_ptr() if truth is not None else None))
+            return
+        x0 = _f32(x0, (self.n_columns, c.n_state))
+        bcs = _f32(bcs, (self.n_columns, c.n_bc))
+        tr = _f32(truth, (self.n_columns, c.n_save, c.n_state)) if truth is not None else None
+        _lib.check(self._L.colnde_set_problem(self._h, _ptr(x0), _ptr(bcs), _ptr(tr)))
+
+    def _chk_dev(self, t, shape):
+        import torch
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+            raise ValueError("expected a contiguous float32 device tensor of shape %s" % (tuple(shape),))
+        if t.device.index != self.device:
+            raise ValueError("tensor on device %s, handle on device %d" % (t.device, self.device))
+
+    # ---- one RHS evaluation ---------------------------------------------------------------------------
+    def rhs(self, x, weights, bcs, t: float = 0.0):
+        c = self.cfg
+        if _is_torch(x):
+            import torch
+            n = x.shape[0]
+            self._chk_dev(x, (n, c.n_state))
+            self._chk_dev(weights, (self.n_params,))
+            self._chk_dev(bcs, (n, c.n_bc))
+            dx = torch.empty_like(x)
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_rhs_dev(self._h, x.data_ptr(), weights.data_ptr(), bcs.data_ptr(), float(t),
+                                              dx.data_ptr(), n))
+            return dx
+        x = _f32(x)
+        n = x.shape[0]
+        x = _f32(x, (n, c.n_state))
+        w = _f32(weights, (self.n_params,))
+        b = _f32(bcs, (n, c.n_bc))
+        dx = np.empty_like(x)
+        _lib.check(self._L.colnde_rhs(self._h, _ptr(x), _ptr(w), _ptr(b), float(t), _ptr(dx), n))
+        return dx
+
+    # ---- forward solve --------------------------------------------------------------------------------
+    def forward(self, weights, out=None):
+        c = self.cfg
+        shape = (self.n_columns, c.n_save, c.n_state)
+        if _is_torch(weights):
+            import torch
+            self._chk_dev(weights, (self.n_params,))
+            sol = out if out is not None else torch.empty(shape, dtype=torch.float32, device=weights.device)
+            self._chk_dev(sol, shape)
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_forward_dev(self._h, weights.data_ptr(), sol.data_ptr()))
+            return sol
+        w = _f32(weights, (self.n_params,))
+        sol = np.empty(shape, dtype=np.float32)
+        _lib.check(self._L.colnde_forward(self._h, _ptr(w), _ptr(sol)))
+        return sol
+
+    # ---- losses ---------------------------------------------------------------------------------------
+    def loss(self, weights, scalings: Sequence[float]):
+        sc = (ctypes.c_float * 6)(*[float(s) for s in scalings])
+        if _is_torch(weights):
+            import torch
+            self._chk_dev(weights, (self.n_params,))
+            out = torch.empty(8, dtype=torch.float32, device=weights.device)
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_loss_dev(self._h, weights.data_ptr(), sc, out.data_ptr()))
+            return out
+        w = _f32(weights, (self.n_params,))
+        terms = (ctypes.c_float * 6)()
+        total = ctypes.c_float(0)
+        _lib.check(self._L.colnde_loss(self._h, _ptr(w), sc, terms, ctypes.byref(total)))
+        return float(total.value), np.array(list(terms), dtype=np.float32)
+
+    def loss_grad(self, weights, scalings: Sequence[float], out=None):
+        """NumPy: (total, terms[6], grad[n_params]).  torch: one device tensor [grad; terms(6); total; 0]
+        (the buffer to all-reduce when columns are sharded over ranks)."""
+        sc = (ctypes.c_float * 6)(*[float(s) for s in scalings])
+        if _is_torch(weights):
+            import torch
+            self._chk_dev(weights, (self.n_params,))
+            if out is None:
+                out = torch.empty(self.n_params + 8, dtype=torch.float32, device=weights.device)
+            self._chk_dev(out, (self.n_params + 8,))
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_loss_grad_dev(self._h, weights.data_ptr(), sc, out.data_ptr()))
+            return out
+        w = _f32(weights, (self.n_params,))
+        terms = (ctypes.c_float * 6)()
+        total = ctypes.c_float(0)
+        grad = np.empty(self.n_params, dtype=np.float32)
+        _lib.check(self._L.colnde_loss_grad(self._h, _ptr(w), sc, terms, ctypes.byref(total), _ptr(grad)))
+        return float(total.value), np.array(list(terms), dtype=np.float32), grad
+
+    # ---- embedded inference ---------------------------------------------------------------------------
+    def infer_forcing(self, weights, T, top_flux, Lz: float):
+        Nz = self.cfg.Nz
+        if _is_torch(T):
+            import torch
+            n = T.shape[0]
+            self._chk_dev(T, (n, Nz))
+            self._chk_dev(top_flux, (n,))
+            self._chk_dev(weights, (self.n_params,))
+            out = torch.empty_like(T)
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_infer_forcing_dev(self._h, weights.data_ptr(), T.data_ptr(), top_flux.data_ptr(),
+                                                        float(Lz), out.data_ptr(), n))
+            return out
+        T = _f32(T)
+        n = T.shape[0]
+        T = _f32(T, (n, Nz))
+        tf = _f32(top_flux, (n,))
+        w = _f32(weights, (self.n_params,))
+        out = np.empty_like(T)
+        _lib.check(self._L.colnde_infer_forcing(self._h, _ptr(w), _ptr(T), _ptr(tf), float(Lz), _ptr(out), n))
+        return out

@@ -1,0 +1,89 @@
+"""GPU parity tests proper: the HIP tile engine, called through the C ABI, against the oracle on the same
+seeded inputs.  Floating-point path: tolerances are stated per test (float32 engine vs float64 oracle)."""
+import numpy as np
+import pytest
+
+import colnde
+from colnde import synthetic
+from oracle import nde_oracle as O
+from tests.test_oracle import VARIANTS
+
+pytestmark = pytest.mark.gpu
+
+SOL_ATOL = 1e-4          # scaled units, O(1) profiles
+LOSS_RTOL = 2e-3
+GRAD_REL = 5e-3          # relative L2 error of the float32 gradient vs the float64 oracle
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-300)
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS) + ["inplace"])
+def test_rhs_wind_mixing(name):
+    kw = dict(VARIANTS.get(name, {}))
+    if name == "inplace":
+        kw = dict(inplace_variant=True)
+    p = synthetic.wind_mixing_problem(37, n_frames=3, weight_divisor=10.0, **kw)
+    ref = O.rhs(p.cfg, p.x0, p.bcs, p.weights, 0.02)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        got = nde.rhs(p.x0, p.weights, p.bcs, 0.02)
+    assert _rel(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "smooth_NN", "smooth_Ri", "diurnal",
+                                  "conv_adj_branch", "swish"])
+def test_forward_loss_grad_wind_mixing(name):
+    p = synthetic.wind_mixing_problem(21, n_frames=9, weight_divisor=1e2, **VARIANTS[name])
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_l, terms_l = nde.loss(p.weights, sc)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    np.testing.assert_allclose(terms_l, terms, rtol=LOSS_RTOL, atol=1e-12)
+    np.testing.assert_allclose(terms_g, terms, rtol=LOSS_RTOL, atol=1e-12)
+    assert np.isclose(tot_l, tot, rtol=LOSS_RTOL) and np.isclose(tot_g, tot, rtol=LOSS_RTOL)
+    assert _rel(grad_g, g) < GRAD_REL
+
+
+@pytest.mark.parametrize("Nz,ca", [(32, False), (32, True), (64, False)])
+def test_free_convection(Nz, ca):
+    p = synthetic.free_convection_problem(19, Nz=Nz, n_save=5, substeps=16 if ca else 2,
+                                          convective_adjustment=ca, t_end=0.01)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(p.cfg)
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
+    assert _rel(grad_g, g) < GRAD_REL
+
+
+def test_infer_forcing():
+    cfg, T, top, w = synthetic.inference_problem(16, 9)
+    ref = O.infer_forcing(cfg, T, top, w, 1000.0)
+    with colnde.ColumnNDE(cfg, T.shape[0]) as nde:
+        got = nde.infer_forcing(w, T, top, 1000.0)
+    assert _rel(got, ref) < 1e-4
+
+
+def test_long_horizon_2day_suite_shape():
+    """BASELINE config 3: 8 simulations x 32 levels x 289 frames, two RK4 sub-steps per frame."""
+    p = synthetic.wind_mixing_problem(8, n_frames=289)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(p.cfg)
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    assert np.abs(sol_g - sol).max() < 5e-4
+    assert np.isclose(tot_g, tot, rtol=5e-3)
+    assert _rel(grad_g, g) < 2e-2

@@ -87,7 +87,9 @@ def test_loss_scaling_ratio_identities():
 VARIANTS = {
     "mpp_zero_weights": {},
     "mpp_bc_faces": dict(zero_weights=False),
-    "conv_adj_branch": dict(modified_pacanowski_philander=False, zero_weights=False, convective_adjustment=True),
+    # κ = 0.1 keeps the explicit RK4 step inside its stability region where ∂T∂z < 0 (κ = 10, the reference default,
+    # needs ≈20 sub-steps per 10-minute frame: the reference reaches for ROCK4 there)
+    "conv_adj_branch": dict(modified_pacanowski_philander=False, zero_weights=False, convective_adjustment=True, kappa=0.1),
     "raw": dict(modified_pacanowski_philander=False, zero_weights=False),
     "smooth_NN": dict(smooth_NN=True),
     "smooth_Ri": dict(smooth_Ri=True),
