@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — column-timesteps/s (forward + adjoint) of the 32-level wind-mixing NDE on N MI355X GPUs.
+
+One "step" = one pass of the hot path over the resident batch: forward RK4 solve + discrete adjoint +
+deterministic gradient reduce for every column of this rank (`colnde_loss_grad_dev`), then — for N > 1 —
+one RCCL SUM all-reduce of [grad(19,563); 6 loss terms; total] (the only exchange step).
+Columns shard across ranks with no other data-path collective: weak scaling, per-GPU columns fixed.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--columns C]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (metric/unit from BASELINE.json) carrying `roofline` (dominant kernel = the adjoint
+kernel, HIP-event timed on its own stream through colnde_kernel_time) and `cpu_baseline` (the C port of the
+oracle on the box's host cores, bounded sample, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+# algorithmic figures per column-timestep (stated in DESIGN.md §Measurement)
+MLP_FLOP_PER_RHS = 2 * 3 * (96 * 50 + 50 * 20 + 20 * 31)          # 38,520: three 96-50-20-31 nets, 2·Σ in·out
+ADJ_FLOP_PER_COLSTEP = 4 * 3 * MLP_FLOP_PER_RHS                    # 4 stages × (recompute + dX + dW) = 462,240
+FWD_FLOP_PER_COLSTEP = 4 * MLP_FLOP_PER_RHS                        # 154,080
+PEAK_FP32_MFMA_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: FP32 matrix, dense
+PEAK_HBM_GBPS = 8000.0
+
+
+def algorithmic_bytes_per_colstep(Nz, substeps):
+    bx = 4 * 3 * Nz
+    return dict(forward=bx / substeps, adjoint=2 * bx / substeps, total=3 * bx / substeps)
+
+
+def cpu_baseline(problem, scalings, budget_s=20.0):
+    """Time oracle/colnde_ref.c (float32 port of the oracle) on the host cores: same workload shape, bounded sample."""
+    from oracle import cref
+    cfg = problem.cfg
+    # the GPU box's CPU share for one GPU is 16 cores (more threads only oversubscribe the cgroup)
+    threads = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
+    steps = cfg.n_steps
+    # single thread first: 4 columns
+    n1 = 4
+    truth1 = cref.forward(cfg, problem.x0[:n1], problem.bcs[:n1], problem.weights_truth, n_threads=1)
+    t0 = time.perf_counter()
+    cref.loss_grad(cfg, problem.x0[:n1], problem.bcs[:n1], problem.weights, truth1, scalings, n_threads=1)
+    t1 = time.perf_counter() - t0
+    rate1 = n1 * steps / t1
+    # all cores: size the sample for ~budget_s/2 of wall time
+    per_col = t1 / n1
+    ncol = int(max(threads, min(problem.n_columns, (budget_s / 2) / per_col * threads * 0.5)))
+    ncol = max(threads, (ncol // threads) * threads)
+    ncol = min(ncol, problem.n_columns)
+    truth = cref.forward(cfg, problem.x0[:ncol], problem.bcs[:ncol], problem.weights_truth, n_threads=threads)
+    t0 = time.perf_counter()
+    cref.loss_grad(cfg, problem.x0[:ncol], problem.bcs[:ncol], problem.weights, truth, scalings, n_threads=threads)
+    tn = time.perf_counter() - t0
+    return {
+        "value": ncol * steps / tn, "unit": "column-timesteps/s", "cores": threads, "kind": "port",
+        "sample": "oracle/colnde_ref.c (float32 C port of the oracle, OpenMP over columns): %d columns x %d RK4 steps "
+                  "fwd+adjoint of the same workload in %.1f s on %d threads; 1 thread: %d columns in %.1f s = %.0f column-timesteps/s; "
+                  "reference Julia path not runnable on this box" % (ncol, steps, tn, threads, n1, t1, rate1),
+        "value_1thread": rate1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--columns", type=int, default=16384, help="columns per GPU (weak scaling)")
+    ap.add_argument("--frames", type=int, default=289, help="saved frames (2-day suite: 289)")
+    ap.add_argument("--substeps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import colnde
+    from colnde import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (colnde has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ncol = args.columns
+    # each rank generates only its shard of the global synthetic suite (seeded per rank: independent columns)
+    prob = synthetic.wind_mixing_problem(ncol, n_frames=args.frames, substeps=args.substeps,
+                                         seed=synthetic.SEED + rank)
+    # weights are replicated: every rank must start from the identical vector
+    wprob = synthetic.wind_mixing_problem(1, n_frames=2, seed=synthetic.SEED)
+    cfg = prob.cfg
+    scal = np.array([1.0, 1.0, 1.0, 5e-3, 5e-3, 5e-3], dtype=np.float64)   # NDE_training.jl:257-258 defaults
+
+    nde = colnde.ColumnNDE(cfg, ncol, device=local_rank)
+    nde.set_global_columns(ncol * world)
+    x0 = torch.from_numpy(prob.x0).to(dev)
+    bcs = torch.from_numpy(prob.bcs).to(dev)
+    w = torch.from_numpy(wprob.weights).to(dev)
+    w_truth = torch.from_numpy(wprob.weights_truth).to(dev)
+    nde.set_problem(x0, bcs)
+    truth = nde.forward(w_truth)                       # synthetic "truth": trajectory of a perturbed weight set
+    nde.set_problem(x0, bcs, truth)
+    out = torch.empty(nde.n_params + 8, dtype=torch.float32, device=dev)
+
+    def step():
+        nde.loss_grad(w, scal, out=out)
+        if dist is not None:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    nde.set_profiling(True)
+    nde.reset_kernel_times()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    ms_fwd, n_fwd = nde.kernel_time("forward")
+    ms_adj, n_adj = nde.kernel_time("adjoint")
+    ms_red, n_red = nde.kernel_time("reduce")
+    nde.set_profiling(False)
+    res = out.cpu().numpy()
+
+    if rank == 0:
+        colsteps_per_step = ncol * world * cfg.n_steps
+        value = colsteps_per_step * args.steps / elapsed
+        units_per_launch = ncol * cfg.n_steps                     # one adjoint launch covers this rank's columns
+        adj_s = ms_adj / max(n_adj, 1) * 1e-3
+        fwd_s = ms_fwd / max(n_fwd, 1) * 1e-3
+        ab = algorithmic_bytes_per_colstep(cfg.Nz, cfg.substeps)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("columns") == ncol and tj.get("frames") == args.frames and tj.get("substeps") == args.substeps:
+                    traffic = tj.get("adjoint_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved_tf = ADJ_FLOP_PER_COLSTEP * units_per_launch / adj_s / 1e12
+        line = {
+            "metric": "column-timesteps/sec (fwd+adjoint), 32-level wind-mixing NDE",
+            "value": value, "unit": "column-timesteps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "wind_mixing train_NDE 2DaySuite shape (BASELINE configs[2]): synthetic suite replicated to "
+                            "%d columns/GPU x %d levels x %d frames, %d RK4 sub-steps/frame, MPP + zero_weights + train_gradient, "
+                            "3 x (96-50-20-31 mish), six-term loss" % (ncol, cfg.Nz, args.frames, cfg.substeps),
+                "columns_per_gpu": ncol, "levels": cfg.Nz, "frames": args.frames, "substeps": cfg.substeps,
+                "rk4_steps": cfg.n_steps, "n_params": cfg.n_params, "parallelism": "columns sharded x%d" % world,
+            },
+            "roofline": {
+                "kernel": "adjoint_kernel", "bound": "mfma",
+                "achieved": achieved_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                "algorithmic_flop_per_column_timestep": ADJ_FLOP_PER_COLSTEP,
+                "avg_launch_ms": adj_s * 1e3, "launches": n_adj,
+                "hbm": {"achieved": ab["adjoint"] * units_per_launch / adj_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": ab["adjoint"] * units_per_launch / adj_s / 1e9 / PEAK_HBM_GBPS,
+                        "algorithmic_bytes_per_column_timestep": ab["adjoint"]},
+                "forward_kernel": {"avg_launch_ms": fwd_s * 1e3,
+                                   "achieved": FWD_FLOP_PER_COLSTEP * units_per_launch / fwd_s / 1e12, "unit": "TFLOP/s",
+                                   "hbm_GBps": ab["forward"] * units_per_launch / fwd_s / 1e9},
+                "reduce_kernel_avg_ms": ms_red / max(n_red, 1),
+            },
+            "loss_total": float(res[nde.n_params + 6]),
+            "grad_l2": float(np.linalg.norm(res[:nde.n_params])),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(prob, scal)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    nde.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

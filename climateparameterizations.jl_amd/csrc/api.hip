@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -43,7 +44,9 @@ struct colnde_handle {
     hipStream_t stream = nullptr;
     int n_col = 0, n_tiles = 0;
     int64_t n_col_total = 0;
-    size_t lds_fwd = 0, lds_adj = 0;
+    size_t lds_fwd = 0, lds_adj = 0, lds_fwd_solve = 0;
+    int fwd_threads = 256;
+    bool fwd_wlds = false;
     float *d_w = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_x0 = nullptr, *d_bcs = nullptr, *d_truth = nullptr,
           *d_sol = nullptr, *d_tape = nullptr, *d_slab = nullptr, *d_out = nullptr, *d_times = nullptr,
           *d_partial = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
@@ -150,7 +153,7 @@ static void build_model(const colnde_config* c, DevModel* m, PackInfo* pk) {
     m->C_fc = (sg[5] / sg[2]) * (c->tau / c->H);
     m->sig_u = sg[0]; m->sig_v = sg[1]; m->mu_u = mu[0]; m->mu_v = mu[1];
     m->mu_wT = mu[5]; m->sig_wT = sg[5]; m->mu_T = mu[2]; m->sig_T = sg[2];
-    m->nu0 = c->nu0; m->nu_minus = c->nu_minus; m->Ric = c->Ric; m->dRi = c->dRi; m->Pr = c->Pr;
+    m->nu0 = c->nu0; m->nu_minus = c->nu_minus; m->Ric = c->Ric; m->dRi = c->dRi; m->inv_dRi = 1.0f / c->dRi; m->Pr = c->Pr;
     m->kappa = c->kappa; m->eps = c->eps; m->ca_K = c->ca_K; m->tau = c->tau; m->alpha_g = c->alpha * c->g;
 }
 
@@ -206,10 +209,23 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     std::vector<int> bz, bg;
     build_tables(h->m, &tiles, &bz, &bg);
     h->m.n_tiles = (int)tiles.size();
-    h->geo_ok = pick_adjoint_geom(h->m, &h->geo);
-    h->lds_fwd = lds_floats_forward(h->m) * sizeof(float);
-    h->lds_adj = lds_floats_adjoint(h->m) * sizeof(float);
     const size_t lds_cap = 160 * 1024;
+    {   // COLNDE_ADJ_GEOM=<index> / COLNDE_FWD_WLDS=0|1 / COLNDE_FWD_THREADS=256|512 override the heuristics (tuning aid)
+        const char* eg = getenv("COLNDE_ADJ_GEOM");
+        h->geo_ok = pick_adjoint_geom(h->m, &h->geo, eg ? atoi(eg) : -1);
+    }
+    h->lds_fwd = lds_floats_forward(h->m) * sizeof(float);
+    h->lds_adj = h->geo_ok ? lds_floats_adjoint_geom(h->m, h->geo) * sizeof(float) : lds_floats_adjoint(h->m) * sizeof(float);
+    {
+        const size_t wl = ((size_t)((h->m.n_params + 3) & ~3) + 128) * sizeof(float);
+        h->fwd_wlds = h->lds_fwd + wl <= lds_cap;
+        const char* ew = getenv("COLNDE_FWD_WLDS");
+        if (ew) h->fwd_wlds = h->fwd_wlds && atoi(ew) != 0;
+        h->fwd_threads = h->fwd_wlds ? 512 : 256;
+        const char* et = getenv("COLNDE_FWD_THREADS");
+        if (et && (atoi(et) == 256 || atoi(et) == 512)) h->fwd_threads = atoi(et);
+        h->lds_fwd_solve = h->lds_fwd + (h->fwd_wlds ? wl : 0);
+    }
     if (h->lds_fwd > lds_cap) {
         const size_t need = h->lds_fwd;
         delete h;
@@ -430,7 +446,8 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
     }
     Timed tm(h, K_FORWARD);
     hipError_t e = launch_forward(h->m, h->pk, d_weights, h->d_wf, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save,
-                                  h->cfg.substeps, d_sol, with_tape ? h->d_tape : nullptr, h->n_col, 256, h->lds_fwd, h->stream);
+                                  h->cfg.substeps, d_sol, with_tape ? h->d_tape : nullptr, h->n_col, h->fwd_threads,
+                                  h->fwd_wlds, h->lds_fwd_solve, h->stream);
     if (e != hipSuccess) return fail("forward launch failed: %s", hipGetErrorString(e));
     return 0;
 }
@@ -562,5 +579,14 @@ extern "C" int colnde_infer_forcing(colnde_handle* h, const float* weights, cons
     if (colnde_infer_forcing_dev(h, h->d_w, h->d_tmp_a, h->d_tmp_b, Lz, h->d_tmp_c, n_columns)) return 1;
     HIPCHK(hipMemcpyAsync(out, h->d_tmp_c, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// Diagnostic builds (-DCOLNDE_STAMPS) only; not part of include/colnde.h.  Returns zeros in the shipped library.
+extern "C" int colnde_debug_stamps(colnde_handle* h, unsigned long long* out16) {
+    if (!h || !out16) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(debug_read_stamps(out16));
     return 0;
 }

@@ -11,7 +11,9 @@ struct PackInfo {
 struct LossWeights { float w[8]; };       // w[q] = loss_scaling[q] / (global element count of term q)
 
 // launch geometry chosen by the host for the adjoint kernel
-struct AdjointGeom { int nthreads, maxt, maxr; };
+struct AdjointGeom { int nthreads, maxt, maxr, wlds; };
+
+#define MODEL_FLOATS ((int)((sizeof(DevModel) / 4 + 3) & ~3))   // the model description at the head of the adjoint kernel's LDS
 
 static inline int lds_pad(int n) { int p = (n + 3) & ~3; return p + 2; }   // == 2 (mod 4)
 
@@ -28,7 +30,7 @@ hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, con
                       const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x0,
                           const float* bcs, const float* save_times, int n_save, int substeps, float* sol, float* tape,
-                          int n_col, int nthreads, size_t lds_bytes, hipStream_t stream);
+                          int n_col, int nthreads, bool wlds, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_loss(const DevModel& m, const float* sol, const float* truth, int n_save, int n_col, float* partial,
                        int n_blocks, hipStream_t stream);
 hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* wb,
@@ -41,4 +43,6 @@ hipError_t launch_reduce(const float* slab, int n_tiles, int n_params, int strid
 hipError_t launch_infer(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* T,
                         const float* top_flux, float inv_dz, float* out, int n_col, int nthreads, size_t lds_bytes,
                         hipStream_t stream);
-bool pick_adjoint_geom(const DevModel& m, AdjointGeom* geo);
+bool pick_adjoint_geom(const DevModel& m, AdjointGeom* geo, int force);
+size_t lds_floats_adjoint_geom(const DevModel& m, const AdjointGeom& g);
+hipError_t debug_read_stamps(unsigned long long* out16);

@@ -22,8 +22,47 @@
 #define FWD_MAXR 12   // owner-thread register items per state array in the forward kernel: CT*ns <= FWD_MAXR*blockDim
 #define MAXB 4        // bias-gradient accumulators per thread: n_bias <= MAXB*blockDim
 
+// Diagnostic build only (-DCOLNDE_STAMPS): per-phase cycle sums of workgroup 0 / wave 0, read back through
+// colnde_debug_stamps().  No stamp executes in the shipped library.
+#ifdef COLNDE_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int q = 0; q < 8; q++) g_stamps[q] = st_acc[q]; } while (0)
+__device__ unsigned long long g_fine[16];
+#define FINE_BEGIN() unsigned long long ft0_; do { __builtin_amdgcn_sched_barrier(0); ft0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FINE(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && threadIdx.x == 0) g_fine[i] += t_ - ft0_; ft0_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FINE_BEGIN()
+#define FINE(i)
+#define STAMP_DECL
+#define STAMP_BEGIN()
+#define STAMP(i)
+#define STAMP_FLUSH()
+#endif
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc += sum_{s<n} mfma(ap[s*a_step], bp[s*b_step]): operands are read U steps at a time ahead of their MFMAs.
+// (The engine is instruction-issue-bound, so the loop carries no clamps or selects: full chunks, then a remainder.)
+template <int U>
+__device__ __forceinline__ f32x4 gemm_chain(const float* ap, int a_step, const float* bp, int b_step, int n, f32x4 acc) {
+    int s = 0;
+    for (; s + U <= n; s += U) {
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            a[u] = ap[(s + u) * a_step];
+            b[u] = bp[(s + u) * b_step];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = mfma16(a[u], b[u], acc);
+    }
+    for (; s < n; s++) acc = mfma16(ap[s * a_step], bp[s * b_step], acc);
+    return acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -69,28 +108,39 @@ __global__ void pack_weights_kernel(DevModel m, PackInfo pk, const float* __rest
 // dense layers on MFMA
 // ------------------------------------------------------------------------------------------------
 // Forward pass of all nets.  xs: [CT][ld_x] state rows; A (and Z when STORE_Z): [net][CT][ld_a].
-template <bool STORE_Z>
-__device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& pk, const float* __restrict__ w,
+// WLDS: `w` points at the raw weights staged in LDS (A operand read in place, rows clamped so that a padded tile
+// never leaves the array; out-of-range k meets a zero B operand); otherwise `w` is global and the A operand comes
+// from the packed image `wf`.
+template <bool STORE_Z, bool WLDS>
+__device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& pk, const float* w,
                                             const float* __restrict__ wf, const float* xs, float* Z, float* A,
                                             int wave, int nwaves, int lane) {
     const int c = lane & 15, kq = lane >> 4;
+    FINE_BEGIN();
     for (int l = 0; l < m.n_layers; l++) {
         const int ni = m.sizes[l], no = m.sizes[l + 1];
         const int nmt = (no + 15) >> 4, nk4 = (ni + 3) >> 2;
         const int act = m.acts[l];
+        FINE(0);
         for (int job = wave; job < nmt * m.n_nets; job += nwaves) {
             const int net = job / nmt, mt = job - net * nmt;
             const float* bl = w + (size_t)net * m.net_size + m.b_off[l];
             const float* in = (l == 0) ? xs + c * m.ld_x : A + (net * CT + c) * m.ld_a + m.act_off[l - 1];
-            const float* ap = wf + (size_t)net * pk.pf_net + pk.pf_off[l] + (size_t)mt * nk4 * 64 + lane;
             f32x4 acc;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = mt * 16 + 4 * kq + r;
                 acc[r] = row < no ? bl[row] : 0.0f;
             }
-#pragma unroll 4
-            for (int k4 = 0; k4 < nk4; k4++) acc = mfma16(ap[k4 * 64], in[k4 * 4 + kq], acc);
+            FINE(1);
+            if (WLDS) {
+                const float* ap = w + net * m.net_size + m.w_off[l] + kq * no + min(mt * 16 + (lane & 15), no - 1);
+                acc = gemm_chain<4>(ap, 4 * no, in + kq, 4, nk4, acc);
+            } else {
+                const float* ap = wf + (size_t)net * pk.pf_net + pk.pf_off[l] + (size_t)mt * nk4 * 64 + lane;
+                acc = gemm_chain<4>(ap, 64, in + kq, 4, nk4, acc);
+            }
+            FINE(2);
             const int ro = (net * CT + c) * m.ld_a + m.act_off[l];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -100,14 +150,18 @@ __device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& p
                     A[ro + row] = dev_act(act, acc[r]);
                 }
             }
+            FINE(3);
         }
         __syncthreads();
+        FINE(4);
     }
 }
 
 // Backward pass: on entry Z's last-layer slot holds dZ_L; on exit every Z slot holds dZ_l and xb += W_1^T dZ_1.
-__device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& pk, const float* __restrict__ wb,
-                                             float* Z, float* xb, int wave, int nwaves, int lane) {
+template <bool WLDS>
+__device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& pk, const float* w,
+                                             const float* __restrict__ wb, float* Z, float* xb, int wave, int nwaves,
+                                             int lane) {
     const int c = lane & 15, jq = lane >> 4;
     for (int l = m.n_layers - 1; l >= 0; l--) {
         const int ni = m.sizes[l], no = m.sizes[l + 1];
@@ -117,10 +171,14 @@ __device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& 
             for (int job = wave; job < nit * m.n_nets; job += nwaves) {
                 const int net = job / nit, it = job - net * nit;
                 const float* dz = Z + (net * CT + c) * m.ld_a + m.act_off[l];
-                const float* ap = wb + (size_t)net * pk.pb_net + pk.pb_off[l] + (size_t)it * nj4 * 64 + lane;
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-                for (int j4 = 0; j4 < nj4; j4++) acc = mfma16(ap[j4 * 64], dz[j4 * 4 + jq], acc);
+                if (WLDS) {
+                    const float* ap = w + net * m.net_size + m.w_off[l] + min(it * 16 + (lane & 15), ni - 1) * no + jq;
+                    acc = gemm_chain<4>(ap, 4, dz + jq, 4, nj4, acc);
+                } else {
+                    const float* ap = wb + (size_t)net * pk.pb_net + pk.pb_off[l] + (size_t)it * nj4 * 64 + lane;
+                    acc = gemm_chain<4>(ap, 64, dz + jq, 4, nj4, acc);
+                }
                 const int ro = (net * CT + c) * m.ld_a + m.act_off[l - 1];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -133,9 +191,13 @@ __device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& 
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
                 for (int net = 0; net < m.n_nets; net++) {
                     const float* dz = Z + (net * CT + c) * m.ld_a + m.act_off[0];
-                    const float* ap = wb + (size_t)net * pk.pb_net + pk.pb_off[0] + (size_t)it * nj4 * 64 + lane;
-#pragma unroll 4
-                    for (int j4 = 0; j4 < nj4; j4++) acc = mfma16(ap[j4 * 64], dz[j4 * 4 + jq], acc);
+                    if (WLDS) {
+                        const float* ap = w + net * m.net_size + m.w_off[0] + min(it * 16 + (lane & 15), ni - 1) * no + jq;
+                        acc = gemm_chain<4>(ap, 4, dz + jq, 4, nj4, acc);
+                    } else {
+                        const float* ap = wb + (size_t)net * pk.pb_net + pk.pb_off[0] + (size_t)it * nj4 * 64 + lane;
+                        acc = gemm_chain<4>(ap, 64, dz + jq, 4, nj4, acc);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -172,6 +234,12 @@ __device__ __forceinline__ float wm_top_flux(const DevModel& m, const float* bc,
 
 struct FaceGrad { float gu, gv, gT, S2, Ri; };
 
+// tanh(y) = 1 - 2/(1 + e^{2y}) on the fast exp / reciprocal units (|rel err| ~ 1e-6)
+__device__ __forceinline__ float fast_tanh(float y) {
+    const float e = __expf(2.0f * fminf(fmaxf(y, -15.0f), 15.0f));
+    return 1.0f - __fdividef(2.0f, 1.0f + e);
+}
+
 __device__ __forceinline__ FaceGrad wm_face(const DevModel& m, const float* x, int f, float eps) {
     const int Nz = m.Nz;
     const bool in = f >= 1 && f < Nz;
@@ -181,7 +249,7 @@ __device__ __forceinline__ FaceGrad wm_face(const DevModel& m, const float* x, i
     g.gT = in ? (x[2 * Nz + f] - x[2 * Nz + f - 1]) * (float)Nz : 0.0f;
     const float a1 = m.sig_u * (g.gu + eps), a2 = m.sig_v * (g.gv + eps);
     g.S2 = a1 * a1 + a2 * a2;
-    g.Ri = m.B * (g.gT + eps) / g.S2;            // local_richardson, NDE_training.jl:46-52
+    g.Ri = __fdividef(m.B * (g.gT + eps), g.S2);   // local_richardson, NDE_training.jl:46-52
     return g;
 }
 
@@ -221,7 +289,7 @@ __device__ void physics_forward(const DevModel& m, const float* xs, const float*
                 if (in) {
                     const FaceGrad g = wm_face(m, xs + c * m.ld_x, f, eps);
                     const float Ris = m.smooth_Ri ? filt3(Ri_l + c * m.ld_f, f, nf) : g.Ri;
-                    const float th = tanhf((Ris - m.Ric) / m.dRi);
+                    const float th = fast_tanh((Ris - m.Ric) * m.inv_dRi);
                     const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;   // tanh_step, :54,:125
                     float nuT = nu / m.Pr;
                     if (m.inplace && m.ca) nuT = g.gu > 0.0f ? nu / m.Pr : m.kappa;  // training_postprocessing.jl:118-121
@@ -301,7 +369,7 @@ __device__ void physics_vjp(const DevModel& m, const float* xs, const float* dba
                 if (m.mpp) {
                     const FaceGrad g = wm_face(m, xs + c * m.ld_x, f, eps);
                     const float Ris = m.smooth_Ri ? filt3(Ri_l + c * m.ld_f, f, nf) : g.Ri;
-                    const float th = tanhf((Ris - m.Ric) / m.dRi);
+                    const float th = fast_tanh((Ris - m.Ric) * m.inv_dRi);
                     const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
                     const float D0 = -Fb0, D1 = -Fb1, D2 = -Fb2;
                     g0 = D0 * m.cs[0] * nu;
@@ -310,8 +378,8 @@ __device__ void physics_vjp(const DevModel& m, const float* xs, const float* dba
                     const float nub = D0 * m.cs[0] * g.gu + D1 * m.cs[1] * g.gv + D2 * m.cs[2] * g.gT / m.Pr;
                     ribs = nub * (-m.nu_minus / (2.0f * m.dRi)) * (1.0f - th * th);
                     if (!m.smooth_Ri) {
-                        g2 += ribs * m.B / g.S2;
-                        const float q = ribs * (-g.Ri / g.S2) * 2.0f;
+                        g2 += __fdividef(ribs * m.B, g.S2);
+                        const float q = __fdividef(ribs * -g.Ri, g.S2) * 2.0f;
                         g0 += q * m.sig_u * m.sig_u * (g.gu + eps);
                         g1 += q * m.sig_v * m.sig_v * (g.gv + eps);
                     }
@@ -438,7 +506,7 @@ __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const
         xs[c * m.ld_x + i] = x[(size_t)min(col0 + c, n_col - 1) * m.ns + i];
     }
     __syncthreads();
-    mlp_forward<false>(m, pk, w, wf, xs, nullptr, A, wave, nwaves, lane);
+    mlp_forward<false, false>(m, pk, w, wf, xs, nullptr, A, wave, nwaves, lane);
     physics_forward(m, xs, A, F, Ri_l, bcl, t, kk, tid, nth);
     for (int it = tid; it < CT * m.ns; it += nth) {
         const int c = it / m.ns, i = it - c * m.ns;
@@ -450,13 +518,15 @@ __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const
 // forward solve: classical RK4, S sub-steps per save interval, state at save points -> sol,
 // stage inputs of every step -> tape (read back by the adjoint kernel)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) forward_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
+template <bool WLDS, int NTH>
+__global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                                const float* __restrict__ x0, const float* __restrict__ bcs,
                                const float* __restrict__ save_times, int n_save, int substeps,
                                float* __restrict__ sol, float* __restrict__ tape, int n_col) {
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
-    float* xs = smem;
+    float* wl = smem;                                   // raw weights (WLDS) + 128 floats of zero padding
+    float* xs = smem + (WLDS ? ((m.n_params + 3) & ~3) + 128 : 0);
     float* kk = xs + CT * m.ld_x;
     float* A = kk + CT * m.ld_x;
     float* F = A + m.n_nets * CT * m.ld_a;
@@ -465,6 +535,8 @@ __global__ void __launch_bounds__(256) forward_kernel(DevModel m, PackInfo pk, c
     const int total = (int)(bcl + CT * 8 - smem);
     for (int i = tid; i < total; i += nth) smem[i] = 0.0f;
     __syncthreads();
+    if (WLDS) for (int i = tid; i < m.n_params; i += nth) wl[i] = w[i];
+    const float* wsrc = WLDS ? wl : w;
     const int col0 = blockIdx.x * CT;
     const int n_items = CT * m.ns;
     load_bcs(m, bcs, bcl, col0, n_col, tid);
@@ -483,16 +555,16 @@ __global__ void __launch_bounds__(256) forward_kernel(DevModel m, PackInfo pk, c
     }
     const int n_steps = (n_save - 1) * substeps;
     float* tp = tape ? tape + (size_t)blockIdx.x * n_steps * 4 * n_items : nullptr;
-    const float ca[4] = {0.0f, 0.5f, 0.5f, 1.0f};
-    const float cb[4] = {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f};
     int step = 0;
     for (int iv = 0; iv < n_save - 1; iv++) {
         const float t0 = save_times[iv];
         const float dt = (save_times[iv + 1] - t0) / (float)substeps;
         for (int s = 0; s < substeps; s++, step++) {
             const float ts = t0 + (float)s * dt;
-#pragma unroll
+#pragma nounroll
             for (int st = 0; st < 4; st++) {
+                const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);            // stage abscissa
+                const float cbp = (st == 1) ? 1.0f / 6.0f : 1.0f / 3.0f;               // weight of k_{st-1}
 #pragma unroll
                 for (int r = 0; r < FWD_MAXR; r++) {
                     const int it = tid + r * nth;
@@ -502,16 +574,16 @@ __global__ void __launch_bounds__(256) forward_kernel(DevModel m, PackInfo pk, c
                         float v = xn[r];
                         if (st > 0) {
                             const float kv = kk[o];
-                            acc[r] += cb[st - 1] * kv;
-                            v += ca[st] * dt * kv;
+                            acc[r] += cbp * kv;
+                            v += ca * dt * kv;
                         }
                         xs[o] = v;
                         if (tp) tp[((size_t)step * 4 + st) * n_items + it] = v;
                     }
                 }
                 __syncthreads();
-                mlp_forward<false>(m, pk, w, wf, xs, nullptr, A, wave, nwaves, lane);
-                physics_forward(m, xs, A, F, Ri_l, bcl, ts + ca[st] * dt, kk, tid, nth);
+                mlp_forward<false, WLDS>(m, pk, wsrc, wf, xs, nullptr, A, wave, nwaves, lane);
+                physics_forward(m, xs, A, F, Ri_l, bcl, ts + ca * dt, kk, tid, nth);
             }
             const bool save = (s == substeps - 1);
 #pragma unroll
@@ -519,7 +591,7 @@ __global__ void __launch_bounds__(256) forward_kernel(DevModel m, PackInfo pk, c
                 const int it = tid + r * nth;
                 if (it < n_items) {
                     const int c = it / m.ns, i = it - c * m.ns;
-                    acc[r] += cb[3] * kk[c * m.ld_x + i];
+                    acc[r] += (1.0f / 6.0f) * kk[c * m.ld_x + i];
                     xn[r] += dt * acc[r];
                     acc[r] = 0.0f;
                     if (save && sol && col0 + c < n_col)
@@ -591,9 +663,9 @@ __global__ void loss_kernel(DevModel m, const float* __restrict__ sol, const flo
 // ------------------------------------------------------------------------------------------------
 // adjoint: back-propagation through the RK4 steps, replaying the stage-input tape
 // ------------------------------------------------------------------------------------------------
-template <int MAXT, int NTH, int MAXR>
+template <int MAXT, int NTH, int MAXR, bool WLDS>
 __global__ void __launch_bounds__(NTH)
-adjoint_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
+adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                const float* __restrict__ wb, const TileDesc* __restrict__ tiles, const int* __restrict__ bias_zoff,
                const int* __restrict__ bias_goff, const float* __restrict__ bcs, const float* __restrict__ save_times,
                int n_save, int substeps, const float* __restrict__ sol, const float* __restrict__ truth,
@@ -601,19 +673,30 @@ adjoint_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float
                int n_col) {
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
-    float* xs = smem;
-    float* dbar = xs + CT * m.ld_x;
-    float* xb = dbar + CT * m.ld_x;
-    float* Z = xb + CT * m.ld_x;
-    float* A = Z + m.n_nets * CT * m.ld_a;
-    float* gb = A + m.n_nets * CT * m.ld_a;
-    float* Ri_l = gb + 3 * CT * m.ld_f;
-    float* Rib_l = Ri_l + CT * m.ld_f;
-    float* bcl = Rib_l + CT * m.ld_f;
+    // the model description lives in LDS: per-layer fields indexed with a runtime layer number would otherwise be
+    // dependent scalar loads from the kernarg segment (each followed by a full lgkmcnt(0) drain)
+    // (kept inside the dynamic region: a static __shared__ object would shift its base, guide G17)
+    DevModel& m_lds = *reinterpret_cast<DevModel*>(smem);
+    float* const base = smem + MODEL_FLOATS;
+    float* wl = base;                                   // raw weights (WLDS) + 128 floats of zero padding
+    float* xs = base + (WLDS ? ((m_arg.n_params + 3) & ~3) + 128 : 0);
+    float* dbar = xs + CT * m_arg.ld_x;
+    float* xb = dbar + CT * m_arg.ld_x;
+    float* Z = xb + CT * m_arg.ld_x;
+    float* A = Z + m_arg.n_nets * CT * m_arg.ld_a;
+    float* gb = A + m_arg.n_nets * CT * m_arg.ld_a;
+    float* Ri_l = gb + 3 * CT * m_arg.ld_f;
+    float* Rib_l = Ri_l + CT * m_arg.ld_f;
+    float* bcl = Rib_l + CT * m_arg.ld_f;
     float* red = bcl + CT * 8;
     const int total = (int)(red + 16 * 8 - smem);
     for (int i = tid; i < total; i += nth) smem[i] = 0.0f;
     __syncthreads();
+    for (int i = tid; i < (int)(sizeof(DevModel) / 4); i += nth) ((int*)&m_lds)[i] = ((const int*)&m_arg)[i];
+    if (WLDS) for (int i = tid; i < m_arg.n_params; i += nth) wl[i] = w[i];
+    __syncthreads();
+    const DevModel& m = m_lds;
+    const float* wsrc = WLDS ? wl : w;
     const int col0 = blockIdx.x * CT;
     const int n_items = CT * m.ns;
     load_bcs(m, bcs, bcl, col0, n_col, tid);
@@ -629,13 +712,40 @@ adjoint_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float
         const int b = tid + r * nth;
         bz[r] = b < m.n_bias ? bias_zoff[b] : -1;
     }
-    float lam[MAXR], xbs[MAXR];
+    float lam[MAXR], xbs[MAXR], xpre[MAXR];
 #pragma unroll
     for (int r = 0; r < MAXR; r++) lam[r] = 0.0f;
     float sums[6] = {0, 0, 0, 0, 0, 0};
+    STAMP_DECL;
+
+    // per-slot LDS addresses (float indices into smem, lane part folded in) of this wave's weight-gradient tiles
+    int a_ad[MAXT], d_ad[MAXT];
+    unsigned long long a_is_act = 0ull;
+    {
+        const int cq = lane >> 4;
+#pragma unroll
+        for (int sl = 0; sl < MAXT; sl++) {
+            const int t = wave + sl * nwaves;
+            a_ad[sl] = 0;
+            d_ad[sl] = 0;
+            if (t < m.n_tiles) {
+                const TileDesc d = tiles[t];
+                const int stride = d.a_src ? m.ld_a : m.ld_x;
+                a_ad[sl] = (int)((d.a_src ? A + d.net * CT * m.ld_a : xs) - smem) + d.a_off + (lane & 15) + cq * stride;
+                d_ad[sl] = (int)(Z - smem) + d.net * CT * m.ld_a + d.d_off + (lane & 15) + cq * m.ld_a;
+                if (d.a_src) a_is_act |= 1ull << sl;
+            }
+        }
+    }
 
     const int n_steps = (n_save - 1) * substeps;
     const float* tp = tape + (size_t)blockIdx.x * n_steps * 4 * n_items;
+    // the tape is read one stage ahead of its use (xpre) so that its HBM latency hides under the previous stage
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) {
+        const int it = tid + r * nth;
+        xpre[r] = it < n_items ? tp[((size_t)n_steps * 4 - 1) * n_items + it] : 0.0f;
+    }
 
     // save point 0 enters the loss value only (x0 does not depend on the weights)
 #pragma unroll
@@ -665,12 +775,14 @@ adjoint_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float
         }
         for (int s = substeps - 1; s >= 0; s--) {
             const int step = iv * substeps + s;
-            const float wl[4] = {dt / 6.0f, dt / 3.0f, dt / 3.0f, dt / 6.0f};
-            const float wx[4] = {0.5f * dt, 0.5f * dt, dt, 0.0f};
 #pragma unroll
             for (int r = 0; r < MAXR; r++) xbs[r] = 0.0f;
-#pragma unroll
+#pragma nounroll
             for (int st = 3; st >= 0; st--) {
+                // k̄4 = dt/6 λ; k̄3 = dt/3 λ + dt x̄4; k̄2 = dt/3 λ + dt/2 x̄3; k̄1 = dt/6 λ + dt/2 x̄2
+                const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
+                const float cwx = st == 2 ? dt : 0.5f * dt;
+                STAMP_BEGIN();
                 // stage input from the tape; stage cotangent k̄_st = wl λ + wx x̄_{st+1}
 #pragma unroll
                 for (int r = 0; r < MAXR; r++) {
@@ -678,31 +790,60 @@ adjoint_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float
                     if (it < n_items) {
                         const int c = it / m.ns, i = it - c * m.ns;
                         const int o = c * m.ld_x + i;
-                        xs[o] = tp[((size_t)step * 4 + st) * n_items + it];
-                        float kb = wl[st] * lam[r];
-                        if (st < 3) kb += wx[st] * xb[o];
+                        xs[o] = xpre[r];
+                        float kb = cwl * lam[r];
+                        if (st < 3) kb += cwx * xb[o];
                         dbar[o] = kb;
                     }
                 }
-                __syncthreads();
-                mlp_forward<true>(m, pk, w, wf, xs, Z, A, wave, nwaves, lane);
-                physics_vjp(m, xs, dbar, Z, xb, gb, Ri_l, Rib_l, tid, nth);
-                mlp_backward(m, pk, wb, Z, xb, wave, nwaves, lane);
-                // weight gradients: dW += A_{l-1}^T dZ_l over the tile's 16 columns
+                {
+                    const int qn = step * 4 + st - 1;            // the stage handled next (tape order is time order)
+                    if (qn >= 0) {
 #pragma unroll
-                for (int sl = 0; sl < MAXT; sl++) {
-                    const int t = wave + sl * nwaves;
-                    if (t < m.n_tiles) {
-                        const TileDesc d = tiles[t];
-                        const int stride = d.a_src ? m.ld_a : m.ld_x;
-                        const float* ar = (d.a_src ? A + d.net * CT * m.ld_a : xs) + d.a_off + (lane & 15);
-                        const float* dr = Z + d.net * CT * m.ld_a + d.d_off + (lane & 15);
-                        const int cq = lane >> 4;
-#pragma unroll
-                        for (int c0 = 0; c0 < CT; c0 += 4)
-                            gacc[sl] = mfma16(ar[(c0 + cq) * stride], dr[(c0 + cq) * m.ld_a], gacc[sl]);
+                        for (int r = 0; r < MAXR; r++) {
+                            const int it = tid + r * nth;
+                            if (it < n_items) xpre[r] = tp[(size_t)qn * n_items + it];
+                        }
                     }
                 }
+                __syncthreads();
+                STAMP(0);
+                mlp_forward<true, WLDS>(m, pk, wsrc, wf, xs, Z, A, wave, nwaves, lane);
+                STAMP(1);
+                physics_vjp(m, xs, dbar, Z, xb, gb, Ri_l, Rib_l, tid, nth);
+                STAMP(2);
+                mlp_backward<WLDS>(m, pk, wsrc, wb, Z, xb, wave, nwaves, lane);
+                STAMP(3);
+                // weight gradients: dW += A_{l-1}^T dZ_l over the tile's 16 columns; operands of slot sl+1 are read
+                // while the MFMAs of slot sl run
+                {
+                    float pa[2][4], pb[2][4];
+                    const int zs4 = 4 * m.ld_a;
+                    if (wave < m.n_tiles) {
+                        const int as4 = 4 * ((a_is_act & 1ull) ? m.ld_a : m.ld_x);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            pa[0][q] = smem[a_ad[0] + q * as4];
+                            pb[0][q] = smem[d_ad[0] + q * zs4];
+                        }
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < MAXT; sl++) {
+                        if (sl + 1 < MAXT && wave + (sl + 1) * nwaves < m.n_tiles) {
+                            const int as4 = 4 * (((a_is_act >> (sl + 1)) & 1ull) ? m.ld_a : m.ld_x);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                pa[(sl + 1) & 1][q] = smem[a_ad[(sl + 1) % MAXT] + q * as4];
+                                pb[(sl + 1) & 1][q] = smem[d_ad[(sl + 1) % MAXT] + q * zs4];
+                            }
+                        }
+                        if (wave + sl * nwaves < m.n_tiles) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) gacc[sl] = mfma16(pa[sl & 1][q], pb[sl & 1][q], gacc[sl]);
+                        }
+                    }
+                }
+                STAMP(4);
 #pragma unroll
                 for (int r = 0; r < MAXB; r++)
                     if (bz[r] >= 0) {
@@ -720,12 +861,14 @@ adjoint_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float
                     }
                 }
                 __syncthreads();
+                STAMP(5);
             }
 #pragma unroll
             for (int r = 0; r < MAXR; r++) lam[r] += xbs[r];
         }
     }
 
+    STAMP_FLUSH();
     // flush this tile's partial gradient and loss sums
     float* out = slab + (size_t)blockIdx.x * (m.n_params + 8);
 #pragma unroll
@@ -793,7 +936,7 @@ __global__ void __launch_bounds__(256) infer_kernel(DevModel m, PackInfo pk, con
             xs[c * m.ld_x + i] = ((19.65f + Tm / 20.0f) - m.mu_T) / m.sig_T;      // :156, T_scaling :158
         }
         __syncthreads();
-        mlp_forward<false>(m, pk, w, wf, xs, nullptr, A, wave, nwaves, lane);
+        mlp_forward<false, false>(m, pk, w, wf, xs, nullptr, A, wave, nwaves, lane);
         for (int it = tid; it < CT * Nz; it += nth) {
             const int c = it / Nz, i = it - c * Nz;
             if (col0 + c < n_col) {
@@ -810,20 +953,30 @@ __global__ void __launch_bounds__(256) infer_kernel(DevModel m, PackInfo pk, con
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (declared in engine_tile16.h)
 // ------------------------------------------------------------------------------------------------
-#define LAUNCH_ADJ(MT, NT, MR)                                                                                 \
-    hipLaunchKernelGGL((adjoint_kernel<MT, NT, MR>), dim3(n_tiles), dim3(NT), lds_bytes, stream, m, pk, w, wf, wb, \
+#define LAUNCH_ADJ(MT, NT, MR, WL)                                                                             \
+    hipLaunchKernelGGL((adjoint_kernel<MT, NT, MR, WL>), dim3(n_tiles), dim3(NT), lds_bytes, stream, m, pk, w, wf, wb, \
                        tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col)
 
-// (threads, dW tiles per wave, state items per thread) instantiations; the host picks the first that fits
-static const AdjointGeom kGeoms[] = {{256, 32, 6}, {256, 32, 12}, {512, 32, 6}, {512, 48, 3}};
+// (threads, dW tiles per wave, state items per thread, weights in LDS) instantiations; the host picks the first that fits
+static const AdjointGeom kGeoms[] = {{512, 16, 3, 1}, {256, 32, 6, 1}, {256, 32, 6, 0}, {256, 32, 12, 0},
+                                     {512, 32, 6, 0}, {512, 48, 3, 0}};
 
-bool pick_adjoint_geom(const DevModel& m, AdjointGeom* geo) {
+size_t lds_floats_adjoint_geom(const DevModel& m, const AdjointGeom& g) {
+    return MODEL_FLOATS + lds_floats_adjoint(m) + (g.wlds ? (size_t)((m.n_params + 3) & ~3) + 128 : 0);
+}
+
+bool pick_adjoint_geom(const DevModel& m, AdjointGeom* geo, int force) {
+    const size_t cap = 160 * 1024;
+    int idx = 0;
     for (const AdjointGeom& g : kGeoms) {
         const int nwaves = g.nthreads / 64;
-        if (m.n_tiles <= g.maxt * nwaves && CT * m.ns <= g.maxr * g.nthreads && m.n_bias <= MAXB * g.nthreads) {
+        const bool fits = m.n_tiles <= g.maxt * nwaves && CT * m.ns <= g.maxr * g.nthreads && m.n_bias <= MAXB * g.nthreads &&
+                          lds_floats_adjoint_geom(m, g) * sizeof(float) <= cap;
+        if (fits && (force < 0 || force == idx)) {
             *geo = g;
             return true;
         }
+        idx++;
     }
     return false;
 }
@@ -842,9 +995,16 @@ hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, con
 
 hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x0,
                           const float* bcs, const float* save_times, int n_save, int substeps, float* sol, float* tape,
-                          int n_col, int nthreads, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(forward_kernel, dim3((n_col + CT - 1) / CT), dim3(nthreads), lds_bytes, stream, m, pk, w, wf, x0, bcs,
-                       save_times, n_save, substeps, sol, tape, n_col);
+                          int n_col, int nthreads, bool wlds, size_t lds_bytes, hipStream_t stream) {
+    const dim3 grid((n_col + CT - 1) / CT);
+#define LAUNCH_FWD(WL, NT)                                                                                           \
+    hipLaunchKernelGGL((forward_kernel<WL, NT>), grid, dim3(NT), lds_bytes, stream, m, pk, w, wf, x0, bcs, save_times, \
+                       n_save, substeps, sol, tape, n_col)
+    if (wlds && nthreads == 512) LAUNCH_FWD(true, 512);
+    else if (wlds && nthreads == 256) LAUNCH_FWD(true, 256);
+    else if (!wlds && nthreads == 512) LAUNCH_FWD(false, 512);
+    else if (!wlds && nthreads == 256) LAUNCH_FWD(false, 256);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -860,10 +1020,12 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
                           const float* tape, const LossWeights& lw, float* slab, int n_col, const AdjointGeom& geo,
                           size_t lds_bytes, hipStream_t stream) {
     const int n_tiles = (n_col + CT - 1) / CT;
-    if (geo.nthreads == 256 && geo.maxt == 32 && geo.maxr == 6) LAUNCH_ADJ(32, 256, 6);
-    else if (geo.nthreads == 256 && geo.maxt == 32 && geo.maxr == 12) LAUNCH_ADJ(32, 256, 12);
-    else if (geo.nthreads == 512 && geo.maxt == 32 && geo.maxr == 6) LAUNCH_ADJ(32, 512, 6);
-    else if (geo.nthreads == 512 && geo.maxt == 48 && geo.maxr == 3) LAUNCH_ADJ(48, 512, 3);
+    if (geo.nthreads == 512 && geo.maxt == 16 && geo.maxr == 3 && geo.wlds) LAUNCH_ADJ(16, 512, 3, true);
+    else if (geo.nthreads == 256 && geo.maxt == 32 && geo.maxr == 6 && geo.wlds) LAUNCH_ADJ(32, 256, 6, true);
+    else if (geo.nthreads == 256 && geo.maxt == 32 && geo.maxr == 6) LAUNCH_ADJ(32, 256, 6, false);
+    else if (geo.nthreads == 256 && geo.maxt == 32 && geo.maxr == 12) LAUNCH_ADJ(32, 256, 12, false);
+    else if (geo.nthreads == 512 && geo.maxt == 32 && geo.maxr == 6) LAUNCH_ADJ(32, 512, 6, false);
+    else if (geo.nthreads == 512 && geo.maxt == 48 && geo.maxr == 3) LAUNCH_ADJ(48, 512, 3, false);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -884,15 +1046,33 @@ hipError_t launch_infer(const DevModel& m, const PackInfo& pk, const float* w, c
     return hipGetLastError();
 }
 
+hipError_t debug_read_stamps(unsigned long long* out16) {
+#ifdef COLNDE_STAMPS
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
+    if (e != hipSuccess) return e;
+    return hipMemcpyFromSymbol(out16 + 8, HIP_SYMBOL(g_fine), sizeof(unsigned long long) * 8);
+#else
+    for (int i = 0; i < 16; i++) out16[i] = 0;
+    return hipSuccess;
+#endif
+}
+
 hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     hipError_t e;
     const int v = (int)max_lds_bytes;
-    if ((e = hipFuncSetAttribute((const void*)rhs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)infer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)adjoint_kernel<32, 256, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)adjoint_kernel<32, 256, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)adjoint_kernel<32, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)adjoint_kernel<48, 512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e;
+#define SETATTR(K) if ((e = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e
+    SETATTR(rhs_kernel);
+    SETATTR(infer_kernel);
+    SETATTR((forward_kernel<true, 512>));
+    SETATTR((forward_kernel<true, 256>));
+    SETATTR((forward_kernel<false, 512>));
+    SETATTR((forward_kernel<false, 256>));
+    SETATTR((adjoint_kernel<16, 512, 3, true>));
+    SETATTR((adjoint_kernel<32, 256, 6, true>));
+    SETATTR((adjoint_kernel<32, 256, 6, false>));
+    SETATTR((adjoint_kernel<32, 256, 12, false>));
+    SETATTR((adjoint_kernel<32, 512, 6, false>));
+    SETATTR((adjoint_kernel<48, 512, 3, false>));
+#undef SETATTR
     return hipSuccess;
 }

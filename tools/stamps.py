@@ -1,0 +1,30 @@
+"""Diagnostic: per-phase cycle shares of one adjoint stage (workgroup 0, wave 0) from the -DCOLNDE_STAMPS build.
+Usage (GPU box): make -C climateparameterizations.jl_amd/csrc stamps && python tools/stamps.py"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import colnde
+from colnde import _lib, synthetic
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcolnde_stamps.so")
+L = _lib.lib()
+L.colnde_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
+ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 33
+p = synthetic.wind_mixing_problem(ncol, n_frames=frames)
+nde = colnde.ColumnNDE(p.cfg, ncol)
+nde.set_problem(p.x0, p.bcs)
+truth = nde.forward(p.weights_truth)
+nde.set_problem(p.x0, p.bcs, truth)
+nde.loss_grad(p.weights, [1, 1, 1, 5e-3, 5e-3, 5e-3])
+buf = (ctypes.c_ulonglong * 16)()
+_lib.check(L.colnde_debug_stamps(nde._h, buf))
+names = ["tape load + kbar", "mlp_forward", "physics_vjp", "mlp_backward", "dW tiles", "bias + xbar sum + barrier"]
+v = np.array(list(buf)[:6], dtype=np.float64)
+nstage = p.cfg.n_steps * 4
+for n, x in zip(names, v):
+    print("%-28s %10.0f cycles/stage  %5.1f %%" % (n, x / nstage, 100 * x / v.sum()))
+print("total %.0f cycles/stage" % (v.sum() / nstage))
+fine = np.array(list(buf)[8:13], dtype=np.float64)
+for n, x in zip(["layer setup", "job prologue (bias)", "MFMA chain", "epilogue (act + store)", "barrier"], fine):
+    print("  mlp_forward/%-24s %9.0f cycles/stage (all kernels' forward passes of wave 0)" % (n, x / nstage))
