@@ -7,3 +7,4 @@ from .config import (NDEConfig, ZeroMeanUnitVarianceScaling, WIND_MIXING, FREE_C
 from . import flux_compat, synthetic
 from ._lib import ColndeError, build as build_extension, LIB_PATH
 from .nde import ColumnNDE
+from . import distributed, wind_mixing, free_convection

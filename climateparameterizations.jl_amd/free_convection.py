@@ -1,0 +1,86 @@
+"""Host-side mirror of the reference's free-convection NDE interface (`FreeConvection` package).
+
+    FreeConvectionNDE / ConvectiveAdjustmentNDE(NN, ds; iterations)     free_convection/src/free_convection_nde.jl:1-47,
+                                                                        convective_adjustment_nde.jl:1-57   -> FreeConvectionNDE class
+    FreeConvectionNDEParameters(ds, T_scaling, wT_scaling)               free_convection_nde.jl:49-62        -> nde_params rows [bottom, top]
+    solve_nde(nde, NN, T₀, alg, nde_params)                              free_convection/src/solve.jl:1-6
+    nde_loss()  and the Flux.train! loop                                  free_convection/src/training.jl:44-74
+    compute_neural_network_forcing!                                       free_convection/double_gyre_nn.jl:149-168
+
+The Oceananigans `FieldDataset` wrangling and DataDeps download stay outside (network + foreign types).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from .config import NDEConfig, FREE_CONVECTION, CONVECTIVE_ADJUSTMENT_NDE
+from .flux_compat import ADAM
+from .nde import ColumnNDE
+
+
+class FreeConvectionNDE:
+    """One NDE per simulation in the reference (`ndes[id]`); here all simulations are columns of one handle."""
+
+    def __init__(self, cfg: NDEConfig, T0, nde_params, true_sols=None, device: int = 0):
+        if cfg.model not in (FREE_CONVECTION, CONVECTIVE_ADJUSTMENT_NDE):
+            raise ValueError("need a free-convection config")
+        self.cfg = cfg
+        T0 = np.ascontiguousarray(T0, dtype=np.float32)
+        self.n_simulations = T0.shape[0]
+        self.engine = ColumnNDE(cfg, self.n_simulations, device=device)
+        self.engine.set_problem(T0, np.ascontiguousarray(nde_params, dtype=np.float32), true_sols)
+
+    def dTdt(self, T, p, t=0.0):
+        """`∂T∂t(T, p, t)` with p = [weights; bottom_flux, top_flux, σ_T, σ_wT, H, τ] (free_convection_nde.jl:29-38);
+        the four trailing scalars must equal the config's (they are compile-time constants of the handle)."""
+        p = np.asarray(p, dtype=np.float32)
+        n = self.cfg.n_params
+        tail = p[n:]
+        c = self.cfg
+        expect = np.array([c.sigma[2], c.sigma[5], c.H, c.tau], dtype=np.float32)
+        if tail.shape[0] != 6 or not np.allclose(tail[2:], expect, rtol=1e-6):
+            raise ValueError("p tail must be [bottom, top, σ_T, σ_wT, H, τ] matching the handle's configuration")
+        T2 = np.atleast_2d(np.asarray(T, dtype=np.float32))
+        out = self.engine.rhs(T2, p[:n], np.broadcast_to(tail[None, :2], (T2.shape[0], 2)), float(t))
+        return out[0] if np.ndim(T) == 1 else out
+
+    def solve_nde(self, weights):
+        """`solve(nde, alg; reltol=1e-4, u0=T₀, p=[w; nde_params])` per simulation → [n_sims, Nz, Nt]."""
+        return np.transpose(self.engine.forward(weights), (0, 2, 1))
+
+    def nde_loss(self, weights) -> float:
+        """`Flux.mse(cat(nde_sols…), true_sols)` (training.jl:55-62)."""
+        total, _ = self.engine.loss(weights, [0, 0, 1, 0, 0, 0])
+        return total
+
+    def nde_loss_and_grad(self, weights):
+        total, _, grad = self.engine.loss_grad(weights, [0, 0, 1, 0, 0, 0])
+        return total, grad
+
+    def close(self):
+        self.engine.close()
+
+
+def train_neural_differential_equation(nde: FreeConvectionNDE, weights, opt: ADAM, epochs: int,
+                                       cb: Optional[Callable] = None):
+    """`Flux.train!(nde_loss, Flux.params(NN), repeated((), epochs), opt, cb)` (training.jl:71)."""
+    theta = np.array(weights, dtype=np.float32)
+    history: List[float] = []
+    for _ in range(epochs):
+        total, grad = nde.nde_loss_and_grad(theta)
+        history.append(total)
+        opt.update(theta, grad.astype(np.float64))
+        if cb is not None:
+            cb(theta, total)
+    return theta, history
+
+
+def compute_neural_network_forcing(engine: ColumnNDE, weights, T_interior, surface_flux, Lz: float):
+    """`compute_neural_network_forcing!` (double_gyre_nn.jl:149-168): T_interior [Nx, Ny, Nz] model units,
+    surface_flux [Nx, Ny]; returns the T-forcing array −∂z wT of the same shape."""
+    T = np.asarray(T_interior, dtype=np.float32)
+    nx, ny, nz = T.shape
+    out = engine.infer_forcing(weights, T.reshape(nx * ny, nz), np.asarray(surface_flux, np.float32).reshape(-1), Lz)
+    return out.reshape(nx, ny, nz)

@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's wind-mixing NDE interface (`WindMixing` package), over the HIP engine.
+
+Same names, argument meaning and return shapes as the Julia closures this path replaces:
+
+    NDE(x, p, t)                     wind_mixing/src/NDE_training.jl:56-81      out-of-place RHS, p = [weights; BCs]
+    NDE!(dx, x, p, t)  -> NDE_inplace  wind_mixing/src/training_postprocessing.jl:131-153
+    solve_NDE_nonmutating / solve_NDE_mutating                                NDE_training.jl:376-406, training_postprocessing.jl:55-159
+    loss_NDE(weights, BCs), loss_gradient_NDE(weights, BCs)                   NDE_training.jl:290-323
+        -> (total, scaled_losses{u,v,T,∂u∂z,∂v∂z,∂T∂z}, loss_scalings)
+    ∇loss  -> grad_loss(weights)      the pullback GalacticOptim obtains from Zygote (NDE_training.jl:327-333)
+    calculate_loss_scalings, apply_loss_scalings                               wind_mixing/src/loss.jl:11-42
+    train_NDE                                                                  NDE_training.jl:167-374 (optimiser loop :340-372)
+
+Data loading, JLD2 logging and plotting stay outside (out of scope).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from .config import NDEConfig, WIND_MIXING
+from .flux_compat import ADAM
+from .nde import ColumnNDE
+
+LOSS_KEYS = ("u", "v", "T", "dudz", "dvdz", "dTdz")
+
+
+def calculate_loss_scalings(losses, fractions, train_gradient: bool):
+    """wind_mixing/src/loss.jl:11-31.  `losses` in LOSS_KEYS order; `fractions` = dict(T, dTdz, profile)."""
+    Lu, Lv, LT, Lgu, Lgv, LgT = [float(x) for x in losses]
+    vel = (1 - fractions["T"]) / fractions["T"] * LT / (Lu + Lv)
+    profile_loss = vel * (Lu + Lv) + LT
+    if train_gradient:
+        velg = (1 - fractions["dTdz"]) / fractions["dTdz"] * LgT / (Lgu + Lgv)
+        gradient_loss = velg * (Lgu + Lgv) + LgT
+        tot = (1 - fractions["profile"]) / fractions["profile"] * profile_loss / gradient_loss
+    else:
+        velg = tot = 0.0
+    return np.array([vel, vel, 1.0, tot * velg, tot * velg, tot], dtype=np.float64)
+
+
+def apply_loss_scalings(losses, scalings):
+    """wind_mixing/src/loss.jl:33-42."""
+    return {k: float(s) * float(l) for k, s, l in zip(LOSS_KEYS, scalings, losses)}
+
+
+@dataclass
+class TrainResult:
+    weights: np.ndarray
+    history: List[dict]
+
+
+class WindMixingNDE:
+    """The closures `train_NDE` builds (NDE_training.jl:252-323) for one set of simulations (columns)."""
+
+    def __init__(self, cfg: NDEConfig, uvT0, BCs, uvT_trains=None, device: int = 0,
+                 gradient_scaling: float = 5e-3, training_fractions: Optional[dict] = None,
+                 weights0=None):
+        if cfg.model != WIND_MIXING:
+            raise ValueError("WindMixingNDE needs a wind-mixing config")
+        self.cfg = cfg
+        uvT0 = np.ascontiguousarray(uvT0, dtype=np.float32)
+        self.n_simulations = uvT0.shape[0]
+        self.BCs = np.ascontiguousarray(BCs, dtype=np.float32)
+        self.engine = ColumnNDE(cfg, self.n_simulations, device=device)
+        self.engine.set_problem(uvT0, self.BCs, uvT_trains)
+        self._rhs_engine = None
+        # determine_loss_scalings (NDE_training.jl:256-288)
+        if training_fractions is None:
+            g = gradient_scaling if cfg.train_gradient else 0.0
+            self.loss_scalings = np.array([1, 1, 1, g, g, g], dtype=np.float64)
+        else:
+            if weights0 is None:
+                raise ValueError("training_fractions needs the initial weights (one forward solve, NDE_training.jl:260)")
+            _, terms = self.engine.loss(weights0, [1, 1, 1, 1, 1, 1] if cfg.train_gradient else [1, 1, 1, 0, 0, 0])
+            self.loss_scalings = calculate_loss_scalings(terms, training_fractions, cfg.train_gradient)
+
+    # ---- RHS closures ---------------------------------------------------------------------------------
+    def _split_p(self, p):
+        p = np.asarray(p, dtype=np.float32)
+        n = self.cfg.n_params
+        if p.shape[-1] != n + 6:
+            raise ValueError("p must be [weights(%d); uw_b, uw_t, vw_b, vw_t, wT_b, wT_t]" % n)
+        return p[..., :n], p[..., n:]
+
+    def NDE(self, x, p, t):
+        """Out-of-place `NDE(x, p, t)`; x: [3Nz] (or [n, 3Nz] with p: [n_params+6] shared weights per row of BCs)."""
+        w, bc = self._split_p(p)
+        x2 = np.atleast_2d(np.asarray(x, dtype=np.float32))
+        bc2 = np.broadcast_to(np.atleast_2d(bc), (x2.shape[0], 6))
+        dx = self.engine.rhs(x2, w if w.ndim == 1 else w[0], bc2, float(t))
+        return dx[0] if np.ndim(x) == 1 else dx
+
+    def NDE_inplace(self, dx, x, p, t):
+        """`NDE!(dx, x, p, t)`: the evaluation RHS arithmetic (no ϵ in Ri; training_postprocessing.jl:105-153)."""
+        if self._rhs_engine is None:
+            self._rhs_engine = ColumnNDE(self.cfg.with_(inplace_variant=True), 1, device=self.engine.device)
+        w, bc = self._split_p(p)
+        x2 = np.atleast_2d(np.asarray(x, dtype=np.float32))
+        bc2 = np.broadcast_to(np.atleast_2d(bc), (x2.shape[0], 6))
+        out = self._rhs_engine.rhs(x2, w, bc2, float(t))
+        dx[...] = out[0] if np.ndim(x) == 1 else out
+        return None
+
+    # ---- solves ---------------------------------------------------------------------------------------
+    def solve_NDE_nonmutating(self, weights):
+        """`[Array(solve(prob_NDEs[i], …; p=[weights; BCs[i]], saveat=t_train)) for i in 1:n_simulations]`
+        (NDE_training.jl:403).  Returns [n_sims, 3Nz, Nt] — each `sols[i]` is the reference's 96×Nt array."""
+        return np.transpose(self.engine.forward(weights), (0, 2, 1))
+
+    # ---- losses ---------------------------------------------------------------------------------------
+    def loss_NDE(self, weights, BCs=None):
+        sc = self.loss_scalings.copy()
+        sc[3:] = 0.0                      # loss_NDE zeroes the gradient terms (NDE_training.jl:298)
+        total, terms = self.engine.loss(weights, sc)
+        return total, dict(zip(LOSS_KEYS, [float(t) for t in terms])), dict(zip(LOSS_KEYS, sc))
+
+    def loss_gradient_NDE(self, weights, BCs=None):
+        total, terms = self.engine.loss(weights, self.loss_scalings)
+        return total, dict(zip(LOSS_KEYS, [float(t) for t in terms])), dict(zip(LOSS_KEYS, self.loss_scalings))
+
+    def grad_loss(self, weights):
+        """∇loss: value and gradient of `first(loss(θ, BCs))` w.r.t. θ — what AutoZygote hands GalacticOptim."""
+        sc = self.loss_scalings.copy()
+        if not self.cfg.train_gradient:
+            sc[3:] = 0.0
+        total, terms, grad = self.engine.loss_grad(weights, sc)
+        return total, dict(zip(LOSS_KEYS, [float(t) for t in terms])), grad
+
+    def close(self):
+        self.engine.close()
+        if self._rhs_engine is not None:
+            self._rhs_engine.close()
+
+
+def train_NDE(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epochs: int = 1, maxiters: int = 500,
+              cb: Optional[Callable] = None) -> TrainResult:
+    """The optimiser loop of `train_NDE` (NDE_training.jl:340-372): for each optimiser and epoch run `maxiters`
+    iterations of {value+gradient, callback(θ, total, scaled_losses, loss_scalings), Flux.update!} and copy back
+    the best-loss θ (`res.minimizer`, :371)."""
+    theta = np.array(weights, dtype=np.float32)
+    history = []
+    for opt in optimizers:
+        for _ in range(epochs):
+            best, best_theta = np.inf, theta.copy()
+            for it in range(maxiters):
+                total, losses, grad = problem.grad_loss(theta)
+                history.append(dict(total=total, **losses))
+                if total < best:
+                    best, best_theta = total, theta.copy()
+                if cb is not None and cb(theta, total, losses, problem.loss_scalings):
+                    break
+                opt.update(theta, grad.astype(np.float64))
+            theta = best_theta
+    return TrainResult(theta, history)

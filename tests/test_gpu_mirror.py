@@ -1,0 +1,156 @@
+"""GPU tests of the host-side mirror (reference-named closures), the device-pointer twins, and size-independent
+properties at BASELINE-scale column counts where the oracle would take too long."""
+import numpy as np
+import pytest
+
+import colnde
+from colnde import synthetic
+from colnde.flux_compat import ADAM
+from colnde.wind_mixing import WindMixingNDE, train_NDE, calculate_loss_scalings
+from colnde.free_convection import FreeConvectionNDE, train_neural_differential_equation, compute_neural_network_forcing
+from oracle import nde_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-300)
+
+
+def test_wind_mixing_closures_match_oracle():
+    p = synthetic.wind_mixing_problem(5, n_frames=9, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    wm = WindMixingNDE(p.cfg, p.x0, p.bcs, truth)
+    # NDE(x, p, t) with p = [weights; BCs[i]]  (NDE_training.jl:56-66)
+    pvec = np.concatenate([p.weights, p.bcs[2]])
+    dx = wm.NDE(p.x0[2], pvec, 0.0)
+    assert _rel(dx, O.rhs(p.cfg, p.x0[2:3], p.bcs[2:3], p.weights)[0]) < 2e-5
+    # NDE!(dx, x, p, t) mutates dx and returns nothing (training_postprocessing.jl:131-153)
+    out = np.zeros(96, np.float32)
+    assert wm.NDE_inplace(out, p.x0[2], pvec, 0.0) is None
+    assert _rel(out, O.rhs(p.cfg.with_(inplace_variant=True), p.x0[2:3], p.bcs[2:3], p.weights)[0]) < 2e-5
+    sols = wm.solve_NDE_nonmutating(p.weights)
+    assert sols.shape == (5, 96, 9)                                   # each sols[i] is the reference's 96 x Nt array
+    ref = O.solve(p.cfg, p.x0, p.bcs, p.weights)
+    assert np.abs(np.transpose(sols, (0, 2, 1)) - ref).max() < 1e-4
+    tot, losses, scal = wm.loss_gradient_NDE(p.weights)
+    tref, terms_ref = O.loss(p.cfg, ref, truth, wm.loss_scalings)
+    assert np.isclose(tot, tref, rtol=2e-3) and set(losses) == {"u", "v", "T", "dudz", "dvdz", "dTdz"}
+    tot0, losses0, _ = wm.loss_NDE(p.weights)
+    assert losses0["dudz"] == 0 and np.isclose(tot0, sum(terms_ref[:3]), rtol=2e-3)
+    wm.close()
+
+
+def test_training_fractions_scalings_and_train_loop_reduce_loss():
+    p = synthetic.wind_mixing_problem(16, n_frames=9, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    fr = dict(T=0.8, dTdz=0.8, profile=0.5)                          # train_NDE.jl:110
+    wm = WindMixingNDE(p.cfg, p.x0, p.bcs, truth, training_fractions=fr, weights0=p.weights)
+    tot, losses, _ = wm.loss_gradient_NDE(p.weights)
+    # the identities of wind_mixing/test/test_training_scaling.jl:17-19 hold for the device-computed terms
+    assert np.isclose(losses["T"] / (losses["u"] + losses["v"]), fr["T"] / (1 - fr["T"]), rtol=1e-3)
+    assert np.isclose((losses["u"] + losses["v"] + losses["T"]) / (losses["dudz"] + losses["dvdz"] + losses["dTdz"]), 1.0, rtol=1e-3)
+    res = train_NDE(wm, p.weights, [ADAM(3e-4)], epochs=1, maxiters=8)
+    assert res.history[-1]["total"] < res.history[0]["total"]
+    wm.close()
+
+
+def test_free_convection_mirror_and_training():
+    p = synthetic.free_convection_problem(6, Nz=32, n_save=5, substeps=2, t_end=0.02)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    nde = FreeConvectionNDE(p.cfg, p.x0, p.bcs, truth)
+    c = p.cfg
+    pvec = np.concatenate([p.weights, p.bcs[1], [c.sigma[2], c.sigma[5], c.H, c.tau]]).astype(np.float32)
+    assert _rel(nde.dTdt(p.x0[1], pvec), O.rhs(c, p.x0[1:2], p.bcs[1:2], p.weights)[0]) < 2e-5
+    assert nde.solve_nde(p.weights).shape == (6, 32, 5)
+    l0 = nde.nde_loss(p.weights)
+    assert np.isclose(l0, O.loss(c, O.solve(c, p.x0, p.bcs, p.weights), truth, [0, 0, 1, 0, 0, 0])[0], rtol=2e-3)
+    theta, hist = train_neural_differential_equation(nde, p.weights, ADAM(1e-3), epochs=6)
+    assert hist[-1] < hist[0]
+    nde.close()
+
+
+def test_forcing_mirror_shape_and_values():
+    cfg, T, top, w = synthetic.inference_problem(8, 6)
+    with colnde.ColumnNDE(cfg, 48) as eng:
+        out = compute_neural_network_forcing(eng, w, T.reshape(8, 6, 32), top.reshape(8, 6), 1000.0)
+    assert out.shape == (8, 6, 32)
+    assert _rel(out.reshape(48, 32), O.infer_forcing(cfg, T, top, w, 1000.0)) < 1e-4
+
+
+def test_device_pointer_twins_match_host_entry_points():
+    import torch
+    p = synthetic.wind_mixing_problem(40, n_frames=5, weight_divisor=1e2)
+    dev = torch.device("cuda", 0)
+    with colnde.ColumnNDE(p.cfg, 40) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        truth_h = nde.forward(p.weights_truth)
+        nde.set_problem(p.x0, p.bcs, truth_h)
+        sc = [1, 1, 1, 5e-3, 5e-3, 5e-3]
+        tot_h, terms_h, grad_h = nde.loss_grad(p.weights, sc)
+        x0, bcs, w = (torch.from_numpy(a).to(dev) for a in (p.x0, p.bcs, p.weights))
+        nde.set_problem(x0, bcs, torch.from_numpy(truth_h).to(dev))
+        sol_d = nde.forward(w)
+        out = nde.loss_grad(w, sc)
+        dx_d = nde.rhs(x0, w, bcs, 0.0)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sol_d.cpu().numpy(), nde.forward(p.weights))
+        np.testing.assert_array_equal(out[:nde.n_params].cpu().numpy(), grad_h)     # deterministic reduction order
+        assert float(out[nde.n_params + 6]) == tot_h
+        np.testing.assert_array_equal(dx_d.cpu().numpy(), nde.rhs(p.x0, p.weights, p.bcs, 0.0))
+
+
+def test_gradient_is_run_to_run_bit_identical():
+    p = synthetic.wind_mixing_problem(100, n_frames=9, weight_divisor=1e2)
+    with colnde.ColumnNDE(p.cfg, 100) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        nde.set_problem(p.x0, p.bcs, nde.forward(p.weights_truth))
+        a = nde.loss_grad(p.weights, [1, 1, 1, 5e-3, 5e-3, 5e-3])
+        b = nde.loss_grad(p.weights, [1, 1, 1, 5e-3, 5e-3, 5e-3])
+    assert a[0] == b[0]
+    np.testing.assert_array_equal(a[2], b[2])
+
+
+# ---- size-independent properties at BASELINE scale (configs[1]: 4096 columns x 32 levels) -----------------
+def test_inertial_oscillation_4096_columns():
+    """Zero nets, nu = 0, zero boundary flux: (U, V) rotates by -f tau t, T constant — for every one of 4096 columns."""
+    p = synthetic.wind_mixing_problem(4096, n_frames=33, substeps=4, nu0=0.0, nu_minus=0.0)
+    cfg = p.cfg
+    s0 = [-cfg.mu[3 + k] / cfg.sigma[3 + k] for k in range(3)]
+    bcs = np.tile(np.array([s0[0], s0[0], s0[1], s0[1], s0[2], s0[2]], np.float32), (4096, 1))
+    with colnde.ColumnNDE(cfg, 4096) as nde:
+        nde.set_problem(p.x0, bcs)
+        sol = nde.forward(np.zeros(cfg.n_params, np.float32))
+    Nz = cfg.Nz
+    th = cfg.f * cfg.tau * cfg.save_times[-1]
+    U0, V0 = cfg.sigma[0] * p.x0[:, :Nz], cfg.sigma[1] * p.x0[:, Nz:2 * Nz]
+    np.testing.assert_allclose(cfg.sigma[0] * sol[:, -1, :Nz], U0 * np.cos(th) + V0 * np.sin(th), atol=2e-6)
+    np.testing.assert_allclose(cfg.sigma[1] * sol[:, -1, Nz:2 * Nz], -U0 * np.sin(th) + V0 * np.cos(th), atol=2e-6)
+    np.testing.assert_array_equal(sol[:, -1, 2 * Nz:], p.x0[:, 2 * Nz:])
+
+
+def test_heat_conservation_and_shard_additivity_4096_columns():
+    p = synthetic.wind_mixing_problem(4096, n_frames=9, weight_divisor=1e2)
+    cfg = p.cfg
+    s0 = [-cfg.mu[3 + k] / cfg.sigma[3 + k] for k in range(3)]
+    bcs = p.bcs.copy()
+    bcs[:, 4] = s0[2]
+    bcs[:, 5] = s0[2]                                   # zero heat flux at both boundaries
+    sc = [1, 1, 1, 5e-3, 5e-3, 5e-3]
+    with colnde.ColumnNDE(cfg, 4096) as nde:
+        nde.set_problem(p.x0, bcs)
+        sol = nde.forward(p.weights)
+        # column heat content is conserved by the telescoping flux divergence
+        assert np.abs(sol[:, -1, 64:].sum(axis=1) - p.x0[:, 64:].sum(axis=1)).max() < 2e-4
+        truth = nde.forward(p.weights_truth)
+        nde.set_problem(p.x0, bcs, truth)
+        tot, terms, grad = nde.loss_grad(p.weights, sc)
+    # two shards normalised by the global count add up to the global result (the multi-GPU contract)
+    parts = []
+    for lo, hi in ((0, 1500), (1500, 4096)):
+        with colnde.ColumnNDE(cfg, hi - lo) as sh:
+            sh.set_global_columns(4096)
+            sh.set_problem(p.x0[lo:hi], bcs[lo:hi], truth[lo:hi])
+            parts.append(sh.loss_grad(p.weights, sc))
+    assert np.isclose(parts[0][0] + parts[1][0], tot, rtol=1e-4)
+    assert _rel(parts[0][2] + parts[1][2], grad.astype(np.float64)) < 1e-4
