@@ -1,0 +1,97 @@
+# ColumnNDE.jl — thin `ccall` layer over libcolnde.so (include/colnde.h) that keeps the reference's call signatures.
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia (SURVEY §8c).  It mirrors, line for line, the
+# ctypes front-end that IS tested (climateparameterizations.jl_amd/nde.py, wind_mixing.py).
+module ColumnNDE
+
+using Flux, ChainRulesCore
+
+const libcolnde = get(ENV, "COLNDE_LIB", "libcolnde.so")
+
+# mirror of `colnde_config` (field order = include/colnde.h)
+Base.@kwdef mutable struct Config
+    model::Int32 = 0; Nz::Int32 = 32; n_layers::Int32 = 3
+    layer_sizes::NTuple{9,Int32} = (96, 50, 20, 31, 0, 0, 0, 0, 0)
+    activations::NTuple{8,Int32} = (2, 2, 0, 0, 0, 0, 0, 0)              # COLNDE_ACT_MISH, MISH, IDENTITY
+    modified_pacanowski_philander::Int32 = 1; convective_adjustment::Int32 = 0; zero_weights::Int32 = 1
+    smooth_NN::Int32 = 0; smooth_Ri::Int32 = 0; diurnal::Int32 = 0; train_gradient::Int32 = 1; inplace_variant::Int32 = 0
+    H::Float32 = 256; tau::Float32 = 172800; f::Float32 = 1f-4; g::Float32 = 9.81f0; alpha::Float32 = 1.67f-4
+    nu0::Float32 = 1f-4; nu_minus::Float32 = 1f-1; Ric::Float32 = 0.25f0; dRi::Float32 = 1f0; Pr::Float32 = 1f0
+    kappa::Float32 = 10f0; eps::Float32 = 1f-7
+    mu::NTuple{6,Float32} = (0, 0, 0, 0, 0, 0); sigma::NTuple{6,Float32} = (1, 1, 1, 1, 1, 1)
+    ca_K::Float32 = 10f0
+    n_save::Int32 = 2; substeps::Int32 = 2; save_times::Ptr{Float32} = C_NULL
+    n_columns::Int32 = 1; device::Int32 = 0; engine::Int32 = 0
+end
+
+check(rc) = rc == 0 || error(unsafe_string(ccall((:colnde_last_error, libcolnde), Cstring, ())))
+
+mutable struct Handle
+    ptr::Ptr{Cvoid}; n_params::Int; n_state::Int; n_save::Int; n_columns::Int
+end
+
+"constants/scalings/conditions as built by prepare_parameters_NDE_training (NDE_training.jl:1-44); t_train ./ τ as save_times"
+function Handle(cfg::Config, save_times::Vector{Float32})
+    cfg.n_save = length(save_times)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve save_times begin
+        cfg.save_times = pointer(save_times)
+        check(ccall((:colnde_create, libcolnde), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out))
+    end
+    h = Handle(out[], ccall((:colnde_n_params, libcolnde), Cint, (Ptr{Cvoid},), out[]),
+               cfg.model == 0 ? 3cfg.Nz : cfg.Nz, cfg.n_save, cfg.n_columns)
+    finalizer(x -> ccall((:colnde_destroy, libcolnde), Cvoid, (Ptr{Cvoid},), x.ptr), h)
+end
+
+"uvT₀s, BCs, uvT_trains of train_NDE (NDE_training.jl:220-243): one column per simulation"
+set_problem!(h::Handle, uvT₀s::Matrix{Float32}, BCs::Matrix{Float32}, uvT_trains::Union{Nothing,Array{Float32,3}}) =
+    check(ccall((:colnde_set_problem, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                h.ptr, uvT₀s, BCs, uvT_trains === nothing ? C_NULL : uvT_trains))   # Julia 96×n / 6×n / 96×Nt×n arrays ARE the C layouts
+
+"NDE(x, p, t) with p = [weights; BCs] — wind_mixing/src/NDE_training.jl:56-66"
+function NDE(h::Handle, x::Vector{Float32}, p::Vector{Float32}, t)
+    dx = similar(x)
+    NDE!(h, dx, x, p, t); dx
+end
+
+"NDE!(dx, x, p, t) — wind_mixing/src/training_postprocessing.jl:131-153 (create the handle with inplace_variant = 1)"
+function NDE!(h::Handle, dx, x, p, t)
+    w = @view p[1:h.n_params]; bc = @view p[h.n_params+1:end]
+    check(ccall((:colnde_rhs, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Ptr{Float32}, Cint),
+                h.ptr, x, w, bc, Float32(t), dx, 1))
+    nothing
+end
+
+"[Array(solve(prob_NDEs[i], …; p=[weights; BCs[i]], saveat=t_train)) for i in 1:n_simulations] — NDE_training.jl:291,403"
+function solve_NDE(h::Handle, weights::Vector{Float32})
+    sol = Array{Float32}(undef, h.n_state, h.n_save, h.n_columns)
+    check(ccall((:colnde_forward, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}), h.ptr, weights, sol))
+    [sol[:, :, i] for i in 1:h.n_columns]
+end
+
+const KEYS = (:u, :v, :T, :∂u∂z, :∂v∂z, :∂T∂z)
+
+"loss_NDE / loss_gradient_NDE(weights, BCs) — NDE_training.jl:290-323: (total, scaled_losses, loss_scalings)"
+function loss_gradient_NDE(h::Handle, weights, loss_scalings::NamedTuple)
+    sc = Float32[loss_scalings[k] for k in KEYS]; terms = zeros(Float32, 6); total = Ref{Float32}(0)
+    check(ccall((:colnde_loss, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ref{Float32}),
+                h.ptr, weights, sc, terms, total))
+    total[], NamedTuple{KEYS}(Tuple(terms)), loss_scalings
+end
+
+"∇loss: value and gradient in one call (replaces Zygote through InterpolatingAdjoint — NDE_training.jl:327-333)"
+function ∇loss(h::Handle, weights, loss_scalings::NamedTuple)
+    sc = Float32[loss_scalings[k] for k in KEYS]; terms = zeros(Float32, 6); total = Ref{Float32}(0)
+    grad = similar(weights)
+    check(ccall((:colnde_loss_grad, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ref{Float32}, Ptr{Float32}),
+                h.ptr, weights, sc, terms, total, grad))
+    total[], NamedTuple{KEYS}(Tuple(terms)), grad
+end
+
+# OptimizationFunction(loss, AutoZygote()) keeps working: the rrule routes the pullback to the HIP adjoint
+function ChainRulesCore.rrule(::typeof(loss_gradient_NDE), h::Handle, weights, loss_scalings)
+    total, losses, grad = ∇loss(h, weights, loss_scalings)
+    pullback(ȳ) = (NoTangent(), NoTangent(), ȳ[1] .* grad, NoTangent())
+    (total, losses, loss_scalings), pullback
+end
+
+end # module
