@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "engine_tile16.h"
+#include "engine_regtile.h"
 
 static thread_local std::string g_err;
 
@@ -47,6 +48,8 @@ struct colnde_handle {
     size_t lds_fwd = 0, lds_adj = 0, lds_fwd_solve = 0;
     int fwd_threads = 256;
     bool fwd_wlds = false;
+    bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
+    float* d_wimg = nullptr;
     float *d_w = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_x0 = nullptr, *d_bcs = nullptr, *d_truth = nullptr,
           *d_sol = nullptr, *d_tape = nullptr, *d_slab = nullptr, *d_out = nullptr, *d_times = nullptr,
           *d_partial = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
@@ -234,7 +237,13 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     if (h->lds_adj > lds_cap) h->geo_ok = false;
     {
         hipError_t e = set_kernel_attributes(lds_cap);
+        if (e == hipSuccess) e = rt_set_attributes();
         if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); }
+    }
+    h->use_rt = rt_supported(h->m) && cfg->engine != COLNDE_ENGINE_GENERIC;
+    if (cfg->engine == COLNDE_ENGINE_MFMA && !h->use_rt) {
+        delete h;
+        return fail("engine = regtile requested, but it covers only Nz=32, three 96-50-20-31 nets, no smoothing, training RHS");
     }
     const DevModel& m = h->m;
 #define ALLOC(ptr, n, T)                                                                   \
@@ -248,6 +257,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     ALLOC(h->d_w, m.n_params, float);
     ALLOC(h->d_wf, (size_t)h->pk.pf_net * m.n_nets, float);
     ALLOC(h->d_wb, (size_t)h->pk.pb_net * m.n_nets, float);
+    ALLOC(h->d_wimg, RT_IMG_FLOATS, float);
     ALLOC(h->d_x0, (size_t)h->n_col * m.ns, float);
     ALLOC(h->d_bcs, (size_t)h->n_col * m.n_bc, float);
     ALLOC(h->d_sol, (size_t)h->n_col * cfg->n_save * m.ns, float);
@@ -284,7 +294,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     drain_events(h);
-    void* ptrs[] = {h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
+    void* ptrs[] = {h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
                     h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -292,7 +302,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
 }
 
 extern "C" int colnde_n_params(const colnde_handle* h) { return h ? h->m.n_params : -1; }
-extern "C" int colnde_engine(const colnde_handle* h) { return h ? COLNDE_ENGINE_MFMA : -1; }
+extern "C" int colnde_engine(const colnde_handle* h) { return h ? (h->use_rt ? COLNDE_ENGINE_MFMA : COLNDE_ENGINE_GENERIC) : -1; }
 
 extern "C" int colnde_set_stream(colnde_handle* h, void* s) {
     if (!h) return fail("null handle");
@@ -438,6 +448,15 @@ extern "C" int colnde_rhs(colnde_handle* h, const float* x, const float* weights
 // ---- forward solve -------------------------------------------------------------------------------------
 static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape) {
     if (!h->have_problem) return fail("colnde_set_problem has not been called");
+    if (h->use_rt && !with_tape) {
+        hipError_t e = rt_launch_pack(h->m, d_weights, h->d_wimg, h->stream);
+        if (e != hipSuccess) return fail("rt pack launch failed: %s", hipGetErrorString(e));
+        Timed tm(h, K_FORWARD);
+        e = rt_launch_forward(h->m, h->d_wimg, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, d_sol, nullptr,
+                              h->n_col, h->stream);
+        if (e != hipSuccess) return fail("rt forward launch failed: %s", hipGetErrorString(e));
+        return 0;
+    }
     if (pack(h, d_weights)) return 1;
     if (with_tape && !h->d_tape) {
         const size_t n = (size_t)h->n_tiles * (h->cfg.n_save - 1) * h->cfg.substeps * 4 * CT * h->m.ns;

@@ -1,0 +1,29 @@
+// engine_regtile.h — register-resident tile engine for the static wind-mixing shape
+// (Nz = 32, three Chain(Dense(96,50,σ), Dense(50,20,σ), Dense(20,31)) nets: wind_mixing/train_NDE.jl:103).
+#pragma once
+#include "colnde_dev.h"
+#include "engine_tile16.h"
+
+#define RT_COLS 32                 // columns per wavefront tile (N of v_mfma_f32_32x32x2_f32)
+#define RT_WAVES 4                 // wavefronts per workgroup (one per SIMD, up to 512 VGPRs each)
+
+// compact weight image in LDS (floats): plain row-major matrices with odd row strides, so that both W (lane = output
+// row) and W^T (lane = input column) A-operand reads are bank-conflict-free with a per-lane base + immediate offset
+#define RT_LD1 97
+#define RT_LD2 51
+#define RT_LD3 21
+#define RT_W1C 0                                   // [150][97]   rows n*50+f, cols = input feature (col 96 zero)
+#define RT_W2C (150 * RT_LD1 + 2)                  // [60][51]    rows n*20+f, cols = a1 feature (col 50 zero)
+#define RT_W3C (RT_W2C + 60 * RT_LD2 + 1)          // [93][21]    rows n*31+f, cols = a2 feature (col 20 zero)
+#define RT_B1C (RT_W3C + 93 * RT_LD3 + 3)          // [160]       n*50+f, tail zero
+#define RT_B2C (RT_B1C + 160)                      // [64]        n*20+f, tail zero
+#define RT_B3C (RT_B2C + 64)                       // [96]        n*32+face (face 0 -> 0)
+#define RT_IMG_FLOATS (RT_B3C + 96)
+
+bool rt_supported(const DevModel& m);
+size_t rt_forward_lds_bytes();
+hipError_t rt_set_attributes();
+hipError_t rt_launch_pack(const DevModel& m, const float* w, float* wimg, hipStream_t stream);
+hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* x0, const float* bcs,
+                             const float* save_times, int n_save, int substeps, float* sol, float* tape, int n_col,
+                             hipStream_t stream);

@@ -1,0 +1,402 @@
+// engine_regtile.hip — register-resident tile engine for the static wind-mixing shape (gfx950 / CDNA4 only).
+//
+// One wavefront owns 32 columns.  Every quantity of a column lives in the MFMA 32x32 accumulator ("D") layout:
+// lane (j = lane & 31, h = lane >> 5) holds, in element r of a 16-float tile, row  rho(r, h) = (r&3) + 8(r>>2) + 4h
+// of column j.  With v_mfma_f32_32x32x2_f32 the B operand of k-step r is exactly element r of such a tile (K pair =
+// rows rho(r,0), rho(r,1)), so a layer's output feeds the next layer with NO lane movement, no LDS round trip and no
+// barrier: state [u;v;T] -> Dense(96,50) -> Dense(50,20) -> Dense(20,31) -> fluxes on faces, all in registers.
+// The A operand (weights) is read from one compact LDS image (plain row-major matrices with odd row strides) as
+// `per-lane base + compile-time immediate`: one ds_read_b32 per 64-cycle MFMA.  Vertical neighbours (the D^f / D^c
+// stencils) are the previous/next tile element, except every fourth level where they sit in the partner lane (lane^32).
+//
+// Row placement (chosen here, free because K order and output-row order of a GEMM are arbitrary):
+//   layer-1 outputs: the 3x50 features are stacked into 5 tiles; register G = 16*tile + r carries features
+//                    (2g, 2g+1) of net n, with n = G / 25, g = G % 25 (G >= 75: padding, never consumed);
+//   layer-2 outputs: registers r < 10 carry features (2r, 2r+1), the rest is padding;
+//   layer-3 outputs: row = face index (row 0 = bottom boundary face, where the NN contributes nothing).
+//
+// Reference arithmetic: wind_mixing/src/NDE_training.jl:46-165 (NDE, predict_flux, predict_NDE).
+#include "engine_regtile.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+#define RHO0(r) (((r) & 3) + 8 * ((r) >> 2))
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float swap32(float x) { return __shfl_xor(x, 32); }
+
+// tile value one level below (rho - 1); level -1 reads `below`
+__device__ __forceinline__ f32x16 shift_down(const f32x16 T, int h, float below) {
+    f32x16 o;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float send = h ? (g > 0 ? T[(4 * g + 15) & 15] : 0.0f) : T[4 * g + 3];   // h=1 sends T[4g-1], h=0 sends T[4g+3]
+        const float recv = swap32(send);
+        o[4 * g] = (h == 0 && g == 0) ? below : recv;
+        o[4 * g + 1] = T[4 * g];
+        o[4 * g + 2] = T[4 * g + 1];
+        o[4 * g + 3] = T[4 * g + 2];
+    }
+    return o;
+}
+
+// tile value one level above (rho + 1); level 32 reads `above`
+__device__ __forceinline__ f32x16 shift_up(const f32x16 T, int h, float above) {
+    f32x16 o;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float send = h ? T[4 * g] : (g < 3 ? T[(4 * g + 4) & 15] : 0.0f);         // h=1 sends T[4g], h=0 sends T[4g+4]
+        const float recv = swap32(send);
+        o[4 * g + 3] = (h == 1 && g == 3) ? above : recv;
+        o[4 * g] = T[4 * g + 1];
+        o[4 * g + 1] = T[4 * g + 2];
+        o[4 * g + 2] = T[4 * g + 3];
+    }
+    return o;
+}
+
+template <int ACT>
+__device__ __forceinline__ float rt_act(float z) {
+    if (ACT == COLNDE_ACT_RELU) return fmaxf(z, 0.0f);
+    if (ACT == COLNDE_ACT_MISH) {
+        const float e = __expf(fminf(z, 20.0f));
+        const float n = e * (e + 2.0f);
+        return z * __fdividef(n, n + 2.0f);
+    }
+    if (ACT == COLNDE_ACT_SWISH) return __fdividef(z, 1.0f + __expf(-z));
+    if (ACT == COLNDE_ACT_TANH) { const float e = __expf(2.0f * fminf(fmaxf(z, -15.0f), 15.0f)); return 1.0f - __fdividef(2.0f, 1.0f + e); }
+    if (ACT == COLNDE_ACT_LEAKYRELU) return z > 0.0f ? z : 0.01f * z;
+    return z;
+}
+
+template <int ACT>
+__device__ __forceinline__ f32x16 act_tile(f32x16 z) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = rt_act<ACT>(z[r]);
+    return o;
+}
+
+// per-lane A-operand bases into the LDS weight image
+struct RtBases {
+    int a1[5];   // layer 1, stacked tiles: row of tile mt for this lane's output row
+    int a2;      // layer 2
+    int a3;      // layer 3
+};
+
+__device__ __forceinline__ RtBases rt_bases(int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    const int r_i = (i & 3) + 4 * (i >> 3), h_i = (i >> 2) & 1;
+    RtBases b;
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++) {
+        const int G = min(mt * 16 + r_i, 74);                       // padding rows read a valid row; their output is never used
+        const int row = (G / 25) * 50 + 2 * (G % 25) + h_i;
+        b.a1[mt] = RT_W1C + row * RT_LD1 + 4 * h;
+    }
+    b.a2 = RT_W2C + ((r_i < 10) ? 2 * r_i + h_i : 0) * RT_LD2 + h;
+    b.a3 = RT_W3C + (i - 1) * RT_LD3 + h;                           // output row i = face i <- NN output i-1 (row 0 masked later)
+    return b;
+}
+
+// acc += sum_{s<N} A_s * B_s on the matrix pipe, with the A operands (one ds_read_b32 each) fetched one chunk of CH
+// k-steps ahead of their MFMAs.  The sched_barrier mask lets ALU work (e.g. the previous tile's activations) be
+// scheduled into the MFMA shadow but pins the DS reads to their region: left alone, the scheduler hoists hundreds of
+// operand reads and spills.
+#define RT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x00F)
+
+template <int N, int CH, class AF, class BF>
+__device__ __forceinline__ f32x16 rt_chain(const float* wl, f32x16 acc, AF aidx, BF bval) {
+    float a[2][CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++)
+        if (u < N) a[0][u] = wl[aidx(u)];
+    RT_SCHED_FENCE();
+#pragma unroll
+    for (int c = 0; c * CH < N; c++) {
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+            if ((c + 1) * CH + u < N) a[(c + 1) & 1][u] = wl[aidx((c + 1) * CH + u)];
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+            if (c * CH + u < N) acc = mfma32(a[c & 1][u], bval(c * CH + u), acc);
+        RT_SCHED_FENCE();
+    }
+    return acc;
+}
+
+// The three MLPs on the stage input X (3 tiles u, v, T) -> face-flux tiles O (3 tiles), all in registers.
+template <int ACT>
+__device__ __forceinline__ void rt_mlp_forward(const float* wl, const RtBases& b, const f32x16 (&X)[3], int h, f32x16 (&O)[3]) {
+    f32x16 A1[5];
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int G = mt * 16 + r;
+            acc[r] = wl[RT_B1C + (G < 75 ? (G / 25) * 50 + 2 * (G % 25) : 150 + 2 * (G - 75)) + h];
+        }
+        const int base = b.a1[mt];
+        acc = rt_chain<48, 8>(wl, acc, [=](int s) { return base + (s >> 4) * 32 + RHO0(s & 15); },
+                              [&](int s) { return X[s >> 4][s & 15]; });
+        A1[mt] = act_tile<ACT>(acc);
+    }
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = r < 10 ? wl[RT_B2C + n * 20 + 2 * r + h] : 0.0f;
+        const int base2 = b.a2 + n * 20 * RT_LD2;
+        acc = rt_chain<25, 8>(wl, acc, [=](int s) { return base2 + 2 * s; },
+                              [&](int s) { return A1[(25 * n + s) >> 4][(25 * n + s) & 15]; });
+        const f32x16 A2 = act_tile<ACT>(acc);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = wl[RT_B3C + n * 32 + RHO0(r) + 4 * h];
+        const int base3 = b.a3 + n * 31 * RT_LD3;
+        o = rt_chain<10, 10>(wl, o, [=](int s) { return base3 + 2 * s; }, [&](int s) { return A2[s]; });
+        O[n] = o;
+    }
+}
+
+struct RtBC { float b[3], t[3]; };   // scaled bottom / top fluxes of (uw, vw, wT) for this lane's column
+
+// K = RHS(X) given the NN face fluxes O  (predict_flux :104-147, predict_NDE :160-162; MPP / CA branches, zero_weights)
+__device__ __forceinline__ void rt_physics_forward(const DevModel& m, const f32x16 (&X)[3], const f32x16 (&O)[3],
+                                                   const RtBC& bc, int h, f32x16 (&K)[3]) {
+    const float Nz = 32.0f;
+    f32x16 F[3];
+    if (m.mpp || m.ca) {
+        const f32x16 Ud = shift_down(X[0], h, 0.0f), Vd = shift_down(X[1], h, 0.0f), Td = shift_down(X[2], h, 0.0f);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const bool in = !(r == 0 && h == 0);                   // face rho(r,h) >= 1 (face 0 is the bottom boundary)
+            const float gu = in ? (X[0][r] - Ud[r]) * Nz : 0.0f;
+            const float gv = in ? (X[1][r] - Vd[r]) * Nz : 0.0f;
+            const float gT = in ? (X[2][r] - Td[r]) * Nz : 0.0f;
+            float f0 = in ? O[0][r] : 0.0f, f1 = in ? O[1][r] : 0.0f, f2 = in ? O[2][r] : 0.0f;
+            if (!m.zero_w && !in) { f0 = bc.b[0]; f1 = bc.b[1]; f2 = bc.b[2]; }
+            if (m.mpp) {
+                if (in) {
+                    const float a1 = m.sig_u * (gu + m.eps), a2 = m.sig_v * (gv + m.eps);
+                    const float Ri = __fdividef(m.B * (gT + m.eps), a1 * a1 + a2 * a2);
+                    const float e = __expf(2.0f * fminf(fmaxf((Ri - m.Ric) * m.inv_dRi, -15.0f), 15.0f));
+                    const float th = 1.0f - __fdividef(2.0f, 1.0f + e);
+                    const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
+                    f0 -= m.cs[0] * nu * gu;
+                    f1 -= m.cs[1] * nu * gv;
+                    f2 -= m.cs[2] * (nu / m.Pr) * gT;
+                } else if (m.zero_w) {
+                    f0 += bc.b[0] - m.s0[0];
+                    f1 += bc.b[1] - m.s0[1];
+                    f2 += bc.b[2] - m.s0[2];
+                }
+            } else if (in) {
+                f2 -= m.cs[2] * m.kappa * fminf(0.0f, gT);
+            }
+            F[0][r] = f0; F[1][r] = f1; F[2][r] = f2;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const bool in = !(r == 0 && h == 0);
+            F[0][r] = in ? O[0][r] : bc.b[0];
+            F[1][r] = in ? O[1][r] : bc.b[1];
+            F[2][r] = in ? O[2][r] : bc.b[2];
+        }
+    }
+    // top boundary face (face Nz): zero_weights: 0 - (-(BC - s(0))) ; else the BC itself
+    float top[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) top[k] = m.zero_w ? bc.t[k] - m.s0[k] : bc.t[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const f32x16 Fu = shift_up(F[k], h, top[k]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = -m.A[k] * (Fu[r] - F[k][r]);
+            if (k == 0) v += m.cor_u * (m.sig_v * X[1][r] + m.mu_v);
+            if (k == 1) v -= m.cor_v * (m.sig_u * X[0][r] + m.mu_u);
+            K[k][r] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ float rt_top_flux(const DevModel& m, float bc5, float t) {
+    if (!m.diurnal) return bc5;
+    const float wq = bc5 * __sinf(6.283185307179586f / 86400.0f * (t * m.tau)) / m.alpha_g;
+    return (wq - m.mu_wT) / m.sig_wT;
+}
+
+extern __shared__ __attribute__((aligned(16))) float rt_smem[];
+
+// ------------------------------------------------------------------------------------------------
+// weight image
+// ------------------------------------------------------------------------------------------------
+__global__ void rt_pack_kernel(DevModel m, const float* __restrict__ w, float* __restrict__ img) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < RT_IMG_FLOATS; e += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (e < RT_W2C) {
+            const int row = e / RT_LD1, c = e - row * RT_LD1;
+            if (row < 150 && c < 96) { const int n = row / 50, f = row - n * 50; v = w[n * m.net_size + m.w_off[0] + c * 50 + f]; }
+        } else if (e < RT_W3C) {
+            const int q = e - RT_W2C, row = q / RT_LD2, c = q - row * RT_LD2;
+            if (row < 60 && c < 50) { const int n = row / 20, f = row - n * 20; v = w[n * m.net_size + m.w_off[1] + c * 20 + f]; }
+        } else if (e < RT_B1C) {
+            const int q = e - RT_W3C, row = q / RT_LD3, c = q - row * RT_LD3;
+            if (row < 93 && c < 20) { const int n = row / 31, f = row - n * 31; v = w[n * m.net_size + m.w_off[2] + c * 31 + f]; }
+        } else if (e < RT_B2C) {
+            const int q = e - RT_B1C;
+            if (q < 150) { const int n = q / 50, f = q - n * 50; v = w[n * m.net_size + m.b_off[0] + f]; }
+        } else if (e < RT_B3C) {
+            const int q = e - RT_B2C;
+            if (q < 60) { const int n = q / 20, f = q - n * 20; v = w[n * m.net_size + m.b_off[1] + f]; }
+        } else {
+            const int q = e - RT_B3C, n = q / 32, face = q - n * 32;
+            if (face >= 1) v = w[n * m.net_size + m.b_off[2] + face - 1];
+        }
+        img[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward solve (classical RK4); stage inputs -> tape in register-image order
+//   tape[((tile*n_steps + step)*4 + stage)*3072 + (q*4 + g)*256 + lane*4 + e] = X[q][4g + e]
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ void __launch_bounds__(256)
+rt_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
+                  const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
+                  float* __restrict__ tape, int n_col) {
+    float* wl = rt_smem;
+    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x * RT_WAVES + wave;
+    if (tile * RT_COLS >= n_col) return;                    // no barrier after this point: waves are independent
+    const int col = tile * RT_COLS + j;
+    const bool valid = col < n_col;
+    const int colc = min(col, n_col - 1);
+    const RtBases bases = rt_bases(lane);
+    RtBC bc;
+    float bc5;
+    {
+        const float* bp = bcs + (size_t)colc * 6;
+        bc.b[0] = bp[0]; bc.t[0] = bp[1]; bc.b[1] = bp[2]; bc.t[1] = bp[3]; bc.b[2] = bp[4]; bc5 = bp[5];
+        bc.t[2] = bc5;
+    }
+    f32x16 Xn[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(x0 + (size_t)colc * 96 + q * 32 + 8 * g + 4 * h);
+            Xn[q][4 * g] = v[0]; Xn[q][4 * g + 1] = v[1]; Xn[q][4 * g + 2] = v[2]; Xn[q][4 * g + 3] = v[3];
+            if (sol && valid) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + q * 32 + 8 * g + 4 * h) = v;
+        }
+    const int n_steps = (n_save - 1) * substeps;
+    float* tp = tape ? tape + (size_t)tile * n_steps * 4 * 3072 : nullptr;
+    int step = 0;
+    for (int iv = 0; iv < n_save - 1; iv++) {
+        const float t0 = save_times[iv];
+        const float dt = (save_times[iv + 1] - t0) / (float)substeps;
+        for (int s = 0; s < substeps; s++, step++) {
+            const float ts = t0 + (float)s * dt;
+            f32x16 Xs[3], Ks[3], Kacc[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) { Xs[q] = Xn[q]; Kacc[q] = Xn[q] - Xn[q]; }
+#pragma nounroll
+            for (int st = 0; st < 4; st++) {
+                const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);
+                const float cb = (st == 0 || st == 3) ? 1.0f / 6.0f : 1.0f / 3.0f;
+                if (st > 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) Xs[q] = Xn[q] + (ca * dt) * Ks[q];
+                }
+                if (tp) {
+                    float* o = tp + ((size_t)step * 4 + st) * 3072 + lane * 4;
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            f32x4v v = {Xs[q][4 * g], Xs[q][4 * g + 1], Xs[q][4 * g + 2], Xs[q][4 * g + 3]};
+                            *reinterpret_cast<f32x4v*>(o + (q * 4 + g) * 256) = v;
+                        }
+                }
+                bc.t[2] = rt_top_flux(m, bc5, ts + ca * dt);
+                f32x16 O[3];
+                rt_mlp_forward<ACT>(wl, bases, Xs, h, O);
+                rt_physics_forward(m, Xs, O, bc, h, Ks);
+#pragma unroll
+                for (int q = 0; q < 3; q++) Kacc[q] += cb * Ks[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) Xn[q] += dt * Kacc[q];
+            if (s == substeps - 1 && sol && valid) {
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        f32x4v v = {Xn[q][4 * g], Xn[q][4 * g + 1], Xn[q][4 * g + 2], Xn[q][4 * g + 3]};
+                        *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save + iv + 1) * 96 + q * 32 + 8 * g + 4 * h) = v;
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+bool rt_supported(const DevModel& m) {
+    return m.model == COLNDE_MODEL_WIND_MIXING && m.Nz == 32 && m.n_layers == 3 && m.sizes[0] == 96 && m.sizes[1] == 50 &&
+           m.sizes[2] == 20 && m.sizes[3] == 31 && m.acts[0] == m.acts[1] && m.acts[2] == COLNDE_ACT_IDENTITY &&
+           !m.smooth_NN && !m.smooth_Ri && !m.inplace;
+}
+
+size_t rt_forward_lds_bytes() { return (size_t)RT_IMG_FLOATS * sizeof(float); }
+
+hipError_t rt_set_attributes() {
+    hipError_t e;
+    const int v = 160 * 1024;
+#define RT_SETATTR(K) if ((e = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e
+    RT_SETATTR(rt_forward_kernel<COLNDE_ACT_IDENTITY>);
+    RT_SETATTR(rt_forward_kernel<COLNDE_ACT_RELU>);
+    RT_SETATTR(rt_forward_kernel<COLNDE_ACT_MISH>);
+    RT_SETATTR(rt_forward_kernel<COLNDE_ACT_SWISH>);
+    RT_SETATTR(rt_forward_kernel<COLNDE_ACT_TANH>);
+    RT_SETATTR(rt_forward_kernel<COLNDE_ACT_LEAKYRELU>);
+#undef RT_SETATTR
+    return hipSuccess;
+}
+
+hipError_t rt_launch_pack(const DevModel& m, const float* w, float* wimg, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_pack_kernel, dim3((RT_IMG_FLOATS + 255) / 256), dim3(256), 0, stream, m, w, wimg);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* x0, const float* bcs,
+                             const float* save_times, int n_save, int substeps, float* sol, float* tape, int n_col,
+                             hipStream_t stream) {
+    const int n_wtiles = (n_col + RT_COLS - 1) / RT_COLS;
+    const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
+    const size_t lds = rt_forward_lds_bytes();
+#define RT_FWD(A) hipLaunchKernelGGL(rt_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, n_col)
+    switch (m.acts[0]) {
+        case COLNDE_ACT_IDENTITY: RT_FWD(COLNDE_ACT_IDENTITY); break;
+        case COLNDE_ACT_RELU: RT_FWD(COLNDE_ACT_RELU); break;
+        case COLNDE_ACT_MISH: RT_FWD(COLNDE_ACT_MISH); break;
+        case COLNDE_ACT_SWISH: RT_FWD(COLNDE_ACT_SWISH); break;
+        case COLNDE_ACT_TANH: RT_FWD(COLNDE_ACT_TANH); break;
+        case COLNDE_ACT_LEAKYRELU: RT_FWD(COLNDE_ACT_LEAKYRELU); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RT_FWD
+    return hipGetLastError();
+}

@@ -1,7 +1,7 @@
 """Print VGPR/SGPR/scratch/spill counts per kernel from the engine's assembly (make -C csrc asm)."""
 import re, sys, os
-p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "climateparameterizations.jl_amd", "csrc", "_build", "engine_tile16.s")
-s = open(p).read()
+d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "climateparameterizations.jl_amd", "csrc", "_build")
+s = "".join(open(os.path.join(d, f)).read() for f in ("engine_tile16.s", "engine_regtile.s") if os.path.exists(os.path.join(d, f)))
 for b in s.split('  - .agpr_count:')[1:]:
     name = re.search(r'\.name:\s+(\S+)', b).group(1)
     g = lambda k: re.search(r'\.%s:\s+(\S+)' % k, b).group(1)
