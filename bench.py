@@ -150,6 +150,7 @@ def main():
     ms_fwd, n_fwd = nde.kernel_time("forward")
     ms_adj, n_adj = nde.kernel_time("adjoint")
     ms_red, n_red = nde.kernel_time("reduce")
+    ms_dw1, n_dw1 = nde.kernel_time("dw1")
     nde.set_profiling(False)
     res = out.cpu().numpy()
 
@@ -197,6 +198,8 @@ def main():
                                    "achieved": FWD_FLOP_PER_COLSTEP * units_per_launch / fwd_s / 1e12, "unit": "TFLOP/s",
                                    "hbm_GBps": ab["forward"] * units_per_launch / fwd_s / 1e9},
                 "reduce_kernel_avg_ms": ms_red / max(n_red, 1),
+                "dw1_kernel_avg_ms": ms_dw1 / max(n_dw1, 1),
+                "engine": {1: "tile16", 2: "regtile"}.get(nde.engine, str(nde.engine)),
             },
             "loss_total": float(res[nde.n_params + 6]),
             "grad_l2": float(np.linalg.norm(res[:nde.n_params])),

@@ -30,7 +30,7 @@ static int fail(const char* fmt, ...) {
         if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-enum { K_FORWARD = 0, K_ADJOINT = 1, K_REDUCE = 2, K_RHS = 3, K_INFER = 4, K_COUNT = 5 };
+enum { K_FORWARD = 0, K_ADJOINT = 1, K_REDUCE = 2, K_RHS = 3, K_INFER = 4, K_DW1 = 5, K_COUNT = 6 };
 
 struct PendingEvent { hipEvent_t a, b; int which; };
 
@@ -50,6 +50,8 @@ struct colnde_handle {
     bool fwd_wlds = false;
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
     float* d_wimg = nullptr;
+    float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr;
+    int rt_rows = 0;
     float *d_w = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_x0 = nullptr, *d_bcs = nullptr, *d_truth = nullptr,
           *d_sol = nullptr, *d_tape = nullptr, *d_slab = nullptr, *d_out = nullptr, *d_times = nullptr,
           *d_partial = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
@@ -59,8 +61,8 @@ struct colnde_handle {
     bool have_problem = false, have_truth = false;
     bool prof = false;
     std::vector<PendingEvent> pending;
-    double ms[K_COUNT] = {0, 0, 0, 0, 0};
-    int launches[K_COUNT] = {0, 0, 0, 0, 0};
+    double ms[K_COUNT] = {0, 0, 0, 0, 0, 0};
+    int launches[K_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 
 extern "C" const char* colnde_last_error(void) { return g_err.c_str(); }
@@ -294,7 +296,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     drain_events(h);
-    void* ptrs[] = {h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
+    void* ptrs[] = {h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
                     h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -448,12 +450,19 @@ extern "C" int colnde_rhs(colnde_handle* h, const float* x, const float* weights
 // ---- forward solve -------------------------------------------------------------------------------------
 static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape) {
     if (!h->have_problem) return fail("colnde_set_problem has not been called");
-    if (h->use_rt && !with_tape) {
+    if (h->use_rt) {
         hipError_t e = rt_launch_pack(h->m, d_weights, h->d_wimg, h->stream);
         if (e != hipSuccess) return fail("rt pack launch failed: %s", hipGetErrorString(e));
+        const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+        if (with_tape && !h->d_rt_tape) {
+            const size_t n1 = rt_tape_floats(h->n_col, n_steps), n2 = rt_tape2_floats(h->n_col, n_steps);
+            e = hipMalloc((void**)&h->d_rt_tape, n1 * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_tape2, n2 * sizeof(float));
+            if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tapes failed: %s", (n1 + n2) * sizeof(float), hipGetErrorString(e));
+        }
         Timed tm(h, K_FORWARD);
-        e = rt_launch_forward(h->m, h->d_wimg, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, d_sol, nullptr,
-                              h->n_col, h->stream);
+        e = rt_launch_forward(h->m, h->d_wimg, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, d_sol,
+                              with_tape ? h->d_rt_tape : nullptr, h->n_col, h->stream);
         if (e != hipSuccess) return fail("rt forward launch failed: %s", hipGetErrorString(e));
         return 0;
     }
@@ -525,11 +534,41 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
     if (!d_weights || !scalings || !d_out) return fail("null pointer argument");
     if (!h->have_truth) return fail("no truth trajectories: pass truth to colnde_set_problem");
     if (h->m.inplace) return fail("the in-place NDE! variant is an evaluation RHS; gradients use the training RHS (inplace_variant = 0)");
-    if (!h->geo_ok)
+    if (!h->geo_ok && !h->use_rt)
         return fail("network too large for the tile engine's adjoint: %d weight-gradient tiles, %zu B of LDS", h->m.n_tiles, h->lds_adj);
     HIPCHK(hipSetDevice(h->device));
     if (forward_impl(h, d_weights, h->d_sol, true)) return 1;
     const int stride = h->m.n_params + 8;
+    if (h->use_rt) {
+        const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+        const int n_wt = rt_n_wtiles(h->n_col), n_dw = rt_dw1_waves(h->n_col, n_steps);
+        if (!h->d_rt_slab) {
+            h->rt_rows = n_wt + n_dw;
+            hipError_t e = hipMalloc((void**)&h->d_rt_slab, (size_t)h->rt_rows * stride * sizeof(float));
+            if (e != hipSuccess) return fail("hipMalloc of the partial-gradient slab failed: %s", hipGetErrorString(e));
+        }
+        LossWeights lw;
+        loss_weights(h, scalings, &lw);
+        HIPCHK(hipMemsetAsync(h->d_rt_slab, 0, (size_t)h->rt_rows * stride * sizeof(float), h->stream));
+        {
+            Timed tm(h, K_ADJOINT);
+            hipError_t e = rt_launch_adjoint(h->m, h->d_wimg, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol,
+                                             h->d_truth, h->d_rt_tape, h->d_rt_tape2, lw, h->d_rt_slab, h->n_col, h->stream);
+            if (e != hipSuccess) return fail("rt adjoint launch failed: %s", hipGetErrorString(e));
+        }
+        {
+            Timed tm(h, K_DW1);
+            hipError_t e = rt_launch_dw1(h->m, h->d_rt_tape, h->d_rt_tape2, h->n_col, n_steps,
+                                         h->d_rt_slab + (size_t)n_wt * stride, h->stream);
+            if (e != hipSuccess) return fail("rt dW1 launch failed: %s", hipGetErrorString(e));
+        }
+        {
+            Timed tm(h, K_REDUCE);
+            hipError_t e = launch_reduce(h->d_rt_slab, h->rt_rows, h->m.n_params, stride, lw, d_out, h->stream);
+            if (e != hipSuccess) return fail("reduce launch failed: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
     if (!h->d_slab) {
         hipError_t e = hipMalloc((void**)&h->d_slab, (size_t)h->n_tiles * stride * sizeof(float));
         if (e != hipSuccess) return fail("hipMalloc of the partial-gradient slab failed: %s", hipGetErrorString(e));

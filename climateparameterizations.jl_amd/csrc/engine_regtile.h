@@ -27,3 +27,13 @@ hipError_t rt_launch_pack(const DevModel& m, const float* w, float* wimg, hipStr
 hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* x0, const float* bcs,
                              const float* save_times, int n_save, int substeps, float* sol, float* tape, int n_col,
                              hipStream_t stream);
+size_t rt_adjoint_lds_bytes();
+size_t rt_tape_floats(int n_col, int n_steps);
+size_t rt_tape2_floats(int n_col, int n_steps);
+int rt_n_wtiles(int n_col);
+int rt_dw1_waves(int n_col, int n_steps);
+hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,
+                             int substeps, const float* sol, const float* truth, const float* tape, float* tape2,
+                             const LossWeights& lw, float* slab, int n_col, hipStream_t stream);
+hipError_t rt_launch_dw1(const DevModel& m, const float* tape, const float* tape2, int n_col, int n_steps, float* slab_rows,
+                         hipStream_t stream);

@@ -352,6 +352,445 @@ rt_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// adjoint (back-propagation through the RK4 stages), register-resident
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float rt_act_grad(float z) {
+    if (ACT == COLNDE_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
+    if (ACT == COLNDE_ACT_MISH) {
+        const float e = __expf(fminf(z, 20.0f));
+        const float n = e * (e + 2.0f);
+        const float t = __fdividef(n, n + 2.0f);
+        const float sg = __fdividef(e, 1.0f + e);
+        return t + z * (1.0f - t * t) * sg;
+    }
+    if (ACT == COLNDE_ACT_SWISH) { const float sg = __fdividef(1.0f, 1.0f + __expf(-z)); return sg + z * sg * (1.0f - sg); }
+    if (ACT == COLNDE_ACT_TANH) { const float e = __expf(2.0f * fminf(fmaxf(z, -15.0f), 15.0f)); const float t = 1.0f - __fdividef(2.0f, 1.0f + e); return 1.0f - t * t; }
+    if (ACT == COLNDE_ACT_LEAKYRELU) return z > 0.0f ? 1.0f : 0.01f;
+    return 1.0f;
+}
+
+// Pullback of rt_physics_forward for the stage cotangent kb: dO = cotangent of the NN face fluxes (0 on face 0),
+// xb = physics part of the state cotangent (flux-divergence transpose + Coriolis).
+__device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (&X)[3], const f32x16 (&kb)[3], int h,
+                                               f32x16 (&dO)[3], f32x16 (&xb)[3]) {
+    const float Nz = 32.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const f32x16 kd = shift_down(kb[k], h, 0.0f);
+#pragma unroll
+        for (int r = 0; r < 16; r++) dO[k][r] = (r == 0 && h == 0) ? 0.0f : m.A[k] * (kb[k][r] - kd[r]);
+    }
+    f32x16 gb[3];
+    if (m.mpp) {
+        const f32x16 Ud = shift_down(X[0], h, 0.0f), Vd = shift_down(X[1], h, 0.0f), Td = shift_down(X[2], h, 0.0f);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const bool in = !(r == 0 && h == 0);
+            const float gu = (X[0][r] - Ud[r]) * Nz, gv = (X[1][r] - Vd[r]) * Nz, gT = (X[2][r] - Td[r]) * Nz;
+            const float a1 = m.sig_u * (gu + m.eps), a2 = m.sig_v * (gv + m.eps);
+            const float S2 = a1 * a1 + a2 * a2;
+            const float Ri = __fdividef(m.B * (gT + m.eps), S2);
+            const float e = __expf(2.0f * fminf(fmaxf((Ri - m.Ric) * m.inv_dRi, -15.0f), 15.0f));
+            const float th = 1.0f - __fdividef(2.0f, 1.0f + e);
+            const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
+            const float D0 = -dO[0][r], D1 = -dO[1][r], D2 = -dO[2][r];
+            float g0 = D0 * m.cs[0] * nu, g1 = D1 * m.cs[1] * nu, g2 = D2 * m.cs[2] * nu / m.Pr;
+            const float nub = D0 * m.cs[0] * gu + D1 * m.cs[1] * gv + D2 * m.cs[2] * gT / m.Pr;
+            const float ribs = nub * (-m.nu_minus / (2.0f * m.dRi)) * (1.0f - th * th);
+            g2 += __fdividef(ribs * m.B, S2);
+            const float q = __fdividef(ribs * -Ri, S2) * 2.0f;
+            g0 += q * m.sig_u * m.sig_u * (gu + m.eps);
+            g1 += q * m.sig_v * m.sig_v * (gv + m.eps);
+            gb[0][r] = in ? g0 : 0.0f;
+            gb[1][r] = in ? g1 : 0.0f;
+            gb[2][r] = in ? g2 : 0.0f;
+        }
+    } else {
+        const f32x16 Td = shift_down(X[2], h, 0.0f);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const bool in = !(r == 0 && h == 0);
+            const float gT = (X[2][r] - Td[r]) * Nz;
+            gb[0][r] = 0.0f;
+            gb[1][r] = 0.0f;
+            gb[2][r] = (m.ca && in && gT < 0.0f) ? -dO[2][r] * m.cs[2] * m.kappa : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const f32x16 gu_ = shift_up(gb[k], h, 0.0f);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = (gb[k][r] - gu_[r]) * Nz;
+            if (k == 0) v += -m.cor_v * m.sig_u * kb[1][r];
+            if (k == 1) v += m.cor_u * m.sig_v * kb[0][r];
+            xb[k][r] = v;
+        }
+    }
+}
+
+// LDS transposition buffer (one 32 x 33 float tile per wave): a D-layout tile (lane = column) becomes the MFMA operand of
+// a product contracted over the 32 columns (lane = row, k-step s = columns 2s, 2s+1)
+__device__ __forceinline__ f32x16 rt_transpose(float* tb, const f32x16 T, int wbase, int rbase) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) tb[wbase + RHO0(r) * 33] = T[r];
+    f32x16 o;
+#pragma unroll
+    for (int s = 0; s < 16; s++) o[s] = tb[rbase + 2 * s];
+    return o;
+}
+
+__device__ __forceinline__ f32x16 rt_outer(f32x16 acc, const f32x16 TA, const f32x16 TB) {
+#pragma unroll
+    for (int s = 0; s < 16; s++) acc = mfma32(TA[s], TB[s], acc);
+    return acc;
+}
+
+__device__ __forceinline__ float rt_sum16(const f32x16 v) {
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s += v[r];
+    return s;
+}
+
+// which nets own registers of layer-1 tile mt (register G = 16 mt + r belongs to net G / 25)
+#define RT_NET_LO(mt) (((mt) * 16) / 25)
+#define RT_NET_HI(mt) ((((mt) * 16 + 15) < 75 ? ((mt) * 16 + 15) : 74) / 25)
+// index of the (net, tile) weight-gradient accumulator: combos (0,0) (0,1) (1,1) (1,2) (1,3) (2,3) (2,4)
+__host__ __device__ constexpr int rt_combo(int n, int mt) { return n == 0 ? mt : (n == 1 ? 1 + mt : 2 + mt); }
+
+// tape of stage inputs (written by rt_forward_kernel):  [tile][step][stage][12 groups][64 lanes][4]
+// tape2 of layer-1 deltas (written here, read by rt_dw1_kernel): [tile][step][stage][19 groups][64 lanes][4], register G = 4 grp + e
+template <int ACT>
+__global__ void __launch_bounds__(256)
+rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ bcs,
+                  const float* __restrict__ save_times, int n_save, int substeps, const float* __restrict__ sol,
+                  const float* __restrict__ truth, const float* __restrict__ tape, float* __restrict__ tape2,
+                  LossWeights lw, float* __restrict__ slab, int n_col) {
+    float* wl = rt_smem;
+    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x * RT_WAVES + wave;
+    if (tile * RT_COLS >= n_col) return;
+    float* lam = rt_smem + RT_IMG_FLOATS + wave * (3072 + 1056);      // λ: [48][64] floats, wave-private
+    float* tb = lam + 3072;                                            // transposition tile [32][33]
+    const int col = tile * RT_COLS + j;
+    const bool valid = col < n_col;
+    const int i_ = lane & 31, r_i = (i_ & 3) + 4 * (i_ >> 3), h_i = (i_ >> 2) & 1;
+    const RtBases bases = rt_bases(lane);
+    // transposed-product bases
+    const int f2c = (r_i < 10) ? 2 * r_i + h_i : 20;                                   // a2 feature of output row i_ (20 = zero column)
+    const int b3T = RT_W3C + (4 * h - 1) * RT_LD3 + f2c;
+    int b2T[7];
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+        for (int n = RT_NET_LO(mt); n <= RT_NET_HI(mt); n++) {
+            const int G = mt * 16 + r_i;
+            const int f1c = (G >= 25 * n && G < 25 * n + 25) ? 2 * (G - 25 * n) + h_i : 50;   // 50 = zero column
+            b2T[rt_combo(n, mt)] = RT_W2C + h * RT_LD2 + f1c;
+        }
+    const int b1T = RT_W1C + h * RT_LD1 + i_;
+    const int wbase = 4 * h * 33 + j, rbase = i_ * 33 + h;
+
+    f32x16 gW3[3], gW2[7];
+#pragma unroll
+    for (int q = 0; q < 3; q++) gW3[q] = (f32x16)(0.0f);
+#pragma unroll
+    for (int q = 0; q < 7; q++) gW2[q] = (f32x16)(0.0f);
+    float b2acc[3] = {0, 0, 0}, b3acc[3] = {0, 0, 0};
+    float sums[6] = {0, 0, 0, 0, 0, 0};
+    f32x16 xb[3], xbs[3], X[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { xb[q] = (f32x16)(0.0f); xbs[q] = (f32x16)(0.0f); }
+#pragma unroll
+    for (int e = 0; e < 48; e++) lam[e * 64 + lane] = 0.0f;
+
+    const int n_steps = (n_save - 1) * substeps;
+    const float* tp = tape + (size_t)tile * n_steps * 4 * 3072 + lane * 4;
+    float* tp2 = tape2 + (size_t)tile * n_steps * 4 * 4864 + lane * 4;
+
+    // loss injection at save point n: λ += ∂loss/∂sol[:, n]; also the six raw sums of squares
+    auto inject = [&](int n, bool add) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            f32x16 d;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const size_t o = ((size_t)min(col, n_col - 1) * n_save + n) * 96 + q * 32 + 8 * g + 4 * h;
+                const f32x4v a = *reinterpret_cast<const f32x4v*>(sol + o);
+                const f32x4v b = *reinterpret_cast<const f32x4v*>(truth + o);
+#pragma unroll
+                for (int e = 0; e < 4; e++) d[4 * g + e] = valid ? a[e] - b[e] : 0.0f;
+            }
+            const f32x16 dd = shift_down(d, h, 0.0f);
+            f32x16 gg;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                gg[r] = (r == 0 && h == 0) ? 0.0f : (d[r] - dd[r]) * 32.0f;
+                sums[q] += d[r] * d[r];
+                sums[3 + q] += gg[r] * gg[r];
+            }
+            if (add) {
+                const f32x16 gu_ = shift_up(gg, h, 0.0f);
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    lam[(q * 16 + r) * 64 + lane] += 2.0f * lw.w[q] * d[r] + 2.0f * lw.w[3 + q] * 32.0f * (gg[r] - gu_[r]);
+            }
+        }
+    };
+    inject(0, false);
+
+    // stage input of the very first stage handled (last step, stage 3)
+    {
+        const float* src = tp + ((size_t)n_steps * 4 - 1) * 3072;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4v v = *reinterpret_cast<const f32x4v*>(src + (q * 4 + g) * 256);
+                X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
+            }
+    }
+
+    for (int iv = n_save - 2; iv >= 0; iv--) {
+        const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
+        inject(iv + 1, true);
+        for (int s = substeps - 1; s >= 0; s--) {
+            const int step = iv * substeps + s;
+#pragma nounroll
+            for (int st = 3; st >= 0; st--) {
+                const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
+                const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
+                // (1) stage cotangent and the physics pullback
+                f32x16 dO[3];
+                {
+                    f32x16 kb[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) kb[q][r] = cwl * lam[(q * 16 + r) * 64 + lane] + cwx * xb[q][r];
+                    rt_physics_vjp(m, X, kb, h, dO, xb);
+                }
+                // (2) forward recompute of the hidden pre-activations (layer 3 is not needed: it enters linearly)
+                f32x16 Z1[5], Z2[3];
+#pragma unroll
+                for (int mt = 0; mt < 5; mt++) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int G = mt * 16 + r;
+                        acc[r] = wl[RT_B1C + (G < 75 ? (G / 25) * 50 + 2 * (G % 25) : 150 + 2 * (G - 75)) + h];
+                    }
+                    const int base = bases.a1[mt];
+                    Z1[mt] = rt_chain<48, 8>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
+                                             [&](int k) { return X[k >> 4][k & 15]; });
+                }
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = r < 10 ? wl[RT_B2C + n * 20 + 2 * r + h] : 0.0f;
+                    const int base2 = bases.a2 + n * 20 * RT_LD2;
+                    Z2[n] = rt_chain<25, 5>(wl, acc, [=](int k) { return base2 + 2 * k; },
+                                            [&](int k) { return rt_act<ACT>(Z1[(25 * n + k) >> 4][(25 * n + k) & 15]); });
+                }
+                // (3) layer 3: weight/bias gradient, then dZ2 = (W3^T dO) .* act'(Z2)
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    const f32x16 TA = rt_transpose(tb, dO[n], wbase, rbase);
+                    b3acc[n] += rt_sum16(TA);
+                    const f32x16 TB = rt_transpose(tb, act_tile<ACT>(Z2[n]), wbase, rbase);
+                    gW3[n] = rt_outer(gW3[n], TA, TB);
+                    const int base = b3T + n * 31 * RT_LD3;
+                    f32x16 da = rt_chain<16, 8>(wl, (f32x16)(0.0f), [=](int k) { return base + RHO0(k) * RT_LD3; },
+                                                [&](int k) { return dO[n][k]; });
+#pragma unroll
+                    for (int r = 0; r < 16; r++) Z2[n][r] = r < 10 ? da[r] * rt_act_grad<ACT>(Z2[n][r]) : 0.0f;
+                }
+                // (4) layer 2: weight/bias gradient
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    const f32x16 TA = rt_transpose(tb, Z2[n], wbase, rbase);
+                    b2acc[n] += rt_sum16(TA);
+#pragma unroll
+                    for (int mt = 0; mt < 5; mt++)
+                        if (n >= RT_NET_LO(mt) && n <= RT_NET_HI(mt)) {
+                            const f32x16 TB = rt_transpose(tb, act_tile<ACT>(Z1[mt]), wbase, rbase);
+                            gW2[rt_combo(n, mt)] = rt_outer(gW2[rt_combo(n, mt)], TA, TB);
+                        }
+                }
+                // (5) dZ1 = (W2^T dZ2) .* act'(Z1), in place; taped for the streaming dW1 kernel
+#pragma unroll
+                for (int mt = 0; mt < 5; mt++) {
+                    f32x16 da = (f32x16)(0.0f);
+#pragma unroll
+                    for (int n = RT_NET_LO(mt); n <= RT_NET_HI(mt); n++) {
+                        const int base = b2T[rt_combo(n, mt)] + n * 20 * RT_LD2;
+                        da = rt_chain<10, 10>(wl, da, [=](int k) { return base + 2 * k * RT_LD2; },
+                                              [&](int k) { return Z2[n][k]; });
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) Z1[mt][r] = (mt * 16 + r < 75) ? da[r] * rt_act_grad<ACT>(Z1[mt][r]) : 0.0f;
+                }
+                {
+                    float* dst = tp2 + ((size_t)step * 4 + st) * 4864;
+#pragma unroll
+                    for (int grp = 0; grp < 19; grp++) {
+                        const f32x4v v = {Z1[grp >> 2][(grp & 3) * 4], Z1[grp >> 2][(grp & 3) * 4 + 1],
+                                          Z1[grp >> 2][(grp & 3) * 4 + 2], Z1[grp >> 2][(grp & 3) * 4 + 3]};
+                        *reinterpret_cast<f32x4v*>(dst + grp * 256) = v;
+                    }
+                }
+                // (6) next stage's input is fetched while the W1^T products run
+                {
+                    const int qn = step * 4 + st - 1;
+                    if (qn >= 0) {
+                        const float* src = tp + (size_t)qn * 3072;
+#pragma unroll
+                        for (int q = 0; q < 3; q++)
+#pragma unroll
+                            for (int g = 0; g < 4; g++) {
+                                const f32x4v v = *reinterpret_cast<const f32x4v*>(src + (q * 4 + g) * 256);
+                                X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
+                            }
+                    }
+                }
+                // (7) x̄ += W1^T dZ1
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int base = b1T + q * 32;
+                    xb[q] = rt_chain<75, 8>(wl, xb[q], [=](int G) { return base + ((G / 25) * 50 + 2 * (G % 25)) * RT_LD1; },
+                                            [&](int G) { return Z1[G >> 4][G & 15]; });
+                    xbs[q] += xb[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) lam[(q * 16 + r) * 64 + lane] += xbs[q][r];
+                xbs[q] = (f32x16)(0.0f);
+            }
+        }
+    }
+
+    // ---- flush this wave's partial gradients (row `tile` of the slab; dW1/db1 come from rt_dw1_kernel) ----
+    float* out = slab + (size_t)tile * (m.n_params + 8);
+    const int r_j = (j & 3) + 4 * (j >> 3), h_j = (j >> 2) & 1;     // this lane as a column index n' of a D tile
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+        // dW3_n[out = face-1][in = f2]: D[m = face rho(r,h)][n' = a2 row j]
+        if (r_j < 10) {
+            const int f2 = 2 * r_j + h_j;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int face = RHO0(r) + 4 * h;
+                if (face >= 1) out[n * m.net_size + m.w_off[2] + f2 * 31 + face - 1] = gW3[n][r];
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 5; mt++)
+            if (n >= RT_NET_LO(mt) && n <= RT_NET_HI(mt)) {
+                // dW2_n[out = f2 = 2r+h][in = f1]: D[m = z2 row rho(r,h)][n' = a1 tile row j]
+                const int G = mt * 16 + r_j;
+                if (G >= 25 * n && G < 25 * n + 25) {
+                    const int f1 = 2 * (G - 25 * n) + h_j;
+#pragma unroll
+                    for (int r = 0; r < 10; r++) out[n * m.net_size + m.w_off[1] + f1 * 20 + 2 * r + h] = gW2[rt_combo(n, mt)][r];
+                }
+            }
+        // biases: lanes (i, 0) and (i, 1) hold the even / odd column halves of row i_
+        const float s2 = b2acc[n] + swap32(b2acc[n]), s3 = b3acc[n] + swap32(b3acc[n]);
+        if (h == 0) {
+            if (r_i < 10) out[n * m.net_size + m.b_off[1] + 2 * r_i + h_i] = s2;
+            if (i_ >= 1) out[n * m.net_size + m.b_off[2] + i_ - 1] = s3;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        float v = sums[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) out[m.n_params + q] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW1 / db1: a streaming GEMM over the two tapes, contracted over (column, step, stage)
+//   dW1[n*50+f][c] = sum dZ1[(n,f)][col] * X[c][col]
+// Each wave walks items (tile, step, stage), transposes the two register images through LDS and accumulates all
+// 15 (layer-1 tile, state tile) products in registers; its partial result is one slab row.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restrict__ tape2, long n_items,
+              float* __restrict__ slab_rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* tb = rt_smem + wave * 1056;
+    const int wbase = 4 * h * 33 + j, rbase = j * 33 + h;
+    const long gw = (long)blockIdx.x * RT_WAVES + wave, GW = (long)gridDim.x * RT_WAVES;
+    f32x16 gW1[5][3];
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) gW1[mt][q] = (f32x16)(0.0f);
+    float b1acc[5] = {0, 0, 0, 0, 0};
+    for (long item = gw; item < n_items; item += GW) {
+        const float* sx = tape + (size_t)item * 3072 + lane * 4;
+        const float* sz = tape2 + (size_t)item * 4864 + lane * 4;
+        f32x16 TB[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            f32x16 x;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4v v = *reinterpret_cast<const f32x4v*>(sx + (q * 4 + g) * 256);
+                x[4 * g] = v[0]; x[4 * g + 1] = v[1]; x[4 * g + 2] = v[2]; x[4 * g + 3] = v[3];
+            }
+            TB[q] = rt_transpose(tb, x, wbase, rbase);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 5; mt++) {
+            f32x16 z;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int grp = mt * 4 + g;
+                if (grp < 19) {
+                    const f32x4v v = *reinterpret_cast<const f32x4v*>(sz + grp * 256);
+                    z[4 * g] = v[0]; z[4 * g + 1] = v[1]; z[4 * g + 2] = v[2]; z[4 * g + 3] = v[3];
+                } else {
+                    z[4 * g] = 0.0f; z[4 * g + 1] = 0.0f; z[4 * g + 2] = 0.0f; z[4 * g + 3] = 0.0f;
+                }
+            }
+            const f32x16 TA = rt_transpose(tb, z, wbase, rbase);
+            b1acc[mt] += rt_sum16(TA);
+#pragma unroll
+            for (int q = 0; q < 3; q++) gW1[mt][q] = rt_outer(gW1[mt][q], TA, TB[q]);
+        }
+    }
+    float* out = slab_rows + (size_t)gw * (m.n_params + 8);
+    // D[m = layer-1 row rho(r,h) of tile mt][n' = state feature 32 q + j]
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int G = mt * 16 + r;
+            if (G < 75) {
+                const int n = G / 25, f = 2 * (G % 25) + h;
+#pragma unroll
+                for (int q = 0; q < 3; q++) out[n * m.net_size + m.w_off[0] + (q * 32 + j) * 50 + f] = gW1[mt][q][r];
+            }
+        }
+        const float s1 = b1acc[mt] + swap32(b1acc[mt]);
+        const int r_j = (j & 3) + 4 * (j >> 3), h_j = (j >> 2) & 1;
+        const int G = mt * 16 + r_j;
+        if (h == 0 && G < 75) out[(G / 25) * m.net_size + m.b_off[0] + 2 * (G % 25) + h_j] = s1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 bool rt_supported(const DevModel& m) {
@@ -361,6 +800,15 @@ bool rt_supported(const DevModel& m) {
 }
 
 size_t rt_forward_lds_bytes() { return (size_t)RT_IMG_FLOATS * sizeof(float); }
+size_t rt_adjoint_lds_bytes() { return ((size_t)RT_IMG_FLOATS + RT_WAVES * (3072 + 1056)) * sizeof(float); }
+size_t rt_tape_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * 3072; }
+size_t rt_tape2_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * 4864; }
+int rt_n_wtiles(int n_col) { return (n_col + RT_COLS - 1) / RT_COLS; }
+int rt_dw1_waves(int n_col, int n_steps) {
+    const long items = (long)rt_n_wtiles(n_col) * n_steps * 4;
+    const long w = items < 1024 ? items : 1024;
+    return (int)((w + RT_WAVES - 1) / RT_WAVES) * RT_WAVES;
+}
 
 hipError_t rt_set_attributes() {
     hipError_t e;
@@ -372,6 +820,12 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_SWISH>);
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_TANH>);
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_LEAKYRELU>);
+    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_IDENTITY>);
+    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_RELU>);
+    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_MISH>);
+    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_SWISH>);
+    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_TANH>);
+    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_LEAKYRELU>);
 #undef RT_SETATTR
     return hipSuccess;
 }
@@ -398,5 +852,34 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
         default: return hipErrorInvalidValue;
     }
 #undef RT_FWD
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,
+                             int substeps, const float* sol, const float* truth, const float* tape, float* tape2,
+                             const LossWeights& lw, float* slab, int n_col, hipStream_t stream) {
+    const int n_wtiles = rt_n_wtiles(n_col);
+    const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
+    const size_t lds = rt_adjoint_lds_bytes();
+#define RT_ADJ(A) hipLaunchKernelGGL(rt_adjoint_kernel<A>, grid, block, lds, stream, m, wimg, bcs, save_times, n_save, substeps, sol, truth, tape, tape2, lw, slab, n_col)
+    switch (m.acts[0]) {
+        case COLNDE_ACT_IDENTITY: RT_ADJ(COLNDE_ACT_IDENTITY); break;
+        case COLNDE_ACT_RELU: RT_ADJ(COLNDE_ACT_RELU); break;
+        case COLNDE_ACT_MISH: RT_ADJ(COLNDE_ACT_MISH); break;
+        case COLNDE_ACT_SWISH: RT_ADJ(COLNDE_ACT_SWISH); break;
+        case COLNDE_ACT_TANH: RT_ADJ(COLNDE_ACT_TANH); break;
+        case COLNDE_ACT_LEAKYRELU: RT_ADJ(COLNDE_ACT_LEAKYRELU); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RT_ADJ
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_dw1(const DevModel& m, const float* tape, const float* tape2, int n_col, int n_steps, float* slab_rows,
+                         hipStream_t stream) {
+    const long items = (long)rt_n_wtiles(n_col) * n_steps * 4;
+    const int waves = rt_dw1_waves(n_col, n_steps);
+    hipLaunchKernelGGL(rt_dw1_kernel, dim3(waves / RT_WAVES), dim3(64 * RT_WAVES), RT_WAVES * 1056 * sizeof(float), stream, m, tape,
+                       tape2, items, slab_rows);
     return hipGetLastError();
 }

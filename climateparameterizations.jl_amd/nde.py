@@ -15,7 +15,8 @@ import numpy as np
 from . import _lib
 from .config import NDEConfig, to_c_config
 
-KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4}
+KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4, "dw1": 5}
+ENGINE_AUTO, ENGINE_TILE16, ENGINE_REGTILE = 0, 1, 2
 
 
 def _f32(a, shape=None):
@@ -47,6 +48,7 @@ class ColumnNDE:
         self.n_params = L.colnde_n_params(self._h)
         assert self.n_params == cfg.n_params
         self.n_columns_total = self.n_columns
+        self.engine = L.colnde_engine(self._h)      # engine actually selected (ENGINE_TILE16 or ENGINE_REGTILE)
 
     # ---- lifetime -------------------------------------------------------------------------------------
     def close(self):

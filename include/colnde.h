@@ -32,9 +32,10 @@ enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_t
 enum { COLNDE_ACT_IDENTITY = 0, COLNDE_ACT_RELU = 1, COLNDE_ACT_MISH = 2, COLNDE_ACT_SWISH = 3,
        COLNDE_ACT_TANH = 4, COLNDE_ACT_LEAKYRELU = 5 };
 
-enum { COLNDE_ENGINE_AUTO = 0,      /* MFMA tile engine when the configuration is one it is built for, else generic */
-       COLNDE_ENGINE_GENERIC = 1,   /* one wavefront per column, any layer sizes */
-       COLNDE_ENGINE_MFMA = 2 };    /* 32-column MFMA tiles (fails at create if the configuration is not covered) */
+enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it is built for, else tile16 */
+       COLNDE_ENGINE_GENERIC = 1,   /* tile16: 16-column MFMA tiles staged through LDS, any layer sizes / model */
+       COLNDE_ENGINE_MFMA = 2 };    /* regtile: 32 columns per wavefront resident in registers (static 96-50-20-31 wind-mixing
+                                       shape; colnde_create fails if the configuration is not covered) */
 
 /* Mirrors the `constants`, `scalings`, `conditions` NamedTuples of prepare_parameters_NDE_training
  * (wind_mixing/src/NDE_training.jl:1-44, :205-207) and the parameter tail of the free-convection NDEs
@@ -120,7 +121,8 @@ int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights, const flo
                              float Lz, float* d_out, int n_columns);
 
 /* ---- measurement: HIP-event timing of the handle's kernels on its stream.
- * which: 0 = forward solve kernel, 1 = adjoint kernel, 2 = gradient reduce, 3 = rhs, 4 = inference.
+ * which: 0 = forward solve kernel, 1 = adjoint kernel, 2 = gradient reduce, 3 = rhs, 4 = inference,
+ * 5 = streaming dW1 GEMM (regtile engine only).
  * Returns accumulated milliseconds and launch count since the last reset (synchronises the stream). */
 int colnde_set_profiling(colnde_handle* h, int enabled);
 int colnde_kernel_time(colnde_handle* h, int which, float* ms_total, int* n_launches);
