@@ -50,7 +50,7 @@ struct colnde_handle {
     bool fwd_wlds = false;
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
     float* d_wimg = nullptr;
-    float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr;
+    float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_xscr = nullptr;
     int rt_rows = 0;
     float *d_w = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_x0 = nullptr, *d_bcs = nullptr, *d_truth = nullptr,
           *d_sol = nullptr, *d_tape = nullptr, *d_slab = nullptr, *d_out = nullptr, *d_times = nullptr,
@@ -296,7 +296,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     drain_events(h);
-    void* ptrs[] = {h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
+    void* ptrs[] = {h->d_rt_xscr, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
                     h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -458,6 +458,7 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
             const size_t n1 = rt_tape_floats(h->n_col, n_steps), n2 = rt_tape2_floats(h->n_col, n_steps);
             e = hipMalloc((void**)&h->d_rt_tape, n1 * sizeof(float));
             if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_tape2, n2 * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_xscr, (size_t)rt_n_wtiles(h->n_col) * 5 * 3072 * sizeof(float));
             if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tapes failed: %s", (n1 + n2) * sizeof(float), hipGetErrorString(e));
         }
         Timed tm(h, K_FORWARD);
@@ -553,7 +554,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         {
             Timed tm(h, K_ADJOINT);
             hipError_t e = rt_launch_adjoint(h->m, h->d_wimg, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol,
-                                             h->d_truth, h->d_rt_tape, h->d_rt_tape2, lw, h->d_rt_slab, h->n_col, h->stream);
+                                             h->d_truth, h->d_rt_tape, h->d_rt_tape2, h->d_rt_xscr, lw, h->d_rt_slab, h->n_col, h->stream);
             if (e != hipSuccess) return fail("rt adjoint launch failed: %s", hipGetErrorString(e));
         }
         {
@@ -645,6 +646,11 @@ extern "C" int colnde_debug_stamps(colnde_handle* h, unsigned long long* out16) 
     if (!h || !out16) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->use_rt) {
+        for (int i = 0; i < 16; i++) out16[i] = 0;
+        HIPCHK(rt_debug_read_stamps(out16));
+        return 0;
+    }
     HIPCHK(debug_read_stamps(out16));
     return 0;
 }

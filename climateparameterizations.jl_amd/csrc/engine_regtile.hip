@@ -19,9 +19,24 @@
 #include "engine_regtile.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// diagnostic build only (-DCOLNDE_STAMPS): per-phase cycle sums of wave 0 of workgroup 0
+#ifdef COLNDE_STAMPS
+__device__ unsigned long long g_rt_stamps[16];
+#define RT_STAMP_DECL unsigned long long rs_t0 = 0, rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RT_STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); rs_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); rs_acc[i] += t_ - rs_t0; rs_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RT_STAMP_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int q_ = 0; q_ < 8; q_++) g_rt_stamps[q_] = rs_acc[q_]; } while (0)
+#else
+#define RT_STAMP_DECL
+#define RT_STAMP_BEGIN()
+#define RT_STAMP(i)
+#define RT_STAMP_FLUSH()
+#endif
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define RHO0(r) (((r) & 3) + 8 * ((r) >> 2))
+#define RT_TAPE2 (21 * 256)   // floats per (tile, step, stage) of the layer-1 delta tape: 3 nets x 7 groups x 64 lanes x 4
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -370,17 +385,25 @@ __device__ __forceinline__ float rt_act_grad(float z) {
     return 1.0f;
 }
 
-// Pullback of rt_physics_forward for the stage cotangent kb: dO = cotangent of the NN face fluxes (0 on face 0),
-// xb = physics part of the state cotangent (flux-divergence transpose + Coriolis).
-__device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (&X)[3], const f32x16 (&kb)[3], int h,
-                                               f32x16 (&dO)[3], f32x16 (&xb)[3]) {
+// Pullback of rt_physics_forward.  On entry kd holds the stage cotangent k̄; on exit it holds dO = the cotangent of the NN
+// face fluxes (0 on face 0) and xb the physics part of the state cotangent (flux-divergence transpose + Coriolis).
+// Ordered so that k̄ is consumed in place (Coriolis first, then F̄ overwrites k̄): this phase is the kernel's
+// register-pressure peak.
+__device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (&X)[3], f32x16 (&kd)[3], int h, f32x16 (&xb)[3]) {
     const float Nz = 32.0f;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const f32x16 kd = shift_down(kb[k], h, 0.0f);
-#pragma unroll
-        for (int r = 0; r < 16; r++) dO[k][r] = (r == 0 && h == 0) ? 0.0f : m.A[k] * (kb[k][r] - kd[r]);
+    for (int r = 0; r < 16; r++) {
+        xb[0][r] = -m.cor_v * m.sig_u * kd[1][r];
+        xb[1][r] = m.cor_u * m.sig_v * kd[0][r];
+        xb[2][r] = 0.0f;
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const f32x16 dn = shift_down(kd[k], h, 0.0f);
+#pragma unroll
+        for (int r = 0; r < 16; r++) kd[k][r] = (r == 0 && h == 0) ? 0.0f : m.A[k] * (kd[k][r] - dn[r]);
+    }
+    if (!m.mpp && !m.ca) return;
     f32x16 gb[3];
     if (m.mpp) {
         const f32x16 Ud = shift_down(X[0], h, 0.0f), Vd = shift_down(X[1], h, 0.0f), Td = shift_down(X[2], h, 0.0f);
@@ -394,7 +417,7 @@ __device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (
             const float e = __expf(2.0f * fminf(fmaxf((Ri - m.Ric) * m.inv_dRi, -15.0f), 15.0f));
             const float th = 1.0f - __fdividef(2.0f, 1.0f + e);
             const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
-            const float D0 = -dO[0][r], D1 = -dO[1][r], D2 = -dO[2][r];
+            const float D0 = -kd[0][r], D1 = -kd[1][r], D2 = -kd[2][r];
             float g0 = D0 * m.cs[0] * nu, g1 = D1 * m.cs[1] * nu, g2 = D2 * m.cs[2] * nu / m.Pr;
             const float nub = D0 * m.cs[0] * gu + D1 * m.cs[1] * gv + D2 * m.cs[2] * gT / m.Pr;
             const float ribs = nub * (-m.nu_minus / (2.0f * m.dRi)) * (1.0f - th * th);
@@ -414,19 +437,14 @@ __device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (
             const float gT = (X[2][r] - Td[r]) * Nz;
             gb[0][r] = 0.0f;
             gb[1][r] = 0.0f;
-            gb[2][r] = (m.ca && in && gT < 0.0f) ? -dO[2][r] * m.cs[2] * m.kappa : 0.0f;
+            gb[2][r] = (in && gT < 0.0f) ? -kd[2][r] * m.cs[2] * m.kappa : 0.0f;
         }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const f32x16 gu_ = shift_up(gb[k], h, 0.0f);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float v = (gb[k][r] - gu_[r]) * Nz;
-            if (k == 0) v += -m.cor_v * m.sig_u * kb[1][r];
-            if (k == 1) v += m.cor_u * m.sig_v * kb[0][r];
-            xb[k][r] = v;
-        }
+        for (int r = 0; r < 16; r++) xb[k][r] += (gb[k][r] - gu_[r]) * Nz;
     }
 }
 
@@ -461,12 +479,14 @@ __device__ __forceinline__ float rt_sum16(const f32x16 v) {
 __host__ __device__ constexpr int rt_combo(int n, int mt) { return n == 0 ? mt : (n == 1 ? 1 + mt : 2 + mt); }
 
 // tape of stage inputs (written by rt_forward_kernel):  [tile][step][stage][12 groups][64 lanes][4]
-// tape2 of layer-1 deltas (written here, read by rt_dw1_kernel): [tile][step][stage][19 groups][64 lanes][4], register G = 4 grp + e
+// tape2 of layer-1 deltas (written here, read by rt_dw1_kernel): [tile][step][stage][net][7 groups][64 lanes][4]; element e of
+// group grp of net n is register g = 4 grp + e (features 2g, 2g+1 of net n; g >= 25: zero padding)
 template <int ACT>
 __global__ void __launch_bounds__(256)
 rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ bcs,
                   const float* __restrict__ save_times, int n_save, int substeps, const float* __restrict__ sol,
                   const float* __restrict__ truth, const float* __restrict__ tape, float* __restrict__ tape2,
+                  float* xscr /* [tile][5][3072]: the four stage cotangents of the step in flight + the flux cotangents */,
                   LossWeights lw, float* __restrict__ slab, int n_col) {
     float* wl = rt_smem;
     for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
@@ -480,38 +500,36 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     const int col = tile * RT_COLS + j;
     const bool valid = col < n_col;
     const int i_ = lane & 31, r_i = (i_ & 3) + 4 * (i_ >> 3), h_i = (i_ >> 2) & 1;
-    const RtBases bases = rt_bases(lane);
+    // per-net layer-1 tiles (n, t): register G' = 16 t + r carries features (2G', 2G'+1) of net n (G' >= 25: padding)
+    int a1n[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) a1n[t] = RT_W1C + (2 * min(t * 16 + r_i, 24) + h_i) * RT_LD1 + 4 * h;
+    const int a2b = RT_W2C + ((r_i < 10) ? 2 * r_i + h_i : 0) * RT_LD2 + h;
     // transposed-product bases
     const int f2c = (r_i < 10) ? 2 * r_i + h_i : 20;                                   // a2 feature of output row i_ (20 = zero column)
     const int b3T = RT_W3C + (4 * h - 1) * RT_LD3 + f2c;
-    int b2T[7];
+    int b2T[2];
 #pragma unroll
-    for (int mt = 0; mt < 5; mt++)
-#pragma unroll
-        for (int n = RT_NET_LO(mt); n <= RT_NET_HI(mt); n++) {
-            const int G = mt * 16 + r_i;
-            const int f1c = (G >= 25 * n && G < 25 * n + 25) ? 2 * (G - 25 * n) + h_i : 50;   // 50 = zero column
-            b2T[rt_combo(n, mt)] = RT_W2C + h * RT_LD2 + f1c;
-        }
+    for (int t = 0; t < 2; t++) b2T[t] = RT_W2C + h * RT_LD2 + ((t * 16 + r_i < 25) ? 2 * (t * 16 + r_i) + h_i : 50);   // 50 = zero column
     const int b1T = RT_W1C + h * RT_LD1 + i_;
     const int wbase = 4 * h * 33 + j, rbase = i_ * 33 + h;
 
-    f32x16 gW3[3], gW2[7];
+    f32x16 gW3[3], gW2[3][2];
 #pragma unroll
-    for (int q = 0; q < 3; q++) gW3[q] = (f32x16)(0.0f);
-#pragma unroll
-    for (int q = 0; q < 7; q++) gW2[q] = (f32x16)(0.0f);
+    for (int q = 0; q < 3; q++) { gW3[q] = (f32x16)(0.0f); gW2[q][0] = (f32x16)(0.0f); gW2[q][1] = (f32x16)(0.0f); }
     float b2acc[3] = {0, 0, 0}, b3acc[3] = {0, 0, 0};
     float sums[6] = {0, 0, 0, 0, 0, 0};
-    f32x16 xb[3], xbs[3], X[3];
+    RT_STAMP_DECL;
+    f32x16 xb[3], X[3];
 #pragma unroll
-    for (int q = 0; q < 3; q++) { xb[q] = (f32x16)(0.0f); xbs[q] = (f32x16)(0.0f); }
+    for (int q = 0; q < 3; q++) xb[q] = (f32x16)(0.0f);
 #pragma unroll
     for (int e = 0; e < 48; e++) lam[e * 64 + lane] = 0.0f;
 
     const int n_steps = (n_save - 1) * substeps;
     const float* tp = tape + (size_t)tile * n_steps * 4 * 3072 + lane * 4;
-    float* tp2 = tape2 + (size_t)tile * n_steps * 4 * 4864 + lane * 4;
+    float* xs4 = xscr + (size_t)tile * 5 * 3072 + lane * 4;
+    float* tp2 = tape2 + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4;
 
     // loss injection at save point n: λ += ∂loss/∂sol[:, n]; also the six raw sums of squares
     auto inject = [&](int n, bool add) {
@@ -565,118 +583,148 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
             for (int st = 3; st >= 0; st--) {
                 const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
                 const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
-                // (1) stage cotangent and the physics pullback
-                f32x16 dO[3];
+                RT_STAMP_BEGIN();
+                // (1) stage cotangent and the physics pullback: dO = cotangent of the NN fluxes, xb = physics part of x̄
+                // (dO is parked in an L2-resident scratch slot and re-read one net at a time: 32 fewer live registers)
                 {
                     f32x16 kb[3];
 #pragma unroll
                     for (int q = 0; q < 3; q++)
 #pragma unroll
                         for (int r = 0; r < 16; r++) kb[q][r] = cwl * lam[(q * 16 + r) * 64 + lane] + cwx * xb[q][r];
-                    rt_physics_vjp(m, X, kb, h, dO, xb);
-                }
-                // (2) forward recompute of the hidden pre-activations (layer 3 is not needed: it enters linearly)
-                f32x16 Z1[5], Z2[3];
+                    rt_physics_vjp(m, X, kb, h, xb);       // kb now holds dO
 #pragma unroll
-                for (int mt = 0; mt < 5; mt++) {
-                    f32x16 acc;
+                    for (int q = 0; q < 3; q++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int G = mt * 16 + r;
-                        acc[r] = wl[RT_B1C + (G < 75 ? (G / 25) * 50 + 2 * (G % 25) : 150 + 2 * (G - 75)) + h];
-                    }
-                    const int base = bases.a1[mt];
-                    Z1[mt] = rt_chain<48, 8>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
-                                             [&](int k) { return X[k >> 4][k & 15]; });
-                }
-#pragma unroll
-                for (int n = 0; n < 3; n++) {
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[r] = r < 10 ? wl[RT_B2C + n * 20 + 2 * r + h] : 0.0f;
-                    const int base2 = bases.a2 + n * 20 * RT_LD2;
-                    Z2[n] = rt_chain<25, 5>(wl, acc, [=](int k) { return base2 + 2 * k; },
-                                            [&](int k) { return rt_act<ACT>(Z1[(25 * n + k) >> 4][(25 * n + k) & 15]); });
-                }
-                // (3) layer 3: weight/bias gradient, then dZ2 = (W3^T dO) .* act'(Z2)
-#pragma unroll
-                for (int n = 0; n < 3; n++) {
-                    const f32x16 TA = rt_transpose(tb, dO[n], wbase, rbase);
-                    b3acc[n] += rt_sum16(TA);
-                    const f32x16 TB = rt_transpose(tb, act_tile<ACT>(Z2[n]), wbase, rbase);
-                    gW3[n] = rt_outer(gW3[n], TA, TB);
-                    const int base = b3T + n * 31 * RT_LD3;
-                    f32x16 da = rt_chain<16, 8>(wl, (f32x16)(0.0f), [=](int k) { return base + RHO0(k) * RT_LD3; },
-                                                [&](int k) { return dO[n][k]; });
-#pragma unroll
-                    for (int r = 0; r < 16; r++) Z2[n][r] = r < 10 ? da[r] * rt_act_grad<ACT>(Z2[n][r]) : 0.0f;
-                }
-                // (4) layer 2: weight/bias gradient
-#pragma unroll
-                for (int n = 0; n < 3; n++) {
-                    const f32x16 TA = rt_transpose(tb, Z2[n], wbase, rbase);
-                    b2acc[n] += rt_sum16(TA);
-#pragma unroll
-                    for (int mt = 0; mt < 5; mt++)
-                        if (n >= RT_NET_LO(mt) && n <= RT_NET_HI(mt)) {
-                            const f32x16 TB = rt_transpose(tb, act_tile<ACT>(Z1[mt]), wbase, rbase);
-                            gW2[rt_combo(n, mt)] = rt_outer(gW2[rt_combo(n, mt)], TA, TB);
+                        for (int g = 0; g < 4; g++) {
+                            const f32x4v v = {kb[q][4 * g], kb[q][4 * g + 1], kb[q][4 * g + 2], kb[q][4 * g + 3]};
+                            *reinterpret_cast<f32x4v*>(xs4 + 4 * 3072 + (q * 4 + g) * 256) = v;
                         }
                 }
-                // (5) dZ1 = (W2^T dZ2) .* act'(Z1), in place; taped for the streaming dW1 kernel
+                RT_STAMP(0);
+                float* dst = tp2 + ((size_t)step * 4 + st) * RT_TAPE2;
+                // the nets are handled one after the other so that only one net's hidden state is live at a time
 #pragma unroll
-                for (int mt = 0; mt < 5; mt++) {
-                    f32x16 da = (f32x16)(0.0f);
+                for (int n = 0; n < 3; n++) {
+                    f32x16 dOn;
 #pragma unroll
-                    for (int n = RT_NET_LO(mt); n <= RT_NET_HI(mt); n++) {
-                        const int base = b2T[rt_combo(n, mt)] + n * 20 * RT_LD2;
-                        da = rt_chain<10, 10>(wl, da, [=](int k) { return base + 2 * k * RT_LD2; },
-                                              [&](int k) { return Z2[n][k]; });
+                    for (int g = 0; g < 4; g++) {
+                        const f32x4v v = *reinterpret_cast<const f32x4v*>(xs4 + 4 * 3072 + (n * 4 + g) * 256);
+                        dOn[4 * g] = v[0]; dOn[4 * g + 1] = v[1]; dOn[4 * g + 2] = v[2]; dOn[4 * g + 3] = v[3];
+                    }
+                    // (2) forward recompute of the hidden pre-activations (layer 3 enters linearly: not needed)
+                    f32x16 Z1[2];
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[r] = (t * 16 + r < 25) ? wl[RT_B1C + n * 50 + 2 * (t * 16 + r) + h] : 0.0f;
+                        const int base = a1n[t] + n * 50 * RT_LD1;
+                        Z1[t] = rt_chain<48, 8>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
+                                                [&](int k) { return X[k >> 4][k & 15]; });
+                    }
+                    RT_STAMP(1);
+                    if (n == 2) {
+                        // X is dead: fetch the next stage's input while the rest of this stage runs
+                        const int qn = step * 4 + st - 1;
+                        if (qn >= 0) {
+                            const float* src = tp + (size_t)qn * 3072;
+#pragma unroll
+                            for (int q = 0; q < 3; q++)
+#pragma unroll
+                                for (int g = 0; g < 4; g++) {
+                                    const f32x4v v = *reinterpret_cast<const f32x4v*>(src + (q * 4 + g) * 256);
+                                    X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
+                                }
+                        }
+                    }
+                    f32x16 Z2;
+                    {
+                        f32x16 acc;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[r] = r < 10 ? wl[RT_B2C + n * 20 + 2 * r + h] : 0.0f;
+                        const int base2 = a2b + n * 20 * RT_LD2;
+                        Z2 = rt_chain<25, 5>(wl, acc, [=](int k) { return base2 + 2 * k; },
+                                             [&](int k) { return rt_act<ACT>(Z1[k >> 4][k & 15]); });
+                    }
+                    RT_STAMP(2);
+                    // (3) layer 3: weight/bias gradient, then dZ2 = (W3^T dO) .* act'(Z2)
+                    {
+                        const f32x16 TA = rt_transpose(tb, dOn, wbase, rbase);
+                        b3acc[n] += rt_sum16(TA);
+                        const f32x16 TB = rt_transpose(tb, act_tile<ACT>(Z2), wbase, rbase);
+                        gW3[n] = rt_outer(gW3[n], TA, TB);
+                    }
+                    {
+                        const int base = b3T + n * 31 * RT_LD3;
+                        const f32x16 da = rt_chain<16, 8>(wl, (f32x16)(0.0f), [=](int k) { return base + RHO0(k) * RT_LD3; },
+                                                          [&](int k) { return dOn[k]; });
+#pragma unroll
+                        for (int r = 0; r < 16; r++) Z2[r] = r < 10 ? da[r] * rt_act_grad<ACT>(Z2[r]) : 0.0f;
+                    }
+                    RT_STAMP(3);
+                    // (4) layer 2: weight/bias gradient
+                    {
+                        const f32x16 TA = rt_transpose(tb, Z2, wbase, rbase);
+                        b2acc[n] += rt_sum16(TA);
+#pragma unroll
+                        for (int t = 0; t < 2; t++) {
+                            const f32x16 TB = rt_transpose(tb, act_tile<ACT>(Z1[t]), wbase, rbase);
+                            gW2[n][t] = rt_outer(gW2[n][t], TA, TB);
+                        }
+                    }
+                    RT_STAMP(4);
+                    // (5) dZ1 = (W2^T dZ2) .* act'(Z1), in place; taped for the streaming dW1 kernel
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const int base = b2T[t] + n * 20 * RT_LD2;
+                        const f32x16 da = rt_chain<10, 10>(wl, (f32x16)(0.0f), [=](int k) { return base + 2 * k * RT_LD2; },
+                                                           [&](int k) { return Z2[k]; });
+#pragma unroll
+                        for (int r = 0; r < 16; r++) Z1[t][r] = (t * 16 + r < 25) ? da[r] * rt_act_grad<ACT>(Z1[t][r]) : 0.0f;
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; r++) Z1[mt][r] = (mt * 16 + r < 75) ? da[r] * rt_act_grad<ACT>(Z1[mt][r]) : 0.0f;
-                }
-                {
-                    float* dst = tp2 + ((size_t)step * 4 + st) * 4864;
-#pragma unroll
-                    for (int grp = 0; grp < 19; grp++) {
+                    for (int grp = 0; grp < 7; grp++) {
                         const f32x4v v = {Z1[grp >> 2][(grp & 3) * 4], Z1[grp >> 2][(grp & 3) * 4 + 1],
                                           Z1[grp >> 2][(grp & 3) * 4 + 2], Z1[grp >> 2][(grp & 3) * 4 + 3]};
-                        *reinterpret_cast<f32x4v*>(dst + grp * 256) = v;
+                        *reinterpret_cast<f32x4v*>(dst + (n * 7 + grp) * 256) = v;
+                    }
+                    RT_STAMP(5);
+                    // (6) x̄ += W1_n^T dZ1_n
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const int base = b1T + q * 32 + n * 50 * RT_LD1;
+                        xb[q] = rt_chain<25, 5>(wl, xb[q], [=](int g) { return base + 2 * g * RT_LD1; },
+                                                [&](int g) { return Z1[g >> 4][g & 15]; });
                     }
                 }
-                // (6) next stage's input is fetched while the W1^T products run
+                RT_STAMP(6);
+                // park this stage's x̄ in an L2-resident scratch slot (keeps 48 registers free); the four slots of the step
+                // are summed into λ below
                 {
-                    const int qn = step * 4 + st - 1;
-                    if (qn >= 0) {
-                        const float* src = tp + (size_t)qn * 3072;
+                    float* slot = xs4 + (size_t)st * 3072;
 #pragma unroll
-                        for (int q = 0; q < 3; q++)
+                    for (int q = 0; q < 3; q++)
 #pragma unroll
-                            for (int g = 0; g < 4; g++) {
-                                const f32x4v v = *reinterpret_cast<const f32x4v*>(src + (q * 4 + g) * 256);
-                                X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
-                            }
-                    }
-                }
-                // (7) x̄ += W1^T dZ1
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const int base = b1T + q * 32;
-                    xb[q] = rt_chain<75, 8>(wl, xb[q], [=](int G) { return base + ((G / 25) * 50 + 2 * (G % 25)) * RT_LD1; },
-                                            [&](int G) { return Z1[G >> 4][G & 15]; });
-                    xbs[q] += xb[q];
+                        for (int g = 0; g < 4; g++) {
+                            const f32x4v v = {xb[q][4 * g], xb[q][4 * g + 1], xb[q][4 * g + 2], xb[q][4 * g + 3]};
+                            *reinterpret_cast<f32x4v*>(slot + (q * 4 + g) * 256) = v;
+                        }
                 }
             }
+            // λ_n = λ_{n+1} + x̄_1 + x̄_2 + x̄_3 + x̄_4
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
+            for (int grp = 0; grp < 12; grp++) {
+                f32x4v acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int r = 0; r < 16; r++) lam[(q * 16 + r) * 64 + lane] += xbs[q][r];
-                xbs[q] = (f32x16)(0.0f);
+                for (int st = 0; st < 4; st++) acc4 += *reinterpret_cast<const f32x4v*>(xs4 + (size_t)st * 3072 + grp * 256);
+#pragma unroll
+                for (int e = 0; e < 4; e++) lam[(grp * 4 + e) * 64 + lane] += acc4[e];
             }
         }
     }
 
+    RT_STAMP_FLUSH();
     // ---- flush this wave's partial gradients (row `tile` of the slab; dW1/db1 come from rt_dw1_kernel) ----
     float* out = slab + (size_t)tile * (m.n_params + 8);
     const int r_j = (j & 3) + 4 * (j >> 3), h_j = (j >> 2) & 1;     // this lane as a column index n' of a D tile
@@ -692,16 +740,15 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
             }
         }
 #pragma unroll
-        for (int mt = 0; mt < 5; mt++)
-            if (n >= RT_NET_LO(mt) && n <= RT_NET_HI(mt)) {
-                // dW2_n[out = f2 = 2r+h][in = f1]: D[m = z2 row rho(r,h)][n' = a1 tile row j]
-                const int G = mt * 16 + r_j;
-                if (G >= 25 * n && G < 25 * n + 25) {
-                    const int f1 = 2 * (G - 25 * n) + h_j;
+        for (int t = 0; t < 2; t++) {
+            // dW2_n[out = f2 = 2r+h][in = f1]: D[m = z2 row rho(r,h)][n' = row j of net n's layer-1 tile t]
+            const int Gp = t * 16 + r_j;
+            if (Gp < 25) {
+                const int f1 = 2 * Gp + h_j;
 #pragma unroll
-                    for (int r = 0; r < 10; r++) out[n * m.net_size + m.w_off[1] + f1 * 20 + 2 * r + h] = gW2[rt_combo(n, mt)][r];
-                }
+                for (int r = 0; r < 10; r++) out[n * m.net_size + m.w_off[1] + f1 * 20 + 2 * r + h] = gW2[n][t][r];
             }
+        }
         // biases: lanes (i, 0) and (i, 1) hold the even / odd column halves of row i_
         const float s2 = b2acc[n] + swap32(b2acc[n]), s3 = b3acc[n] + swap32(b3acc[n]);
         if (h == 0) {
@@ -739,7 +786,7 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
     float b1acc[5] = {0, 0, 0, 0, 0};
     for (long item = gw; item < n_items; item += GW) {
         const float* sx = tape + (size_t)item * 3072 + lane * 4;
-        const float* sz = tape2 + (size_t)item * 4864 + lane * 4;
+        const float* sz = tape2 + (size_t)item * RT_TAPE2 + lane * 4;
         f32x16 TB[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -751,18 +798,20 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
             }
             TB[q] = rt_transpose(tb, x, wbase, rbase);
         }
+        // the 75 taped registers (net n, g) re-assembled into the stacked tiles: G = 25 n + g = 16 mt + r
+        float zr[84];
+#pragma unroll
+        for (int grp = 0; grp < 21; grp++) {
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(sz + grp * 256);
+            zr[4 * grp] = v[0]; zr[4 * grp + 1] = v[1]; zr[4 * grp + 2] = v[2]; zr[4 * grp + 3] = v[3];
+        }
 #pragma unroll
         for (int mt = 0; mt < 5; mt++) {
             f32x16 z;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int grp = mt * 4 + g;
-                if (grp < 19) {
-                    const f32x4v v = *reinterpret_cast<const f32x4v*>(sz + grp * 256);
-                    z[4 * g] = v[0]; z[4 * g + 1] = v[1]; z[4 * g + 2] = v[2]; z[4 * g + 3] = v[3];
-                } else {
-                    z[4 * g] = 0.0f; z[4 * g + 1] = 0.0f; z[4 * g + 2] = 0.0f; z[4 * g + 3] = 0.0f;
-                }
+            for (int r = 0; r < 16; r++) {
+                const int G = mt * 16 + r;
+                z[r] = G < 75 ? zr[(G / 25) * 28 + (G % 25)] : 0.0f;
             }
             const f32x16 TA = rt_transpose(tb, z, wbase, rbase);
             b1acc[mt] += rt_sum16(TA);
@@ -802,7 +851,7 @@ bool rt_supported(const DevModel& m) {
 size_t rt_forward_lds_bytes() { return (size_t)RT_IMG_FLOATS * sizeof(float); }
 size_t rt_adjoint_lds_bytes() { return ((size_t)RT_IMG_FLOATS + RT_WAVES * (3072 + 1056)) * sizeof(float); }
 size_t rt_tape_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * 3072; }
-size_t rt_tape2_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * 4864; }
+size_t rt_tape2_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * RT_TAPE2; }
 int rt_n_wtiles(int n_col) { return (n_col + RT_COLS - 1) / RT_COLS; }
 int rt_dw1_waves(int n_col, int n_steps) {
     const long items = (long)rt_n_wtiles(n_col) * n_steps * 4;
@@ -857,11 +906,11 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
 
 hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,
                              int substeps, const float* sol, const float* truth, const float* tape, float* tape2,
-                             const LossWeights& lw, float* slab, int n_col, hipStream_t stream) {
+                             float* xscr, const LossWeights& lw, float* slab, int n_col, hipStream_t stream) {
     const int n_wtiles = rt_n_wtiles(n_col);
     const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
     const size_t lds = rt_adjoint_lds_bytes();
-#define RT_ADJ(A) hipLaunchKernelGGL(rt_adjoint_kernel<A>, grid, block, lds, stream, m, wimg, bcs, save_times, n_save, substeps, sol, truth, tape, tape2, lw, slab, n_col)
+#define RT_ADJ(A) hipLaunchKernelGGL(rt_adjoint_kernel<A>, grid, block, lds, stream, m, wimg, bcs, save_times, n_save, substeps, sol, truth, tape, tape2, xscr, lw, slab, n_col)
     switch (m.acts[0]) {
         case COLNDE_ACT_IDENTITY: RT_ADJ(COLNDE_ACT_IDENTITY); break;
         case COLNDE_ACT_RELU: RT_ADJ(COLNDE_ACT_RELU); break;
@@ -882,4 +931,13 @@ hipError_t rt_launch_dw1(const DevModel& m, const float* tape, const float* tape
     hipLaunchKernelGGL(rt_dw1_kernel, dim3(waves / RT_WAVES), dim3(64 * RT_WAVES), RT_WAVES * 1056 * sizeof(float), stream, m, tape,
                        tape2, items, slab_rows);
     return hipGetLastError();
+}
+
+hipError_t rt_debug_read_stamps(unsigned long long* out8) {
+#ifdef COLNDE_STAMPS
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_rt_stamps), sizeof(unsigned long long) * 8);
+#else
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    return hipSuccess;
+#endif
 }

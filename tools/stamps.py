@@ -19,12 +19,18 @@ nde.set_problem(p.x0, p.bcs, truth)
 nde.loss_grad(p.weights, [1, 1, 1, 5e-3, 5e-3, 5e-3])
 buf = (ctypes.c_ulonglong * 16)()
 _lib.check(L.colnde_debug_stamps(nde._h, buf))
-names = ["tape load + kbar", "mlp_forward", "physics_vjp", "mlp_backward", "dW tiles", "bias + xbar sum + barrier"]
-v = np.array(list(buf)[:6], dtype=np.float64)
+if nde.engine == 2:
+    names = ["kbar + physics pullback + dO park", "dO reload + L1 chains (3 nets)", "X prefetch + L2 chain", "dW3 + W3^T + dZ2",
+             "dW2 (transposes + outer)", "W2^T + dZ1 + tape2 store", "W1^T chains"]
+else:
+    names = ["tape load + kbar", "mlp_forward", "physics_vjp", "mlp_backward", "dW tiles", "bias + xbar sum + barrier"]
+v = np.array(list(buf)[:len(names)], dtype=np.float64)
 nstage = p.cfg.n_steps * 4
 for n, x in zip(names, v):
     print("%-28s %10.0f cycles/stage  %5.1f %%" % (n, x / nstage, 100 * x / v.sum()))
 print("total %.0f cycles/stage" % (v.sum() / nstage))
+if nde.engine == 2:
+    raise SystemExit(0)
 fine = np.array(list(buf)[8:13], dtype=np.float64)
 for n, x in zip(["layer setup", "job prologue (bias)", "MFMA chain", "epilogue (act + store)", "barrier"], fine):
     print("  mlp_forward/%-24s %9.0f cycles/stage (all kernels' forward passes of wave 0)" % (n, x / nstage))
