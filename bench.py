@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--columns", type=int, default=16384, help="columns per GPU (weak scaling)")
+    ap.add_argument("--columns", type=int, default=32768, help="columns per GPU (weak scaling); 32768 = one 32-column wavefront per SIMD")
     ap.add_argument("--frames", type=int, default=289, help="saved frames (2-day suite: 289)")
     ap.add_argument("--substeps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,7 +179,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "wind_mixing train_NDE 2DaySuite shape (BASELINE configs[2]): synthetic suite replicated to "
+                "workload": "wind_mixing train_NDE 2DaySuite shape (BASELINE configs[2]: 8 sims x 32 levels x 289 frames, fwd+adjoint): synthetic suite replicated to "
                             "%d columns/GPU x %d levels x %d frames, %d RK4 sub-steps/frame, MPP + zero_weights + train_gradient, "
                             "3 x (96-50-20-31 mish), six-term loss" % (ncol, cfg.Nz, args.frames, cfg.substeps),
                 "columns_per_gpu": ncol, "levels": cfg.Nz, "frames": args.frames, "substeps": cfg.substeps,

@@ -158,7 +158,7 @@ static void build_model(const colnde_config* c, DevModel* m, PackInfo* pk) {
     m->C_fc = (sg[5] / sg[2]) * (c->tau / c->H);
     m->sig_u = sg[0]; m->sig_v = sg[1]; m->mu_u = mu[0]; m->mu_v = mu[1];
     m->mu_wT = mu[5]; m->sig_wT = sg[5]; m->mu_T = mu[2]; m->sig_T = sg[2];
-    m->nu0 = c->nu0; m->nu_minus = c->nu_minus; m->Ric = c->Ric; m->dRi = c->dRi; m->inv_dRi = 1.0f / c->dRi; m->Pr = c->Pr;
+    m->nu0 = c->nu0; m->nu_minus = c->nu_minus; m->Ric = c->Ric; m->dRi = c->dRi; m->inv_dRi = 1.0f / c->dRi; m->inv_Pr = 1.0f / c->Pr; m->c_rib = -c->nu_minus / (2.0f * c->dRi); m->Pr = c->Pr;
     m->kappa = c->kappa; m->eps = c->eps; m->ca_K = c->ca_K; m->tau = c->tau; m->alpha_g = c->alpha * c->g;
 }
 

@@ -33,7 +33,7 @@ struct DevModel {
     int n_tiles, tiles_per_wave;
     float cs[3], A[3], s0[3], B, cor_u, cor_v, C_fc;
     float sig_u, sig_v, mu_u, mu_v, mu_wT, sig_wT, mu_T, sig_T;
-    float nu0, nu_minus, Ric, dRi, inv_dRi, Pr, kappa, eps, ca_K, tau, alpha_g;
+    float nu0, nu_minus, Ric, dRi, inv_dRi, Pr, inv_Pr, c_rib, kappa, eps, ca_K, tau, alpha_g;
 };
 
 // ---- activations (NNlib 0.7: relu, mish, swish, tanh, leakyrelu) ------------------------------------

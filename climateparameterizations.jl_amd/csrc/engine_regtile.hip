@@ -36,13 +36,21 @@ __device__ unsigned long long g_rt_stamps[16];
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define RHO0(r) (((r) & 3) + 8 * ((r) >> 2))
+#ifndef RT_PARK_DO
+#define RT_PARK_DO 1
+#endif
 #define RT_TAPE2 (21 * 256)   // floats per (tile, step, stage) of the layer-1 delta tape: 3 nets x 7 groups x 64 lanes x 4
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float swap32(float x) { return __shfl_xor(x, 32); }
+// value held by the partner lane (lane ^ 32): v_permlane32_swap (one VALU op, no LDS round trip; semantics probed on
+// gfx950 by tools/probe/permlane.hip: result 0 = low half in both halves, result 1 = high half in both halves)
+__device__ __forceinline__ float swap32(float x, int h) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(h ? r[0] : r[1]);
+}
 
 // tile value one level below (rho - 1); level -1 reads `below`
 __device__ __forceinline__ f32x16 shift_down(const f32x16 T, int h, float below) {
@@ -50,7 +58,7 @@ __device__ __forceinline__ f32x16 shift_down(const f32x16 T, int h, float below)
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const float send = h ? (g > 0 ? T[(4 * g + 15) & 15] : 0.0f) : T[4 * g + 3];   // h=1 sends T[4g-1], h=0 sends T[4g+3]
-        const float recv = swap32(send);
+        const float recv = swap32(send, h);
         o[4 * g] = (h == 0 && g == 0) ? below : recv;
         o[4 * g + 1] = T[4 * g];
         o[4 * g + 2] = T[4 * g + 1];
@@ -65,7 +73,7 @@ __device__ __forceinline__ f32x16 shift_up(const f32x16 T, int h, float above) {
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const float send = h ? T[4 * g] : (g < 3 ? T[(4 * g + 4) & 15] : 0.0f);         // h=1 sends T[4g], h=0 sends T[4g+4]
-        const float recv = swap32(send);
+        const float recv = swap32(send, h);
         o[4 * g + 3] = (h == 1 && g == 3) ? above : recv;
         o[4 * g] = T[4 * g + 1];
         o[4 * g + 1] = T[4 * g + 2];
@@ -205,7 +213,7 @@ __device__ __forceinline__ void rt_physics_forward(const DevModel& m, const f32x
                     const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
                     f0 -= m.cs[0] * nu * gu;
                     f1 -= m.cs[1] * nu * gv;
-                    f2 -= m.cs[2] * (nu / m.Pr) * gT;
+                    f2 -= m.cs[2] * (nu * m.inv_Pr) * gT;
                 } else if (m.zero_w) {
                     f0 += bc.b[0] - m.s0[0];
                     f1 += bc.b[1] - m.s0[1];
@@ -385,6 +393,26 @@ __device__ __forceinline__ float rt_act_grad(float z) {
     return 1.0f;
 }
 
+// activation and its derivative in one evaluation (shared exponential)
+template <int ACT>
+__device__ __forceinline__ void rt_act_pair(float z, float& a, float& d) {
+    if (ACT == COLNDE_ACT_MISH) {
+        const float e = __expf(fminf(z, 20.0f));
+        const float n = e * (e + 2.0f);
+        const float t = __fdividef(n, n + 2.0f);
+        const float sg = __fdividef(e, 1.0f + e);
+        a = z * t;
+        d = t + z * (1.0f - t * t) * sg;
+    } else if (ACT == COLNDE_ACT_SWISH) {
+        const float sg = __fdividef(1.0f, 1.0f + __expf(-z));
+        a = z * sg;
+        d = sg + a * (1.0f - sg);
+    } else {
+        a = rt_act<ACT>(z);
+        d = rt_act_grad<ACT>(z);
+    }
+}
+
 // Pullback of rt_physics_forward.  On entry kd holds the stage cotangent k̄; on exit it holds dO = the cotangent of the NN
 // face fluxes (0 on face 0) and xb the physics part of the state cotangent (flux-divergence transpose + Coriolis).
 // Ordered so that k̄ is consumed in place (Coriolis first, then F̄ overwrites k̄): this phase is the kernel's
@@ -418,9 +446,9 @@ __device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (
             const float th = 1.0f - __fdividef(2.0f, 1.0f + e);
             const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
             const float D0 = -kd[0][r], D1 = -kd[1][r], D2 = -kd[2][r];
-            float g0 = D0 * m.cs[0] * nu, g1 = D1 * m.cs[1] * nu, g2 = D2 * m.cs[2] * nu / m.Pr;
-            const float nub = D0 * m.cs[0] * gu + D1 * m.cs[1] * gv + D2 * m.cs[2] * gT / m.Pr;
-            const float ribs = nub * (-m.nu_minus / (2.0f * m.dRi)) * (1.0f - th * th);
+            float g0 = D0 * m.cs[0] * nu, g1 = D1 * m.cs[1] * nu, g2 = D2 * m.cs[2] * nu * m.inv_Pr;
+            const float nub = D0 * m.cs[0] * gu + D1 * m.cs[1] * gv + D2 * m.cs[2] * gT * m.inv_Pr;
+            const float ribs = nub * m.c_rib * (1.0f - th * th);
             g2 += __fdividef(ribs * m.B, S2);
             const float q = __fdividef(ribs * -Ri, S2) * 2.0f;
             g0 += q * m.sig_u * m.sig_u * (gu + m.eps);
@@ -585,7 +613,10 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
                 RT_STAMP_BEGIN();
                 // (1) stage cotangent and the physics pullback: dO = cotangent of the NN fluxes, xb = physics part of x̄
-                // (dO is parked in an L2-resident scratch slot and re-read one net at a time: 32 fewer live registers)
+                // (RT_PARK_DO: dO is parked in an L2-resident scratch slot and re-read one net at a time: 32 fewer live registers)
+#if !RT_PARK_DO
+                f32x16 dOk[3];
+#endif
                 {
                     f32x16 kb[3];
 #pragma unroll
@@ -593,6 +624,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                         for (int r = 0; r < 16; r++) kb[q][r] = cwl * lam[(q * 16 + r) * 64 + lane] + cwx * xb[q][r];
                     rt_physics_vjp(m, X, kb, h, xb);       // kb now holds dO
+#if RT_PARK_DO
 #pragma unroll
                     for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -600,28 +632,44 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                             const f32x4v v = {kb[q][4 * g], kb[q][4 * g + 1], kb[q][4 * g + 2], kb[q][4 * g + 3]};
                             *reinterpret_cast<f32x4v*>(xs4 + 4 * 3072 + (q * 4 + g) * 256) = v;
                         }
+#else
+#pragma unroll
+                    for (int q = 0; q < 3; q++) dOk[q] = kb[q];
+#endif
                 }
                 RT_STAMP(0);
                 float* dst = tp2 + ((size_t)step * 4 + st) * RT_TAPE2;
                 // the nets are handled one after the other so that only one net's hidden state is live at a time
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
+#if RT_PARK_DO
                     f32x16 dOn;
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const f32x4v v = *reinterpret_cast<const f32x4v*>(xs4 + 4 * 3072 + (n * 4 + g) * 256);
                         dOn[4 * g] = v[0]; dOn[4 * g + 1] = v[1]; dOn[4 * g + 2] = v[2]; dOn[4 * g + 3] = v[3];
                     }
-                    // (2) forward recompute of the hidden pre-activations (layer 3 enters linearly: not needed)
-                    f32x16 Z1[2];
+#else
+                    const f32x16 dOn = dOk[n];
+#endif
+                    // (2) forward recompute of the hidden layer 1 (layer 3 enters linearly: not needed); activation and
+                    //     derivative are evaluated once, together, and kept: A1 feeds layer 2 and the dW2 products, D1 the dZ1
+                    f32x16 A1[2], D1[2];
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
                         f32x16 acc;
 #pragma unroll
                         for (int r = 0; r < 16; r++) acc[r] = (t * 16 + r < 25) ? wl[RT_B1C + n * 50 + 2 * (t * 16 + r) + h] : 0.0f;
                         const int base = a1n[t] + n * 50 * RT_LD1;
-                        Z1[t] = rt_chain<48, 8>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
-                                                [&](int k) { return X[k >> 4][k & 15]; });
+                        acc = rt_chain<48, 8>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
+                                              [&](int k) { return X[k >> 4][k & 15]; });
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            float av = 0.0f, dv = 0.0f;
+                            if (t * 16 + r < 25) rt_act_pair<ACT>(acc[r], av, dv);
+                            A1[t][r] = av;
+                            D1[t][r] = dv;
+                        }
                     }
                     RT_STAMP(1);
                     if (n == 2) {
@@ -645,14 +693,22 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         for (int r = 0; r < 16; r++) acc[r] = r < 10 ? wl[RT_B2C + n * 20 + 2 * r + h] : 0.0f;
                         const int base2 = a2b + n * 20 * RT_LD2;
                         Z2 = rt_chain<25, 5>(wl, acc, [=](int k) { return base2 + 2 * k; },
-                                             [&](int k) { return rt_act<ACT>(Z1[k >> 4][k & 15]); });
+                                             [&](int k) { return A1[k >> 4][k & 15]; });
                     }
                     RT_STAMP(2);
                     // (3) layer 3: weight/bias gradient, then dZ2 = (W3^T dO) .* act'(Z2)
                     {
                         const f32x16 TA = rt_transpose(tb, dOn, wbase, rbase);
                         b3acc[n] += rt_sum16(TA);
-                        const f32x16 TB = rt_transpose(tb, act_tile<ACT>(Z2), wbase, rbase);
+                        f32x16 A2;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            float av = 0.0f, dv = 0.0f;
+                            if (r < 10) rt_act_pair<ACT>(Z2[r], av, dv);
+                            A2[r] = av;
+                            Z2[r] = dv;                                             // Z2 now holds act'(z2)
+                        }
+                        const f32x16 TB = rt_transpose(tb, A2, wbase, rbase);
                         gW3[n] = rt_outer(gW3[n], TA, TB);
                     }
                     {
@@ -660,7 +716,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         const f32x16 da = rt_chain<16, 8>(wl, (f32x16)(0.0f), [=](int k) { return base + RHO0(k) * RT_LD3; },
                                                           [&](int k) { return dOn[k]; });
 #pragma unroll
-                        for (int r = 0; r < 16; r++) Z2[r] = r < 10 ? da[r] * rt_act_grad<ACT>(Z2[r]) : 0.0f;
+                        for (int r = 0; r < 16; r++) Z2[r] = da[r] * Z2[r];
                     }
                     RT_STAMP(3);
                     // (4) layer 2: weight/bias gradient
@@ -669,7 +725,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         b2acc[n] += rt_sum16(TA);
 #pragma unroll
                         for (int t = 0; t < 2; t++) {
-                            const f32x16 TB = rt_transpose(tb, act_tile<ACT>(Z1[t]), wbase, rbase);
+                            const f32x16 TB = rt_transpose(tb, A1[t], wbase, rbase);
                             gW2[n][t] = rt_outer(gW2[n][t], TA, TB);
                         }
                     }
@@ -681,12 +737,12 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         const f32x16 da = rt_chain<10, 10>(wl, (f32x16)(0.0f), [=](int k) { return base + 2 * k * RT_LD2; },
                                                            [&](int k) { return Z2[k]; });
 #pragma unroll
-                        for (int r = 0; r < 16; r++) Z1[t][r] = (t * 16 + r < 25) ? da[r] * rt_act_grad<ACT>(Z1[t][r]) : 0.0f;
+                        for (int r = 0; r < 16; r++) D1[t][r] = da[r] * D1[t][r];     // dZ1 in place of act'(z1)
                     }
 #pragma unroll
                     for (int grp = 0; grp < 7; grp++) {
-                        const f32x4v v = {Z1[grp >> 2][(grp & 3) * 4], Z1[grp >> 2][(grp & 3) * 4 + 1],
-                                          Z1[grp >> 2][(grp & 3) * 4 + 2], Z1[grp >> 2][(grp & 3) * 4 + 3]};
+                        const f32x4v v = {D1[grp >> 2][(grp & 3) * 4], D1[grp >> 2][(grp & 3) * 4 + 1],
+                                          D1[grp >> 2][(grp & 3) * 4 + 2], D1[grp >> 2][(grp & 3) * 4 + 3]};
                         *reinterpret_cast<f32x4v*>(dst + (n * 7 + grp) * 256) = v;
                     }
                     RT_STAMP(5);
@@ -695,7 +751,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     for (int q = 0; q < 3; q++) {
                         const int base = b1T + q * 32 + n * 50 * RT_LD1;
                         xb[q] = rt_chain<25, 5>(wl, xb[q], [=](int g) { return base + 2 * g * RT_LD1; },
-                                                [&](int g) { return Z1[g >> 4][g & 15]; });
+                                                [&](int g) { return D1[g >> 4][g & 15]; });
                     }
                 }
                 RT_STAMP(6);
@@ -750,7 +806,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
             }
         }
         // biases: lanes (i, 0) and (i, 1) hold the even / odd column halves of row i_
-        const float s2 = b2acc[n] + swap32(b2acc[n]), s3 = b3acc[n] + swap32(b3acc[n]);
+        const float s2 = b2acc[n] + swap32(b2acc[n], h), s3 = b3acc[n] + swap32(b3acc[n], h);
         if (h == 0) {
             if (r_i < 10) out[n * m.net_size + m.b_off[1] + 2 * r_i + h_i] = s2;
             if (i_ >= 1) out[n * m.net_size + m.b_off[2] + i_ - 1] = s3;
@@ -832,7 +888,7 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
                 for (int q = 0; q < 3; q++) out[n * m.net_size + m.w_off[0] + (q * 32 + j) * 50 + f] = gW1[mt][q][r];
             }
         }
-        const float s1 = b1acc[mt] + swap32(b1acc[mt]);
+        const float s1 = b1acc[mt] + swap32(b1acc[mt], h);
         const int r_j = (j & 3) + 4 * (j >> 3), h_j = (j >> 2) & 1;
         const int G = mt * 16 + r_j;
         if (h == 0 && G < 75) out[(G / 25) * m.net_size + m.b_off[0] + 2 * (G % 25) + h_j] = s1;

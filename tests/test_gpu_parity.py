@@ -87,3 +87,45 @@ def test_long_horizon_2day_suite_shape():
     assert np.abs(sol_g - sol).max() < 5e-4
     assert np.isclose(tot_g, tot, rtol=5e-3)
     assert _rel(grad_g, g) < 2e-2
+
+
+# ---- engine selection: regtile (register-resident, static wind-mixing shape) vs tile16 (generic) -------------------
+def test_engine_selection_and_cross_check():
+    from colnde.nde import ENGINE_AUTO, ENGINE_TILE16, ENGINE_REGTILE
+    p = synthetic.wind_mixing_problem(70, n_frames=9, weight_divisor=1e2)      # 70 columns: ragged 32- and 16-column tiles
+    sc = [1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3]
+    res = {}
+    for eng in (ENGINE_TILE16, ENGINE_REGTILE, ENGINE_AUTO):
+        with colnde.ColumnNDE(p.cfg, p.n_columns, engine=eng) as nde:
+            assert nde.engine == (ENGINE_TILE16 if eng == ENGINE_TILE16 else ENGINE_REGTILE)
+            nde.set_problem(p.x0, p.bcs)
+            truth = nde.forward(p.weights_truth)
+            nde.set_problem(p.x0, p.bcs, truth)
+            res[eng] = (truth, nde.loss_grad(p.weights, sc))
+    # two independent kernel families agree to float32 round-off
+    assert np.abs(res[ENGINE_TILE16][0] - res[ENGINE_REGTILE][0]).max() < 2e-5
+    a, b = res[ENGINE_TILE16][1], res[ENGINE_REGTILE][1]
+    assert np.isclose(a[0], b[0], rtol=1e-4)
+    assert _rel(a[2], b[2].astype(np.float64)) < 1e-4
+    # smoothing is outside the regtile engine's coverage: AUTO falls back, an explicit request fails loudly
+    ps = synthetic.wind_mixing_problem(8, n_frames=3, smooth_NN=True)
+    with colnde.ColumnNDE(ps.cfg, 8) as nde:
+        assert nde.engine == ENGINE_TILE16
+    with pytest.raises(colnde.ColndeError, match="regtile"):
+        colnde.ColumnNDE(ps.cfg, 8, engine=ENGINE_REGTILE)
+
+
+@pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "diurnal", "conv_adj_branch", "swish", "raw", "dRi_small"])
+def test_regtile_engine_against_oracle(name):
+    from colnde.nde import ENGINE_REGTILE
+    p = synthetic.wind_mixing_problem(45, n_frames=9, weight_divisor=1e2, **VARIANTS[name])
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    np.testing.assert_allclose(terms_g, terms, rtol=LOSS_RTOL, atol=1e-12)
+    assert _rel(grad_g, g) < GRAD_REL
