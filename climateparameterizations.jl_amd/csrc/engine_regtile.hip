@@ -36,8 +36,14 @@ __device__ unsigned long long g_rt_stamps[16];
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define RHO0(r) (((r) & 3) + 8 * ((r) >> 2))
+// Optional "parking" of the flux cotangents / stage cotangents in an L2-resident scratch buffer to free registers.
+// Measured (tools/ab_bench.py, 32,768 columns): park both 126.1 ms, park x̄ only 132.3 ms, park nothing 121.6 ms per adjoint
+// launch, and parking adds 115 GB of scratch traffic: off.
 #ifndef RT_PARK_DO
-#define RT_PARK_DO 1
+#define RT_PARK_DO 0
+#endif
+#ifndef RT_PARK_XB
+#define RT_PARK_XB 0
 #endif
 #define RT_TAPE2 (21 * 256)   // floats per (tile, step, stage) of the layer-1 delta tape: 3 nets x 7 groups x 64 lanes x 4
 
@@ -551,6 +557,11 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     f32x16 xb[3], X[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) xb[q] = (f32x16)(0.0f);
+#if !RT_PARK_XB
+    f32x16 xbs[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) xbs[q] = (f32x16)(0.0f);
+#endif
 #pragma unroll
     for (int e = 0; e < 48; e++) lam[e * 64 + lane] = 0.0f;
 
@@ -755,6 +766,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     }
                 }
                 RT_STAMP(6);
+#if RT_PARK_XB
                 // park this stage's x̄ in an L2-resident scratch slot (keeps 48 registers free); the four slots of the step
                 // are summed into λ below
                 {
@@ -767,8 +779,13 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                             *reinterpret_cast<f32x4v*>(slot + (q * 4 + g) * 256) = v;
                         }
                 }
+#else
+#pragma unroll
+                for (int q = 0; q < 3; q++) xbs[q] += xb[q];
+#endif
             }
             // λ_n = λ_{n+1} + x̄_1 + x̄_2 + x̄_3 + x̄_4
+#if RT_PARK_XB
 #pragma unroll
             for (int grp = 0; grp < 12; grp++) {
                 f32x4v acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -777,6 +794,14 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                 for (int e = 0; e < 4; e++) lam[(grp * 4 + e) * 64 + lane] += acc4[e];
             }
+#else
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) lam[(q * 16 + r) * 64 + lane] += xbs[q][r];
+                xbs[q] = (f32x16)(0.0f);
+            }
+#endif
         }
     }
 
