@@ -36,6 +36,10 @@ struct DevModel {
     float nu0, nu_minus, Ric, dRi, inv_dRi, Pr, inv_Pr, c_rib, kappa, eps, ca_K, tau, alpha_g;
 };
 
+// a / b on the reciprocal unit (v_rcp_f32, 1 ulp).  NOTE: HIP's __fdividef(a, b) compiles to the full IEEE division
+// sequence (v_div_scale / v_div_fmas / v_div_fixup, ~10 instructions) unless fast-math is on: not used here.
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 // ---- activations (NNlib 0.7: relu, mish, swish, tanh, leakyrelu) ------------------------------------
 __device__ __forceinline__ float dev_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 

@@ -45,6 +45,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef RT_PARK_XB
 #define RT_PARK_XB 0
 #endif
+#ifndef RT_ADJ_CH
+#define RT_ADJ_CH 8       // A-operand prefetch depth (k-steps) of the adjoint kernel's layer-1 chains
+#endif
+// The adjoint kernel sits at the edge of the 256-VGPR + 256-AGPR file, so codegen details move its time by several per cent.
+// Measured in one process (tools/ab_bench.py, 32,768 columns): IEEE division in the activation pair 118.6 ms per launch vs
+// 125.9 ms with the reciprocal unit (fewer instructions, worse allocation); chain prefetch depth 4 / 8 / 16: no difference.
+#ifndef RT_ADJ_IEEE_DIV
+#define RT_ADJ_IEEE_DIV 1
+#endif
 #define RT_TAPE2 (21 * 256)   // floats per (tile, step, stage) of the layer-1 delta tape: 3 nets x 7 groups x 64 lanes x 4
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -94,10 +103,10 @@ __device__ __forceinline__ float rt_act(float z) {
     if (ACT == COLNDE_ACT_MISH) {
         const float e = __expf(fminf(z, 20.0f));
         const float n = e * (e + 2.0f);
-        return z * __fdividef(n, n + 2.0f);
+        return z * fast_div(n, n + 2.0f);
     }
-    if (ACT == COLNDE_ACT_SWISH) return __fdividef(z, 1.0f + __expf(-z));
-    if (ACT == COLNDE_ACT_TANH) { const float e = __expf(2.0f * fminf(fmaxf(z, -15.0f), 15.0f)); return 1.0f - __fdividef(2.0f, 1.0f + e); }
+    if (ACT == COLNDE_ACT_SWISH) return fast_div(z, 1.0f + __expf(-z));
+    if (ACT == COLNDE_ACT_TANH) { const float e = __expf(2.0f * fminf(fmaxf(z, -15.0f), 15.0f)); return 1.0f - fast_div(2.0f, 1.0f + e); }
     if (ACT == COLNDE_ACT_LEAKYRELU) return z > 0.0f ? z : 0.01f * z;
     return z;
 }
@@ -138,8 +147,8 @@ __device__ __forceinline__ RtBases rt_bases(int lane) {
 // operand reads and spills.
 #define RT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x00F)
 
-template <int N, int CH, class AF, class BF>
-__device__ __forceinline__ f32x16 rt_chain(const float* wl, f32x16 acc, AF aidx, BF bval) {
+template <int N, int CH, class AF, class BF, class FF>
+__device__ __forceinline__ f32x16 rt_chain_fill(const float* wl, f32x16 acc, AF aidx, BF bval, FF fill) {
     float a[2][CH];
 #pragma unroll
     for (int u = 0; u < CH; u++)
@@ -150,6 +159,7 @@ __device__ __forceinline__ f32x16 rt_chain(const float* wl, f32x16 acc, AF aidx,
 #pragma unroll
         for (int u = 0; u < CH; u++)
             if ((c + 1) * CH + u < N) a[(c + 1) & 1][u] = wl[aidx((c + 1) * CH + u)];
+        fill(c);        // independent VALU work: scheduled into the gaps between this chunk's dependent MFMAs
 #pragma unroll
         for (int u = 0; u < CH; u++)
             if (c * CH + u < N) acc = mfma32(a[c & 1][u], bval(c * CH + u), acc);
@@ -158,10 +168,16 @@ __device__ __forceinline__ f32x16 rt_chain(const float* wl, f32x16 acc, AF aidx,
     return acc;
 }
 
+template <int N, int CH, class AF, class BF>
+__device__ __forceinline__ f32x16 rt_chain(const float* wl, f32x16 acc, AF aidx, BF bval) {
+    return rt_chain_fill<N, CH>(wl, acc, aidx, bval, [](int) {});
+}
+
 // The three MLPs on the stage input X (3 tiles u, v, T) -> face-flux tiles O (3 tiles), all in registers.
+// The activations of a finished tile are issued as "filler" inside the next chain's chunks (MFMA shadow).
 template <int ACT>
 __device__ __forceinline__ void rt_mlp_forward(const float* wl, const RtBases& b, const f32x16 (&X)[3], int h, f32x16 (&O)[3]) {
-    f32x16 A1[5];
+    f32x16 A1[5];      // holds the raw pre-activation of a tile until the next chain's filler activates it in place
 #pragma unroll
     for (int mt = 0; mt < 5; mt++) {
         f32x16 acc;
@@ -171,25 +187,48 @@ __device__ __forceinline__ void rt_mlp_forward(const float* wl, const RtBases& b
             acc[r] = wl[RT_B1C + (G < 75 ? (G / 25) * 50 + 2 * (G % 25) : 150 + 2 * (G - 75)) + h];
         }
         const int base = b.a1[mt];
-        acc = rt_chain<48, 8>(wl, acc, [=](int s) { return base + (s >> 4) * 32 + RHO0(s & 15); },
-                              [&](int s) { return X[s >> 4][s & 15]; });
-        A1[mt] = act_tile<ACT>(acc);
+        A1[mt] = rt_chain_fill<48, 8>(wl, acc, [=](int s) { return base + (s >> 4) * 32 + RHO0(s & 15); },
+                                      [&](int s) { return X[s >> 4][s & 15]; },
+                                      [&](int c) {
+                                          if (mt > 0) {
+#pragma unroll
+                                              for (int r = 0; r < 16; r++)
+                                                  if (r / 3 == c) A1[mt > 0 ? mt - 1 : 0][r] = rt_act<ACT>(A1[mt > 0 ? mt - 1 : 0][r]);
+                                          }
+                                      });
     }
+    f32x16 Z2[3];
 #pragma unroll
     for (int n = 0; n < 3; n++) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = r < 10 ? wl[RT_B2C + n * 20 + 2 * r + h] : 0.0f;
         const int base2 = b.a2 + n * 20 * RT_LD2;
-        acc = rt_chain<25, 8>(wl, acc, [=](int s) { return base2 + 2 * s; },
-                              [&](int s) { return A1[(25 * n + s) >> 4][(25 * n + s) & 15]; });
-        const f32x16 A2 = act_tile<ACT>(acc);
+        // net 0 reads layer-1 registers G < 25 only, so tile 4 (G >= 64) can still be activated under its chain;
+        // nets 1, 2 activate the previous net's layer-2 outputs
+        Z2[n] = rt_chain_fill<25, 5>(wl, acc, [=](int s) { return base2 + 2 * s; },
+                                     [&](int s) { return A1[(25 * n + s) >> 4][(25 * n + s) & 15]; },
+                                     [&](int c) {
+                                         if (n == 0) {
+#pragma unroll
+                                             for (int r = 0; r < 16; r++)
+                                                 if (r / 4 == c) A1[4][r] = rt_act<ACT>(A1[4][r]);
+                                         } else {
+#pragma unroll
+                                             for (int r = 0; r < 10; r++)
+                                                 if (r / 2 == c) Z2[n > 0 ? n - 1 : 0][r] = rt_act<ACT>(Z2[n > 0 ? n - 1 : 0][r]);
+                                         }
+                                     });
+    }
+#pragma unroll
+    for (int r = 0; r < 10; r++) Z2[2][r] = rt_act<ACT>(Z2[2][r]);
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; r++) o[r] = wl[RT_B3C + n * 32 + RHO0(r) + 4 * h];
         const int base3 = b.a3 + n * 31 * RT_LD3;
-        o = rt_chain<10, 10>(wl, o, [=](int s) { return base3 + 2 * s; }, [&](int s) { return A2[s]; });
-        O[n] = o;
+        O[n] = rt_chain<10, 10>(wl, o, [=](int s) { return base3 + 2 * s; }, [&](int s) { return Z2[n][s]; });
     }
 }
 
@@ -213,9 +252,9 @@ __device__ __forceinline__ void rt_physics_forward(const DevModel& m, const f32x
             if (m.mpp) {
                 if (in) {
                     const float a1 = m.sig_u * (gu + m.eps), a2 = m.sig_v * (gv + m.eps);
-                    const float Ri = __fdividef(m.B * (gT + m.eps), a1 * a1 + a2 * a2);
+                    const float Ri = fast_div(m.B * (gT + m.eps), a1 * a1 + a2 * a2);
                     const float e = __expf(2.0f * fminf(fmaxf((Ri - m.Ric) * m.inv_dRi, -15.0f), 15.0f));
-                    const float th = 1.0f - __fdividef(2.0f, 1.0f + e);
+                    const float th = 1.0f - fast_div(2.0f, 1.0f + e);
                     const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
                     f0 -= m.cs[0] * nu * gu;
                     f1 -= m.cs[1] * nu * gv;
@@ -389,28 +428,33 @@ __device__ __forceinline__ float rt_act_grad(float z) {
     if (ACT == COLNDE_ACT_MISH) {
         const float e = __expf(fminf(z, 20.0f));
         const float n = e * (e + 2.0f);
-        const float t = __fdividef(n, n + 2.0f);
-        const float sg = __fdividef(e, 1.0f + e);
+        const float t = fast_div(n, n + 2.0f);
+        const float sg = fast_div(e, 1.0f + e);
         return t + z * (1.0f - t * t) * sg;
     }
-    if (ACT == COLNDE_ACT_SWISH) { const float sg = __fdividef(1.0f, 1.0f + __expf(-z)); return sg + z * sg * (1.0f - sg); }
-    if (ACT == COLNDE_ACT_TANH) { const float e = __expf(2.0f * fminf(fmaxf(z, -15.0f), 15.0f)); const float t = 1.0f - __fdividef(2.0f, 1.0f + e); return 1.0f - t * t; }
+    if (ACT == COLNDE_ACT_SWISH) { const float sg = fast_div(1.0f, 1.0f + __expf(-z)); return sg + z * sg * (1.0f - sg); }
+    if (ACT == COLNDE_ACT_TANH) { const float e = __expf(2.0f * fminf(fmaxf(z, -15.0f), 15.0f)); const float t = 1.0f - fast_div(2.0f, 1.0f + e); return 1.0f - t * t; }
     if (ACT == COLNDE_ACT_LEAKYRELU) return z > 0.0f ? 1.0f : 0.01f;
     return 1.0f;
 }
 
 // activation and its derivative in one evaluation (shared exponential)
+#if RT_ADJ_IEEE_DIV
+#define RT_PAIR_DIV(a_, b_) ((a_) / (b_))
+#else
+#define RT_PAIR_DIV(a_, b_) fast_div((a_), (b_))
+#endif
 template <int ACT>
 __device__ __forceinline__ void rt_act_pair(float z, float& a, float& d) {
     if (ACT == COLNDE_ACT_MISH) {
         const float e = __expf(fminf(z, 20.0f));
         const float n = e * (e + 2.0f);
-        const float t = __fdividef(n, n + 2.0f);
-        const float sg = __fdividef(e, 1.0f + e);
+        const float t = RT_PAIR_DIV(n, n + 2.0f);
+        const float sg = RT_PAIR_DIV(e, 1.0f + e);
         a = z * t;
         d = t + z * (1.0f - t * t) * sg;
     } else if (ACT == COLNDE_ACT_SWISH) {
-        const float sg = __fdividef(1.0f, 1.0f + __expf(-z));
+        const float sg = fast_div(1.0f, 1.0f + __expf(-z));
         a = z * sg;
         d = sg + a * (1.0f - sg);
     } else {
@@ -447,16 +491,16 @@ __device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (
             const float gu = (X[0][r] - Ud[r]) * Nz, gv = (X[1][r] - Vd[r]) * Nz, gT = (X[2][r] - Td[r]) * Nz;
             const float a1 = m.sig_u * (gu + m.eps), a2 = m.sig_v * (gv + m.eps);
             const float S2 = a1 * a1 + a2 * a2;
-            const float Ri = __fdividef(m.B * (gT + m.eps), S2);
+            const float Ri = fast_div(m.B * (gT + m.eps), S2);
             const float e = __expf(2.0f * fminf(fmaxf((Ri - m.Ric) * m.inv_dRi, -15.0f), 15.0f));
-            const float th = 1.0f - __fdividef(2.0f, 1.0f + e);
+            const float th = 1.0f - fast_div(2.0f, 1.0f + e);
             const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
             const float D0 = -kd[0][r], D1 = -kd[1][r], D2 = -kd[2][r];
             float g0 = D0 * m.cs[0] * nu, g1 = D1 * m.cs[1] * nu, g2 = D2 * m.cs[2] * nu * m.inv_Pr;
             const float nub = D0 * m.cs[0] * gu + D1 * m.cs[1] * gv + D2 * m.cs[2] * gT * m.inv_Pr;
             const float ribs = nub * m.c_rib * (1.0f - th * th);
-            g2 += __fdividef(ribs * m.B, S2);
-            const float q = __fdividef(ribs * -Ri, S2) * 2.0f;
+            g2 += fast_div(ribs * m.B, S2);
+            const float q = fast_div(ribs * -Ri, S2) * 2.0f;
             g0 += q * m.sig_u * m.sig_u * (gu + m.eps);
             g1 += q * m.sig_v * m.sig_v * (gv + m.eps);
             gb[0][r] = in ? g0 : 0.0f;
@@ -672,7 +716,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                         for (int r = 0; r < 16; r++) acc[r] = (t * 16 + r < 25) ? wl[RT_B1C + n * 50 + 2 * (t * 16 + r) + h] : 0.0f;
                         const int base = a1n[t] + n * 50 * RT_LD1;
-                        acc = rt_chain<48, 8>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
+                        acc = rt_chain<48, RT_ADJ_CH>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
                                               [&](int k) { return X[k >> 4][k & 15]; });
 #pragma unroll
                         for (int r = 0; r < 16; r++) {

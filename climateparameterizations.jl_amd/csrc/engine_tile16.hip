@@ -237,7 +237,7 @@ struct FaceGrad { float gu, gv, gT, S2, Ri; };
 // tanh(y) = 1 - 2/(1 + e^{2y}) on the fast exp / reciprocal units (|rel err| ~ 1e-6)
 __device__ __forceinline__ float fast_tanh(float y) {
     const float e = __expf(2.0f * fminf(fmaxf(y, -15.0f), 15.0f));
-    return 1.0f - __fdividef(2.0f, 1.0f + e);
+    return 1.0f - fast_div(2.0f, 1.0f + e);
 }
 
 __device__ __forceinline__ FaceGrad wm_face(const DevModel& m, const float* x, int f, float eps) {
@@ -249,7 +249,7 @@ __device__ __forceinline__ FaceGrad wm_face(const DevModel& m, const float* x, i
     g.gT = in ? (x[2 * Nz + f] - x[2 * Nz + f - 1]) * (float)Nz : 0.0f;
     const float a1 = m.sig_u * (g.gu + eps), a2 = m.sig_v * (g.gv + eps);
     g.S2 = a1 * a1 + a2 * a2;
-    g.Ri = __fdividef(m.B * (g.gT + eps), g.S2);   // local_richardson, NDE_training.jl:46-52
+    g.Ri = fast_div(m.B * (g.gT + eps), g.S2);   // local_richardson, NDE_training.jl:46-52
     return g;
 }
 
@@ -378,8 +378,8 @@ __device__ void physics_vjp(const DevModel& m, const float* xs, const float* dba
                     const float nub = D0 * m.cs[0] * g.gu + D1 * m.cs[1] * g.gv + D2 * m.cs[2] * g.gT / m.Pr;
                     ribs = nub * (-m.nu_minus / (2.0f * m.dRi)) * (1.0f - th * th);
                     if (!m.smooth_Ri) {
-                        g2 += __fdividef(ribs * m.B, g.S2);
-                        const float q = __fdividef(ribs * -g.Ri, g.S2) * 2.0f;
+                        g2 += fast_div(ribs * m.B, g.S2);
+                        const float q = fast_div(ribs * -g.Ri, g.S2) * 2.0f;
                         g0 += q * m.sig_u * m.sig_u * (g.gu + eps);
                         g1 += q * m.sig_v * m.sig_v * (g.gv + eps);
                     }
