@@ -62,6 +62,14 @@ def lib() -> ctypes.CDLL:
             raise ColndeError(
                 "%s is missing: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; g.build()'`"
                 " or `make -C %s`). colnde has no CPU fallback." % (LIB_PATH, CSRC))
+        # libcolnde.so and PyTorch-ROCm both need `libamdhip64.so.7`; the dynamic linker binds that SONAME once per process.
+        # PyTorch bundles its own build of the runtime and fails to initialise against the system one, so when torch is
+        # installed its copy must be the one that gets loaded: import it first.  (Without torch — e.g. under Julia — the
+        # library's RUNPATH finds the system ROCm runtime.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)   # AttributeError if a declared symbol is not exported

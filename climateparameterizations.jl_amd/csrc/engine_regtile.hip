@@ -909,40 +909,57 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
 #pragma unroll
         for (int q = 0; q < 3; q++) gW1[mt][q] = (f32x16)(0.0f);
     float b1acc[5] = {0, 0, 0, 0, 0};
+    // register images of the item in flight; the next item's loads are issued as soon as these have been consumed, so
+    // that their HBM latency hides under the current item's outer products
+    f32x4v xq[12], zq[21];
+    if (gw < n_items) {
+        const float* sx = tape + (size_t)gw * 3072 + lane * 4;
+        const float* sz = tape2 + (size_t)gw * RT_TAPE2 + lane * 4;
+#pragma unroll
+        for (int g = 0; g < 12; g++) xq[g] = *reinterpret_cast<const f32x4v*>(sx + g * 256);
+#pragma unroll
+        for (int g = 0; g < 21; g++) zq[g] = *reinterpret_cast<const f32x4v*>(sz + g * 256);
+    }
     for (long item = gw; item < n_items; item += GW) {
-        const float* sx = tape + (size_t)item * 3072 + lane * 4;
-        const float* sz = tape2 + (size_t)item * RT_TAPE2 + lane * 4;
+        const long nxt = item + GW;
         f32x16 TB[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             f32x16 x;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const f32x4v v = *reinterpret_cast<const f32x4v*>(sx + (q * 4 + g) * 256);
-                x[4 * g] = v[0]; x[4 * g + 1] = v[1]; x[4 * g + 2] = v[2]; x[4 * g + 3] = v[3];
+                x[4 * g] = xq[q * 4 + g][0]; x[4 * g + 1] = xq[q * 4 + g][1]; x[4 * g + 2] = xq[q * 4 + g][2]; x[4 * g + 3] = xq[q * 4 + g][3];
             }
             TB[q] = rt_transpose(tb, x, wbase, rbase);
         }
-        // the 75 taped registers (net n, g) re-assembled into the stacked tiles: G = 25 n + g = 16 mt + r
-        float zr[84];
+        if (nxt < n_items) {
+            const float* sx = tape + (size_t)nxt * 3072 + lane * 4;
 #pragma unroll
-        for (int grp = 0; grp < 21; grp++) {
-            const f32x4v v = *reinterpret_cast<const f32x4v*>(sz + grp * 256);
-            zr[4 * grp] = v[0]; zr[4 * grp + 1] = v[1]; zr[4 * grp + 2] = v[2]; zr[4 * grp + 3] = v[3];
+            for (int g = 0; g < 12; g++) xq[g] = *reinterpret_cast<const f32x4v*>(sx + g * 256);
         }
+        // the 75 taped registers (net n, g) re-assembled into the stacked tiles: G = 25 n + g = 16 mt + r
+        f32x16 TA[5];
 #pragma unroll
         for (int mt = 0; mt < 5; mt++) {
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int G = mt * 16 + r;
-                z[r] = G < 75 ? zr[(G / 25) * 28 + (G % 25)] : 0.0f;
+                const int e = (G / 25) * 28 + (G % 25);
+                z[r] = G < 75 ? zq[e >> 2][e & 3] : 0.0f;
             }
-            const f32x16 TA = rt_transpose(tb, z, wbase, rbase);
-            b1acc[mt] += rt_sum16(TA);
-#pragma unroll
-            for (int q = 0; q < 3; q++) gW1[mt][q] = rt_outer(gW1[mt][q], TA, TB[q]);
+            TA[mt] = rt_transpose(tb, z, wbase, rbase);
+            b1acc[mt] += rt_sum16(TA[mt]);
         }
+        if (nxt < n_items) {
+            const float* sz = tape2 + (size_t)nxt * RT_TAPE2 + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 21; g++) zq[g] = *reinterpret_cast<const f32x4v*>(sz + g * 256);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) gW1[mt][q] = rt_outer(gW1[mt][q], TA[mt], TB[q]);
     }
     float* out = slab_rows + (size_t)gw * (m.n_params + 8);
     // D[m = layer-1 row rho(r,h) of tile mt][n' = state feature 32 q + j]

@@ -154,3 +154,50 @@ def test_heat_conservation_and_shard_additivity_4096_columns():
             parts.append(sh.loss_grad(p.weights, sc))
     assert np.isclose(parts[0][0] + parts[1][0], tot, rtol=1e-4)
     assert _rel(parts[0][2] + parts[1][2], grad.astype(np.float64)) < 1e-4
+
+
+# ---- BASELINE configs[3] and configs[4] at (near) full size: size-independent properties --------------------------
+def test_config5_inference_65536_columns():
+    """double_gyre_nn forcing at 256 x 256 columns x 32 levels (BASELINE configs[4]); oracle on a strided sample,
+    linearity of the forcing in the surface flux, and column-integral identity sum_k dz * forcing = -(top - 0)."""
+    cfg, T, top, w = synthetic.inference_problem(256, 256)
+    with colnde.ColumnNDE(cfg, T.shape[0]) as nde:
+        out = nde.infer_forcing(w, T, top, 1000.0)
+        out2 = nde.infer_forcing(w, T, 2.0 * top, 1000.0)
+    idx = np.arange(0, T.shape[0], 997)
+    assert _rel(out[idx], O.infer_forcing(cfg, T[idx], top[idx], w, 1000.0)) < 1e-4
+    dz = 1000.0 / 32
+    np.testing.assert_allclose(out.sum(axis=1) * dz, -top, rtol=2e-4, atol=1e-9)          # telescoping flux divergence
+    # only the surface cell sees the top flux
+    np.testing.assert_array_equal(out[:, :-1], out2[:, :-1])
+    np.testing.assert_allclose((out2 - out)[:, -1] * dz, -top, rtol=1e-4, atol=1e-10)
+
+
+def test_config4_free_convection_64_levels_properties():
+    """Free convection, 64 levels, Dense(64,256) -> Dense(256,256) -> Dense(256,63) relu (BASELINE configs[3] shape, 2048
+    columns here): zero-weight known answer, shard additivity of loss/gradient, run-to-run determinism."""
+    p = synthetic.free_convection_problem(2048, Nz=64, n_save=9, substeps=2, t_end=0.05)
+    cfg = p.cfg
+    sc = [0, 0, 1.0, 0, 0, 0]
+    with colnde.ColumnNDE(cfg, 2048) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        sol0 = nde.forward(np.zeros(cfg.n_params, np.float32))
+        # zero weights: only the two boundary cells change, linearly in time (exact for any RK)
+        C = cfg.sigma[5] / cfg.sigma[2] * cfg.tau / cfg.H
+        t = np.asarray(cfg.save_times, np.float32)
+        np.testing.assert_array_equal(sol0[:, :, 1:-1], np.repeat(p.x0[:, None, 1:-1], 9, 1))
+        np.testing.assert_allclose(sol0[:, :, -1], p.x0[:, -1:] - C * 64 * p.bcs[:, 1:2] * t[None], rtol=1e-5, atol=2e-6)
+        truth = nde.forward(p.weights_truth)
+        nde.set_problem(p.x0, p.bcs, truth)
+        tot, terms, grad = nde.loss_grad(p.weights, sc)
+        tot2, _, grad2 = nde.loss_grad(p.weights, sc)
+    assert tot == tot2
+    np.testing.assert_array_equal(grad, grad2)
+    parts = []
+    for lo, hi in ((0, 700), (700, 2048)):
+        with colnde.ColumnNDE(cfg, hi - lo) as sh:
+            sh.set_global_columns(2048)
+            sh.set_problem(p.x0[lo:hi], p.bcs[lo:hi], truth[lo:hi])
+            parts.append(sh.loss_grad(p.weights, sc))
+    assert np.isclose(parts[0][0] + parts[1][0], tot, rtol=1e-4)
+    assert _rel(parts[0][2] + parts[1][2], grad.astype(np.float64)) < 1e-4
