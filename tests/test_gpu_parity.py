@@ -129,3 +129,48 @@ def test_regtile_engine_against_oracle(name):
     assert np.abs(sol_g - sol).max() < SOL_ATOL
     np.testing.assert_allclose(terms_g, terms, rtol=LOSS_RTOL, atol=1e-12)
     assert _rel(grad_g, g) < GRAD_REL
+
+
+# ---- edge cases: ragged/minimal shapes, non-uniform time axis, odd sub-step counts, both engines ---------------------
+@pytest.mark.parametrize("engine", [1, 2])
+@pytest.mark.parametrize("n_col", [1, 31, 33])
+def test_edge_columns_nonuniform_times(engine, n_col):
+    p = synthetic.wind_mixing_problem(n_col, n_frames=5, weight_divisor=1e2)
+    # non-uniform save times and 3 sub-steps per interval (train_tranges such as 1:20:200 give uniform spacing; the ABI
+    # takes any increasing `saveat`)
+    cfg = p.cfg.with_(save_times=(0.0, 0.004, 0.005, 0.011, 0.0125), substeps=3)
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(cfg, n_col, engine=engine) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+        tot_l, terms_l = nde.loss(p.weights, sc)
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL) and np.isclose(tot_l, tot, rtol=LOSS_RTOL)
+    assert _rel(grad_g, g) < GRAD_REL
+
+
+@pytest.mark.parametrize("engine", [1, 2])
+def test_zero_weights_give_zero_weight_gradient_blocks(engine):
+    """With all weights zero every hidden activation of a mish net is 0, so dW2, dW3 vanish identically while db3 and
+    (through mish'(0) = 0.6) the other gradients do not: checks the per-layer block placement in Flux.destructure order."""
+    p = synthetic.wind_mixing_problem(40, n_frames=5)
+    cfg = p.cfg
+    w0 = np.zeros(cfg.n_params, np.float32)
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = [1, 1, 1, 5e-3, 5e-3, 5e-3]
+    _, _, g_ref, _ = O.loss_and_grad(cfg, p.x0, p.bcs, w0, truth, sc)
+    with colnde.ColumnNDE(cfg, 40, engine=engine) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        _, _, g = nde.loss_grad(w0, sc)
+    ns = cfg.net_size
+    for n in range(3):
+        blk = g[n * ns:(n + 1) * ns]
+        W1, b1 = blk[:4800], blk[4800:4850]
+        W2, b2 = blk[4850:5850], blk[5850:5870]
+        W3, b3 = blk[5870:6490], blk[6490:6521]
+        assert np.all(W1 == 0) and np.all(b1 == 0) and np.all(W2 == 0) and np.all(b2 == 0) and np.all(W3 == 0)
+        assert np.abs(b3).max() > 0
+    assert _rel(g, g_ref) < GRAD_REL
