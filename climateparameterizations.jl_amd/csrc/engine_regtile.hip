@@ -16,6 +16,7 @@
 //   layer-3 outputs: row = face index (row 0 = bottom boundary face, where the NN contributes nothing).
 //
 // Reference arithmetic: wind_mixing/src/NDE_training.jl:46-165 (NDE, predict_flux, predict_NDE).
+#include <cstdlib>
 #include "engine_regtile.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -982,6 +983,264 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward solve on 16-column wave tiles (v_mfma_f32_16x16x4_f32), TWO wavefronts per SIMD
+//
+// Same idea as rt_forward_kernel with half the per-wave state: lane (j = lane & 15, g = lane >> 4) holds rows 4g..4g+3 of
+// a 16-row x 16-column tile in a float4; the B operand of k-step r is element r (K quad = rows r, 4+r, 8+r, 12+r).  A
+// 32-level variable is two tiles.  ~150 registers per wave, so eight waves (two per SIMD) share one LDS weight image and
+// one wave's activations / physics / RK update hide under the other's MFMA chains.  The stage tape is written in the
+// 32-column register-image format the adjoint and dW1 kernels read (two 16-column waves make one 32-column tile).
+//
+// Row placement: layer-1 outputs stacked into 10 tiles; quad Q = 4 t + r (rows 16t + 4g + r) carries features 4 (Q%13) + g
+// of net Q / 13 (13 quads = 52 rows per net, 2 of them padding); layer-2 outputs: quad Q2 = 4u + r carries features
+// 4 Q2 + g (Q2 < 5); layer-3 output row = face index.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4t mfma16t(float a, float b, f32x4t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float rot_dn16(float x, int lane) { return __shfl(x, (lane + 48) & 63); }   // from lane - 16
+__device__ __forceinline__ float rot_up16(float x, int lane) { return __shfl(x, (lane + 16) & 63); }   // from lane + 16
+
+struct V16 { f32x4t t[2]; };    // one 32-level variable of 16 columns: level = 16 tau + 4 g + r
+
+__device__ __forceinline__ V16 shift_down16(const V16& T, int lane, float below) {
+    const int g = lane >> 4;
+    const float r0 = rot_dn16(T.t[0][3], lane), r1 = rot_dn16(T.t[1][3], lane);
+    V16 o;
+    o.t[0][0] = g == 0 ? below : r0;
+    o.t[1][0] = g == 0 ? r0 : r1;
+#pragma unroll
+    for (int tau = 0; tau < 2; tau++) { o.t[tau][1] = T.t[tau][0]; o.t[tau][2] = T.t[tau][1]; o.t[tau][3] = T.t[tau][2]; }
+    return o;
+}
+
+__device__ __forceinline__ V16 shift_up16(const V16& T, int lane, float above) {
+    const int g = lane >> 4;
+    const float r0 = rot_up16(T.t[0][0], lane), r1 = rot_up16(T.t[1][0], lane);
+    V16 o;
+    o.t[0][3] = g == 3 ? r1 : r0;
+    o.t[1][3] = g == 3 ? above : r1;
+#pragma unroll
+    for (int tau = 0; tau < 2; tau++) { o.t[tau][0] = T.t[tau][1]; o.t[tau][1] = T.t[tau][2]; o.t[tau][2] = T.t[tau][3]; }
+    return o;
+}
+
+// acc += sum_{s<N} A_s B_s on 16x16x4 MFMAs, A operands prefetched one chunk ahead (see rt_chain)
+template <int N, int CH, class AF, class BF>
+__device__ __forceinline__ f32x4t rt16_chain(const float* wl, f32x4t acc, AF aidx, BF bval) {
+    float a[2][CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++)
+        if (u < N) a[0][u] = wl[aidx(u)];
+    RT_SCHED_FENCE();
+#pragma unroll
+    for (int c = 0; c * CH < N; c++) {
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+            if ((c + 1) * CH + u < N) a[(c + 1) & 1][u] = wl[aidx((c + 1) * CH + u)];
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+            if (c * CH + u < N) acc = mfma16t(a[c & 1][u], bval(c * CH + u), acc);
+        RT_SCHED_FENCE();
+    }
+    return acc;
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(512)
+rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
+                    const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
+                    float* __restrict__ tape, int n_col) {
+    float* wl = rt_smem;
+    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int wt = blockIdx.x * 8 + wave;                 // 16-column tile
+    const int tile32 = wt >> 1, half = wt & 1;
+    if (tile32 * 32 >= n_col) return;                     // (both halves of a live 32-column tile run: the tape must be whole)
+    const int col = wt * 16 + j;
+    const bool valid = col < n_col;
+    const int colc = min(col, n_col - 1);
+    // A-operand bases (this lane as output row i = 4 g_i + r_i of a 16-row tile; k index = g)
+    const int i_ = lane & 15, g_i = i_ >> 2, r_i = i_ & 3;
+    int a1b[10];
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        const int Q = 4 * t + r_i, f = 4 * (Q % 13) + g_i;
+        const int row = (Q < 39 && f < 50) ? (Q / 13) * 50 + f : 0;       // padding rows read a valid row; never consumed
+        a1b[t] = RT_W1C + row * RT_LD1 + 4 * g;
+    }
+    int a2b[2], a2l[2], a3b[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int Q2 = 4 * u + r_i;
+        const int row2 = Q2 < 5 ? 4 * Q2 + g_i : 0;
+        a2b[u] = RT_W2C + row2 * RT_LD2 + g;
+        a2l[u] = RT_W2C + row2 * RT_LD2 + (g < 2 ? 48 + g : 50);           // last quad of a net: features 48, 49, then the zero column
+        a3b[u] = RT_W3C + (16 * u + i_ - 1) * RT_LD3 + g;
+    }
+    RtBC bc;
+    float bc5;
+    {
+        const float* bp = bcs + (size_t)colc * 6;
+        bc.b[0] = bp[0]; bc.t[0] = bp[1]; bc.b[1] = bp[2]; bc.t[1] = bp[3]; bc.b[2] = bp[4]; bc5 = bp[5];
+        bc.t[2] = bc5;
+    }
+    V16 Xn[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++) {
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(x0 + (size_t)colc * 96 + q * 32 + 16 * tau + 4 * g);
+            Xn[q].t[tau] = v;
+            if (sol && valid) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + q * 32 + 16 * tau + 4 * g) = v;
+        }
+    const int n_steps = (n_save - 1) * substeps;
+    // 32-column register image: group (q*4 + 2 tau + (g>>1)), lane32 = j + 16 half + 32 (g & 1)
+    float* tp = tape ? tape + (size_t)tile32 * n_steps * 4 * 3072 + ((g >> 1) * 64 + j + 16 * half + 32 * (g & 1)) * 4 : nullptr;
+    const float Nz = 32.0f;
+    int step = 0;
+    for (int iv = 0; iv < n_save - 1; iv++) {
+        const float t0 = save_times[iv];
+        const float dt = (save_times[iv + 1] - t0) / (float)substeps;
+        for (int s = 0; s < substeps; s++, step++) {
+            const float ts = t0 + (float)s * dt;
+            V16 Xs[3], Kacc[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) { Xs[q] = Xn[q]; Kacc[q].t[0] = (f32x4t)(0.0f); Kacc[q].t[1] = (f32x4t)(0.0f); }
+#pragma nounroll
+            for (int st = 0; st < 4; st++) {
+                const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);
+                const float cb = (st == 0 || st == 3) ? 1.0f / 6.0f : 1.0f / 3.0f;
+                if (tp) {
+                    float* o = tp + ((size_t)step * 4 + st) * 3072;
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(o + (q * 4 + 2 * tau) * 256) = Xs[q].t[tau];
+                }
+                bc.t[2] = rt_top_flux(m, bc5, ts + ca * dt);
+                // ---- three MLPs -------------------------------------------------------------------------------------
+                f32x4t A1[10];
+#pragma unroll
+                for (int t = 0; t < 10; t++) {
+                    f32x4t acc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int Q = 4 * t + r;
+                        acc[r] = Q < 39 ? wl[RT_B1C + (Q / 13) * 50 + min(4 * (Q % 13) + g, 49)] : 0.0f;
+                    }
+                    const int base = a1b[t];
+                    acc = rt16_chain<24, 8>(wl, acc, [=](int k) { return base + (k >> 3) * 32 + ((k >> 2) & 1) * 16 + (k & 3); },
+                                            [&](int k) { return Xs[k >> 3].t[(k >> 2) & 1][k & 3]; });
+#pragma unroll
+                    for (int r = 0; r < 4; r++) A1[t][r] = rt_act<ACT>(acc[r]);
+                }
+                V16 O[3];
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    f32x4t A2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        f32x4t acc;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[r] = (4 * u + r < 5) ? wl[RT_B2C + n * 20 + 4 * (4 * u + r) + g] : 0.0f;
+                        const int base = a2b[u] + n * 20 * RT_LD2, basel = a2l[u] + n * 20 * RT_LD2;
+                        acc = rt16_chain<13, 13>(wl, acc, [=](int k) { return k < 12 ? base + 4 * k : basel; },
+                                                 [&](int k) { return A1[(13 * n + k) >> 2][(13 * n + k) & 3]; });
+#pragma unroll
+                        for (int r = 0; r < 4; r++) A2[u][r] = rt_act<ACT>(acc[r]);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        f32x4t acc;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[r] = wl[RT_B3C + n * 32 + 16 * v + 4 * g + r];
+                        const int base = a3b[v] + n * 31 * RT_LD3;
+                        O[n].t[v] = rt16_chain<5, 5>(wl, acc, [=](int k) { return base + 4 * k; },
+                                                     [&](int k) { return A2[k >> 2][k & 3]; });
+                    }
+                }
+                // ---- physics (predict_flux / predict_NDE), face index = level index ----------------------------------
+                V16 F[3];
+                {
+                    V16 Ud, Vd, Td;
+                    if (m.mpp || m.ca) {
+                        Ud = shift_down16(Xs[0], lane, 0.0f); Vd = shift_down16(Xs[1], lane, 0.0f); Td = shift_down16(Xs[2], lane, 0.0f);
+                    }
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const bool in = !(tau == 0 && r == 0 && g == 0);       // face >= 1
+                            float f0 = in ? O[0].t[tau][r] : 0.0f, f1 = in ? O[1].t[tau][r] : 0.0f, f2 = in ? O[2].t[tau][r] : 0.0f;
+                            if (!m.zero_w && !in) { f0 = bc.b[0]; f1 = bc.b[1]; f2 = bc.b[2]; }
+                            if (m.mpp) {
+                                if (in) {
+                                    const float gu = (Xs[0].t[tau][r] - Ud.t[tau][r]) * Nz, gv = (Xs[1].t[tau][r] - Vd.t[tau][r]) * Nz,
+                                                gT = (Xs[2].t[tau][r] - Td.t[tau][r]) * Nz;
+                                    const float a1 = m.sig_u * (gu + m.eps), a2 = m.sig_v * (gv + m.eps);
+                                    const float Ri = fast_div(m.B * (gT + m.eps), a1 * a1 + a2 * a2);
+                                    const float e = __expf(2.0f * fminf(fmaxf((Ri - m.Ric) * m.inv_dRi, -15.0f), 15.0f));
+                                    const float th = 1.0f - fast_div(2.0f, 1.0f + e);
+                                    const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
+                                    f0 -= m.cs[0] * nu * gu;
+                                    f1 -= m.cs[1] * nu * gv;
+                                    f2 -= m.cs[2] * (nu * m.inv_Pr) * gT;
+                                } else if (m.zero_w) {
+                                    f0 += bc.b[0] - m.s0[0]; f1 += bc.b[1] - m.s0[1]; f2 += bc.b[2] - m.s0[2];
+                                }
+                            } else if (m.ca && in) {
+                                const float gT = (Xs[2].t[tau][r] - Td.t[tau][r]) * Nz;
+                                f2 -= m.cs[2] * m.kappa * fminf(0.0f, gT);
+                            }
+                            F[0].t[tau][r] = f0; F[1].t[tau][r] = f1; F[2].t[tau][r] = f2;
+                        }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float top = m.zero_w ? bc.t[k] - m.s0[k] : bc.t[k];
+                    const V16 Fu = shift_up16(F[k], lane, top);
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float v = -m.A[k] * (Fu.t[tau][r] - F[k].t[tau][r]);
+                            if (k == 0) v += m.cor_u * (m.sig_v * Xs[1].t[tau][r] + m.mu_v);
+                            if (k == 1) v -= m.cor_v * (m.sig_u * Xs[0].t[tau][r] + m.mu_u);
+                            F[k].t[tau][r] = v;                           // F now holds the tendency K
+                        }
+                }
+                // ---- RK4 bookkeeping: accumulate, form the next stage input ------------------------------------------
+                const float can = st == 2 ? 1.0f : 0.5f;                    // abscissa of the NEXT stage
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) {
+                        Kacc[q].t[tau] += cb * F[q].t[tau];
+                        Xs[q].t[tau] = Xn[q].t[tau] + (can * dt) * F[q].t[tau];
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) Xn[q].t[tau] += dt * Kacc[q].t[tau];
+            if (s == substeps - 1 && sol && valid) {
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++)
+                        *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save + iv + 1) * 96 + q * 32 + 16 * tau + 4 * g) = Xn[q].t[tau];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 bool rt_supported(const DevModel& m) {
@@ -1011,6 +1270,12 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_SWISH>);
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_TANH>);
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_LEAKYRELU>);
+    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_IDENTITY>);
+    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_RELU>);
+    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_MISH>);
+    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_SWISH>);
+    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_TANH>);
+    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_LEAKYRELU>);
     RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_IDENTITY>);
     RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_RELU>);
     RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_MISH>);
@@ -1029,20 +1294,38 @@ hipError_t rt_launch_pack(const DevModel& m, const float* w, float* wimg, hipStr
 hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* x0, const float* bcs,
                              const float* save_times, int n_save, int substeps, float* sol, float* tape, int n_col,
                              hipStream_t stream) {
-    const int n_wtiles = (n_col + RT_COLS - 1) / RT_COLS;
-    const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
     const size_t lds = rt_forward_lds_bytes();
+    // COLNDE_RT_FWD=32 selects the one-wave-per-SIMD 32-column kernel (A/B aid); default: 16-column tiles, two waves per SIMD
+    static const bool use32 = getenv("COLNDE_RT_FWD") && atoi(getenv("COLNDE_RT_FWD")) == 32;
+    if (use32) {
+        const int n_wtiles = (n_col + RT_COLS - 1) / RT_COLS;
+        const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
 #define RT_FWD(A) hipLaunchKernelGGL(rt_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, n_col)
-    switch (m.acts[0]) {
-        case COLNDE_ACT_IDENTITY: RT_FWD(COLNDE_ACT_IDENTITY); break;
-        case COLNDE_ACT_RELU: RT_FWD(COLNDE_ACT_RELU); break;
-        case COLNDE_ACT_MISH: RT_FWD(COLNDE_ACT_MISH); break;
-        case COLNDE_ACT_SWISH: RT_FWD(COLNDE_ACT_SWISH); break;
-        case COLNDE_ACT_TANH: RT_FWD(COLNDE_ACT_TANH); break;
-        case COLNDE_ACT_LEAKYRELU: RT_FWD(COLNDE_ACT_LEAKYRELU); break;
-        default: return hipErrorInvalidValue;
-    }
+        switch (m.acts[0]) {
+            case COLNDE_ACT_IDENTITY: RT_FWD(COLNDE_ACT_IDENTITY); break;
+            case COLNDE_ACT_RELU: RT_FWD(COLNDE_ACT_RELU); break;
+            case COLNDE_ACT_MISH: RT_FWD(COLNDE_ACT_MISH); break;
+            case COLNDE_ACT_SWISH: RT_FWD(COLNDE_ACT_SWISH); break;
+            case COLNDE_ACT_TANH: RT_FWD(COLNDE_ACT_TANH); break;
+            case COLNDE_ACT_LEAKYRELU: RT_FWD(COLNDE_ACT_LEAKYRELU); break;
+            default: return hipErrorInvalidValue;
+        }
 #undef RT_FWD
+    } else {
+        const int n_wt16 = 2 * ((n_col + RT_COLS - 1) / RT_COLS);
+        const dim3 grid((n_wt16 + 7) / 8), block(512);
+#define RT_FWD(A) hipLaunchKernelGGL(rt16_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, n_col)
+        switch (m.acts[0]) {
+            case COLNDE_ACT_IDENTITY: RT_FWD(COLNDE_ACT_IDENTITY); break;
+            case COLNDE_ACT_RELU: RT_FWD(COLNDE_ACT_RELU); break;
+            case COLNDE_ACT_MISH: RT_FWD(COLNDE_ACT_MISH); break;
+            case COLNDE_ACT_SWISH: RT_FWD(COLNDE_ACT_SWISH); break;
+            case COLNDE_ACT_TANH: RT_FWD(COLNDE_ACT_TANH); break;
+            case COLNDE_ACT_LEAKYRELU: RT_FWD(COLNDE_ACT_LEAKYRELU); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef RT_FWD
+    }
     return hipGetLastError();
 }
 
