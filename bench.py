@@ -25,10 +25,16 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-# algorithmic figures per column-timestep (stated in DESIGN.md §Measurement)
-MLP_FLOP_PER_RHS = 2 * 3 * (96 * 50 + 50 * 20 + 20 * 31)          # 38,520: three 96-50-20-31 nets, 2·Σ in·out
-ADJ_FLOP_PER_COLSTEP = 4 * 3 * MLP_FLOP_PER_RHS                    # 4 stages × (recompute + dX + dW) = 462,240
-FWD_FLOP_PER_COLSTEP = 4 * MLP_FLOP_PER_RHS                        # 154,080
+# algorithmic figures per column-timestep (stated in DESIGN.md §4/§5): 2·Σ in·out per net, three nets.
+# Each kernel is charged only the MLP flops it actually performs (padding, activations and physics are not counted):
+L1, L2, L3 = 2 * 3 * 96 * 50, 2 * 3 * 50 * 20, 2 * 3 * 20 * 31      # 28,800 / 6,000 / 3,720 flop per RHS
+MLP_FLOP_PER_RHS = L1 + L2 + L3                                     # 38,520
+FWD_FLOP_PER_COLSTEP = 4 * MLP_FLOP_PER_RHS                         # forward kernel: 154,080
+# adjoint pass per stage = dX (38,520) + dW (38,520) + whatever forward state is recomputed rather than taped
+ADJ_FLOP_REGTILE = 4 * (MLP_FLOP_PER_RHS + (L2 + L3) + L2)          # rt_adjoint_kernel with Z1 taped: dX + dW2/dW3 + layer-2 recompute = 216,960
+ADJ_FLOP_REGTILE_NOZ = ADJ_FLOP_REGTILE + 4 * L1                    # ... recomputing layer 1 as well: 332,160
+DW1_FLOP_PER_COLSTEP = 4 * L1                                       # rt_dw1_kernel: 115,200
+ADJ_FLOP_TILE16 = 4 * 3 * MLP_FLOP_PER_RHS                          # tile16 adjoint_kernel: recompute + dX + dW = 462,240 (SURVEY's "3x forward")
 PEAK_FP32_MFMA_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: FP32 matrix, dense
 PEAK_HBM_GBPS = 8000.0
 
@@ -170,7 +176,12 @@ def main():
                     traffic = tj.get("adjoint_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        achieved_tf = ADJ_FLOP_PER_COLSTEP * units_per_launch / adj_s / 1e12
+        regtile = nde.engine == 2
+        ztape = regtile and os.environ.get("COLNDE_RT_ZTAPE", "1") != "0" and os.environ.get("COLNDE_RT_FWD", "16") != "32"
+        adj_flop = (ADJ_FLOP_REGTILE if ztape else ADJ_FLOP_REGTILE_NOZ) if regtile else ADJ_FLOP_TILE16
+        dw1_s = ms_dw1 / max(n_dw1, 1) * 1e-3
+        achieved_tf = adj_flop * units_per_launch / adj_s / 1e12
+        step_flop = FWD_FLOP_PER_COLSTEP + adj_flop + (DW1_FLOP_PER_COLSTEP if regtile else 0)
         line = {
             "metric": "column-timesteps/sec (fwd+adjoint), 32-level wind-mixing NDE",
             "value": value, "unit": "column-timesteps/s",
@@ -186,10 +197,13 @@ def main():
                 "rk4_steps": cfg.n_steps, "n_params": cfg.n_params, "parallelism": "columns sharded x%d" % world,
             },
             "roofline": {
-                "kernel": "adjoint_kernel", "bound": "mfma",
+                "kernel": "rt_adjoint_kernel" if regtile else "adjoint_kernel", "bound": "mfma",
                 "achieved": achieved_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                "algorithmic_flop_per_column_timestep": ADJ_FLOP_PER_COLSTEP,
+                "algorithmic_flop_per_column_timestep": adj_flop,
+                "whole_step": {"algorithmic_flop_per_column_timestep": step_flop,
+                               "achieved": step_flop * colsteps_per_step / (elapsed / args.steps) / 1e12 / world, "unit": "TFLOP/s per GPU",
+                               "frac": step_flop * colsteps_per_step / (elapsed / args.steps) / 1e12 / world / PEAK_FP32_MFMA_TFLOPS},
                 "avg_launch_ms": adj_s * 1e3, "launches": n_adj,
                 "hbm": {"achieved": ab["adjoint"] * units_per_launch / adj_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": ab["adjoint"] * units_per_launch / adj_s / 1e9 / PEAK_HBM_GBPS,
@@ -198,7 +212,9 @@ def main():
                                    "achieved": FWD_FLOP_PER_COLSTEP * units_per_launch / fwd_s / 1e12, "unit": "TFLOP/s",
                                    "hbm_GBps": ab["forward"] * units_per_launch / fwd_s / 1e9},
                 "reduce_kernel_avg_ms": ms_red / max(n_red, 1),
-                "dw1_kernel_avg_ms": ms_dw1 / max(n_dw1, 1),
+                "dw1_kernel": {"avg_launch_ms": dw1_s * 1e3,
+                               "achieved": (DW1_FLOP_PER_COLSTEP * units_per_launch / dw1_s / 1e12) if dw1_s > 0 else None,
+                               "unit": "TFLOP/s"},
                 "engine": {1: "tile16", 2: "regtile"}.get(nde.engine, str(nde.engine)),
             },
             "loss_total": float(res[nde.n_params + 6]),

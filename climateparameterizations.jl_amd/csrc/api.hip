@@ -50,7 +50,8 @@ struct colnde_handle {
     bool fwd_wlds = false;
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
     float* d_wimg = nullptr;
-    float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_xscr = nullptr;
+    float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_xscr = nullptr, *d_rt_tapez = nullptr;
+    bool rt_ztape = false;         // layer-1 pre-activations taped by the forward kernel instead of recomputed by the adjoint
     int rt_rows = 0;
     float *d_w = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_x0 = nullptr, *d_bcs = nullptr, *d_truth = nullptr,
           *d_sol = nullptr, *d_tape = nullptr, *d_slab = nullptr, *d_out = nullptr, *d_times = nullptr,
@@ -296,7 +297,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     drain_events(h);
-    void* ptrs[] = {h->d_rt_xscr, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
+    void* ptrs[] = {h->d_rt_tapez, h->d_rt_xscr, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
                     h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -459,11 +460,21 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
             e = hipMalloc((void**)&h->d_rt_tape, n1 * sizeof(float));
             if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_tape2, n2 * sizeof(float));
             if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_xscr, (size_t)rt_n_wtiles(h->n_col) * 5 * 3072 * sizeof(float));
+            // Z1 tape: COLNDE_RT_ZTAPE=0 disables it (the adjoint then recomputes layer 1); it is also dropped when the
+            // allocation does not fit (it trades n2 more floats of HBM for 288 of the adjoint's 840 MFMAs per stage)
+            const char* ez = getenv("COLNDE_RT_ZTAPE");
+            h->rt_ztape = !rt_forward_is32() && !(ez && atoi(ez) == 0);
+            if (e == hipSuccess && h->rt_ztape && hipMalloc((void**)&h->d_rt_tapez, n2 * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError();
+                h->d_rt_tapez = nullptr;
+                h->rt_ztape = false;
+            }
             if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tapes failed: %s", (n1 + n2) * sizeof(float), hipGetErrorString(e));
         }
         Timed tm(h, K_FORWARD);
         e = rt_launch_forward(h->m, h->d_wimg, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, d_sol,
-                              with_tape ? h->d_rt_tape : nullptr, h->n_col, h->stream);
+                              with_tape ? h->d_rt_tape : nullptr, (with_tape && h->rt_ztape) ? h->d_rt_tapez : nullptr, h->n_col,
+                              h->stream);
         if (e != hipSuccess) return fail("rt forward launch failed: %s", hipGetErrorString(e));
         return 0;
     }
@@ -554,7 +565,8 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         {
             Timed tm(h, K_ADJOINT);
             hipError_t e = rt_launch_adjoint(h->m, h->d_wimg, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol,
-                                             h->d_truth, h->d_rt_tape, h->d_rt_tape2, h->d_rt_xscr, lw, h->d_rt_slab, h->n_col, h->stream);
+                                             h->d_truth, h->d_rt_tape, h->d_rt_tape2, h->d_rt_xscr, h->rt_ztape ? h->d_rt_tapez : nullptr, lw,
+                                             h->d_rt_slab, h->n_col, h->stream);
             if (e != hipSuccess) return fail("rt adjoint launch failed: %s", hipGetErrorString(e));
         }
         {

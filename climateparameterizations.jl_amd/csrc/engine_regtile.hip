@@ -560,12 +560,13 @@ __host__ __device__ constexpr int rt_combo(int n, int mt) { return n == 0 ? mt :
 // tape of stage inputs (written by rt_forward_kernel):  [tile][step][stage][12 groups][64 lanes][4]
 // tape2 of layer-1 deltas (written here, read by rt_dw1_kernel): [tile][step][stage][net][7 groups][64 lanes][4]; element e of
 // group grp of net n is register g = 4 grp + e (features 2g, 2g+1 of net n; g >= 25: zero padding)
-template <int ACT>
+template <int ACT, bool ZT>
 __global__ void __launch_bounds__(256)
 rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ bcs,
                   const float* __restrict__ save_times, int n_save, int substeps, const float* __restrict__ sol,
                   const float* __restrict__ truth, const float* __restrict__ tape, float* __restrict__ tape2,
                   float* xscr /* [tile][5][3072]: the four stage cotangents of the step in flight + the flux cotangents */,
+                  const float* __restrict__ tapez /* layer-1 pre-activations taped by the forward kernel (ZT) */,
                   LossWeights lw, float* __restrict__ slab, int n_col) {
     float* wl = rt_smem;
     for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
@@ -614,6 +615,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     const float* tp = tape + (size_t)tile * n_steps * 4 * 3072 + lane * 4;
     float* xs4 = xscr + (size_t)tile * 5 * 3072 + lane * 4;
     float* tp2 = tape2 + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4;
+    const float* tpz = ZT ? tapez + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4 : nullptr;
 
     // loss injection at save point n: λ += ∂loss/∂sol[:, n]; also the six raw sums of squares
     auto inject = [&](int n, bool add) {
@@ -714,11 +716,25 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
                         f32x16 acc;
+                        if (ZT) {
+                            // the forward kernel taped these pre-activations: 288 MFMAs per stage less than recomputing them
+                            const float* srcz = tpz + ((size_t)step * 4 + st) * RT_TAPE2 + n * 7 * 256;
 #pragma unroll
-                        for (int r = 0; r < 16; r++) acc[r] = (t * 16 + r < 25) ? wl[RT_B1C + n * 50 + 2 * (t * 16 + r) + h] : 0.0f;
-                        const int base = a1n[t] + n * 50 * RT_LD1;
-                        acc = rt_chain<48, RT_ADJ_CH>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
-                                              [&](int k) { return X[k >> 4][k & 15]; });
+                            for (int g4 = 0; g4 < 4; g4++) {
+                                if (t * 4 + g4 < 7) {
+                                    const f32x4v v = *reinterpret_cast<const f32x4v*>(srcz + (t * 4 + g4) * 256);
+                                    acc[4 * g4] = v[0]; acc[4 * g4 + 1] = v[1]; acc[4 * g4 + 2] = v[2]; acc[4 * g4 + 3] = v[3];
+                                } else {
+                                    acc[4 * g4] = 0.0f; acc[4 * g4 + 1] = 0.0f; acc[4 * g4 + 2] = 0.0f; acc[4 * g4 + 3] = 0.0f;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) acc[r] = (t * 16 + r < 25) ? wl[RT_B1C + n * 50 + 2 * (t * 16 + r) + h] : 0.0f;
+                            const int base = a1n[t] + n * 50 * RT_LD1;
+                            acc = rt_chain<48, RT_ADJ_CH>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
+                                                          [&](int k) { return X[k >> 4][k & 15]; });
+                        }
 #pragma unroll
                         for (int r = 0; r < 16; r++) {
                             float av = 0.0f, dv = 0.0f;
@@ -1053,7 +1069,7 @@ template <int ACT>
 __global__ void __launch_bounds__(512)
 rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
                     const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
-                    float* __restrict__ tape, int n_col) {
+                    float* __restrict__ tape, float* __restrict__ tapez, int n_col) {
     float* wl = rt_smem;
     for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
     __syncthreads();
@@ -1102,6 +1118,9 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
     const int n_steps = (n_save - 1) * substeps;
     // 32-column register image: group (q*4 + 2 tau + (g>>1)), lane32 = j + 16 half + 32 (g & 1)
     float* tp = tape ? tape + (size_t)tile32 * n_steps * 4 * 3072 + ((g >> 1) * 64 + j + 16 * half + 32 * (g & 1)) * 4 : nullptr;
+    // layer-1 pre-activations, taped in the adjoint kernel's per-net register-image format (same as the delta tape): feature
+    // f = 4 qq + g of net n is element (2qq & 3) + (g >> 1) of group qq >> 1, lane32 = j + 16 half + 32 (g & 1)
+    float* tz = tapez ? tapez + (size_t)tile32 * n_steps * 4 * RT_TAPE2 + (j + 16 * half + 32 * (g & 1)) * 4 + (g >> 1) : nullptr;
     const float Nz = 32.0f;
     int step = 0;
     for (int iv = 0; iv < n_save - 1; iv++) {
@@ -1137,6 +1156,14 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                     const int base = a1b[t];
                     acc = rt16_chain<24, 8>(wl, acc, [=](int k) { return base + (k >> 3) * 32 + ((k >> 2) & 1) * 16 + (k & 3); },
                                             [&](int k) { return Xs[k >> 3].t[(k >> 2) & 1][k & 3]; });
+                    if (tz) {
+                        float* oz = tz + ((size_t)step * 4 + st) * RT_TAPE2;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int Q = 4 * t + r, qq = Q % 13;
+                            if (Q < 39 && (qq < 12 || g < 2)) oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = acc[r];
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; r++) A1[t][r] = rt_act<ACT>(acc[r]);
                 }
@@ -1276,12 +1303,18 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_SWISH>);
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_TANH>);
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_LEAKYRELU>);
-    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_IDENTITY>);
-    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_RELU>);
-    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_MISH>);
-    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_SWISH>);
-    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_TANH>);
-    RT_SETATTR(rt_adjoint_kernel<COLNDE_ACT_LEAKYRELU>);
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_SWISH, false>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_TANH, false>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
 #undef RT_SETATTR
     return hipSuccess;
 }
@@ -1291,13 +1324,18 @@ hipError_t rt_launch_pack(const DevModel& m, const float* w, float* wimg, hipStr
     return hipGetLastError();
 }
 
+// COLNDE_RT_FWD=32 selects the one-wave-per-SIMD 32-column forward kernel (A/B aid; it does not tape Z1)
+bool rt_forward_is32() {
+    static const bool v = getenv("COLNDE_RT_FWD") && atoi(getenv("COLNDE_RT_FWD")) == 32;
+    return v;
+}
+
 hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* x0, const float* bcs,
-                             const float* save_times, int n_save, int substeps, float* sol, float* tape, int n_col,
-                             hipStream_t stream) {
+                             const float* save_times, int n_save, int substeps, float* sol, float* tape, float* tapez,
+                             int n_col, hipStream_t stream) {
     const size_t lds = rt_forward_lds_bytes();
     // COLNDE_RT_FWD=32 selects the one-wave-per-SIMD 32-column kernel (A/B aid); default: 16-column tiles, two waves per SIMD
-    static const bool use32 = getenv("COLNDE_RT_FWD") && atoi(getenv("COLNDE_RT_FWD")) == 32;
-    if (use32) {
+    if (rt_forward_is32()) {
         const int n_wtiles = (n_col + RT_COLS - 1) / RT_COLS;
         const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
 #define RT_FWD(A) hipLaunchKernelGGL(rt_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, n_col)
@@ -1314,7 +1352,7 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
     } else {
         const int n_wt16 = 2 * ((n_col + RT_COLS - 1) / RT_COLS);
         const dim3 grid((n_wt16 + 7) / 8), block(512);
-#define RT_FWD(A) hipLaunchKernelGGL(rt16_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, n_col)
+#define RT_FWD(A) hipLaunchKernelGGL(rt16_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, tapez, n_col)
         switch (m.acts[0]) {
             case COLNDE_ACT_IDENTITY: RT_FWD(COLNDE_ACT_IDENTITY); break;
             case COLNDE_ACT_RELU: RT_FWD(COLNDE_ACT_RELU); break;
@@ -1331,11 +1369,17 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
 
 hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,
                              int substeps, const float* sol, const float* truth, const float* tape, float* tape2,
-                             float* xscr, const LossWeights& lw, float* slab, int n_col, hipStream_t stream) {
+                             float* xscr, const float* tapez, const LossWeights& lw, float* slab, int n_col, hipStream_t stream) {
     const int n_wtiles = rt_n_wtiles(n_col);
     const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
     const size_t lds = rt_adjoint_lds_bytes();
-#define RT_ADJ(A) hipLaunchKernelGGL(rt_adjoint_kernel<A>, grid, block, lds, stream, m, wimg, bcs, save_times, n_save, substeps, sol, truth, tape, tape2, xscr, lw, slab, n_col)
+#define RT_ADJ(A)                                                                                                             \
+    do {                                                                                                                      \
+        if (tapez) hipLaunchKernelGGL((rt_adjoint_kernel<A, true>), grid, block, lds, stream, m, wimg, bcs, save_times, n_save, \
+                                      substeps, sol, truth, tape, tape2, xscr, tapez, lw, slab, n_col);                      \
+        else hipLaunchKernelGGL((rt_adjoint_kernel<A, false>), grid, block, lds, stream, m, wimg, bcs, save_times, n_save,    \
+                                substeps, sol, truth, tape, tape2, xscr, tapez, lw, slab, n_col);                            \
+    } while (0)
     switch (m.acts[0]) {
         case COLNDE_ACT_IDENTITY: RT_ADJ(COLNDE_ACT_IDENTITY); break;
         case COLNDE_ACT_RELU: RT_ADJ(COLNDE_ACT_RELU); break;
