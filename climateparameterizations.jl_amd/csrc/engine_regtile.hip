@@ -744,20 +744,6 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         }
                     }
                     RT_STAMP(1);
-                    if (n == 2) {
-                        // X is dead: fetch the next stage's input while the rest of this stage runs
-                        const int qn = step * 4 + st - 1;
-                        if (qn >= 0) {
-                            const float* src = tp + (size_t)qn * 3072;
-#pragma unroll
-                            for (int q = 0; q < 3; q++)
-#pragma unroll
-                                for (int g = 0; g < 4; g++) {
-                                    const f32x4v v = *reinterpret_cast<const f32x4v*>(src + (q * 4 + g) * 256);
-                                    X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
-                                }
-                        }
-                    }
                     f32x16 Z2;
                     {
                         f32x16 acc;
@@ -818,6 +804,21 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         *reinterpret_cast<f32x4v*>(dst + (n * 7 + grp) * 256) = v;
                     }
                     RT_STAMP(5);
+                    if (n == 2) {
+                        // fetch the next stage's input under the last W1^T products (75 MFMAs hide the HBM latency); X has
+                        // been dead since the physics pullback (ZT) / net 2's layer-1 chains
+                        const int qn = step * 4 + st - 1;
+                        if (qn >= 0) {
+                            const float* src = tp + (size_t)qn * 3072;
+#pragma unroll
+                            for (int q = 0; q < 3; q++)
+#pragma unroll
+                                for (int g = 0; g < 4; g++) {
+                                    const f32x4v v = *reinterpret_cast<const f32x4v*>(src + (q * 4 + g) * 256);
+                                    X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
+                                }
+                        }
+                    }
                     // (6) x̄ += W1_n^T dZ1_n
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
