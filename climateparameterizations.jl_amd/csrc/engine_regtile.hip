@@ -40,6 +40,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // Optional "parking" of the flux cotangents / stage cotangents in an L2-resident scratch buffer to free registers.
 // Measured (tools/ab_bench.py, 32,768 columns): park both 126.1 ms, park x̄ only 132.3 ms, park nothing 121.6 ms per adjoint
 // launch, and parking adds 115 GB of scratch traffic: off.
+#ifndef RT_PROBE
+#define RT_PROBE 0     // timing probes only (wrong results): 1 = Z1 tape reads, 2 = X tape reads, 4 = tape2 stores hit one hot slot
+#endif
 #ifndef RT_PARK_DO
 #define RT_PARK_DO 0
 #endif
@@ -49,32 +52,31 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef RT_ADJ_CH
 #define RT_ADJ_CH 8       // A-operand prefetch depth (k-steps) of the adjoint kernel's layer-1 chains
 #endif
-// The adjoint kernel sits at the edge of the 256-VGPR + 256-AGPR file, so codegen details move its time by several per cent.
-// Measured in one process (tools/ab_bench.py, 32,768 columns): IEEE division in the activation pair 118.6 ms per launch vs
-// 125.9 ms with the reciprocal unit (fewer instructions, worse allocation); chain prefetch depth 4 / 8 / 16: no difference.
-#ifndef RT_ADJ_IEEE_DIV
-#define RT_ADJ_IEEE_DIV 1
-#endif
 #define RT_TAPE2 (21 * 256)   // floats per (tile, step, stage) of the layer-1 delta tape: 3 nets x 7 groups x 64 lanes x 4
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// value held by the partner lane (lane ^ 32): v_permlane32_swap (one VALU op, no LDS round trip; semantics probed on
-// gfx950 by tools/probe/permlane.hip: result 0 = low half in both halves, result 1 = high half in both halves)
-__device__ __forceinline__ float swap32(float x, int h) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+// exchange between the two lane halves with v_permlane32_swap (one VALU op, no LDS round trip): lanes h = 0 receive
+// `from_hi` as held by their partner lane + 32, lanes h = 1 receive `from_lo` as held by their partner lane - 32.
+// (The instruction swaps vdst[32:63] with src0[0:31]: result 0 = {vdst.lo, src0.lo}, result 1 = {vdst.hi, src0.hi};
+// probed on gfx950 by tools/probe/permlane.hip.)  The two values go in as separate operands on purpose: selecting the
+// value to send per lane first (`h ? T[i] : T[j]`) is folded by LLVM into a divergent dynamic index into the register
+// tile, which lowers to a 16-long v_cmp/v_cndmask chain per exchange.
+__device__ __forceinline__ float xchg32(float from_hi, float from_lo, int h) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(from_hi), __float_as_uint(from_lo), false, false);
     return __uint_as_float(h ? r[0] : r[1]);
 }
+__device__ __forceinline__ float swap32(float x, int h) { return xchg32(x, x, h); }
 
 // tile value one level below (rho - 1); level -1 reads `below`
 __device__ __forceinline__ f32x16 shift_down(const f32x16 T, int h, float below) {
     f32x16 o;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const float send = h ? (g > 0 ? T[(4 * g + 15) & 15] : 0.0f) : T[4 * g + 3];   // h=1 sends T[4g-1], h=0 sends T[4g+3]
-        const float recv = swap32(send, h);
+        // row 8g (h = 0) takes T[4g-1] of the upper half; row 8g+4 (h = 1) takes T[4g+3] of the lower half
+        const float recv = xchg32(g > 0 ? T[(4 * g + 15) & 15] : 0.0f, T[4 * g + 3], h);
         o[4 * g] = (h == 0 && g == 0) ? below : recv;
         o[4 * g + 1] = T[4 * g];
         o[4 * g + 2] = T[4 * g + 1];
@@ -88,8 +90,8 @@ __device__ __forceinline__ f32x16 shift_up(const f32x16 T, int h, float above) {
     f32x16 o;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const float send = h ? T[4 * g] : (g < 3 ? T[(4 * g + 4) & 15] : 0.0f);         // h=1 sends T[4g], h=0 sends T[4g+4]
-        const float recv = swap32(send, h);
+        // row 8g+3 (h = 0) takes T[4g] of the upper half; row 8g+7 (h = 1) takes T[4g+4] of the lower half
+        const float recv = xchg32(T[4 * g], g < 3 ? T[(4 * g + 4) & 15] : 0.0f, h);
         o[4 * g + 3] = (h == 1 && g == 3) ? above : recv;
         o[4 * g] = T[4 * g + 1];
         o[4 * g + 1] = T[4 * g + 2];
@@ -439,21 +441,19 @@ __device__ __forceinline__ float rt_act_grad(float z) {
     return 1.0f;
 }
 
-// activation and its derivative in one evaluation (shared exponential)
-#if RT_ADJ_IEEE_DIV
-#define RT_PAIR_DIV(a_, b_) ((a_) / (b_))
-#else
-#define RT_PAIR_DIV(a_, b_) fast_div((a_), (b_))
-#endif
+// activation and its derivative in one evaluation: one exponential and one reciprocal.
+// mish(z) = z n / (n + 2) with n = e (e + 2), e = exp(z);  mish'(z) = e w / (n + 2)^2 with
+// w = 4 (z + 1) + 4 e^2 + e^3 + e (4 z + 6) = p + e (n + 2 e + p + 2), p = 4 z + 4.
 template <int ACT>
 __device__ __forceinline__ void rt_act_pair(float z, float& a, float& d) {
     if (ACT == COLNDE_ACT_MISH) {
         const float e = __expf(fminf(z, 20.0f));
         const float n = e * (e + 2.0f);
-        const float t = RT_PAIR_DIV(n, n + 2.0f);
-        const float sg = RT_PAIR_DIV(e, 1.0f + e);
-        a = z * t;
-        d = t + z * (1.0f - t * t) * sg;
+        const float r = __builtin_amdgcn_rcpf(n + 2.0f);
+        const float p = 4.0f * z + 4.0f;
+        const float w = fmaf(e, (n + 2.0f * e) + (p + 2.0f), p);
+        a = z * (n * r);
+        d = (e * r) * (w * r);
     } else if (ACT == COLNDE_ACT_SWISH) {
         const float sg = fast_div(1.0f, 1.0f + __expf(-z));
         a = z * sg;
@@ -696,7 +696,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #endif
                 }
                 RT_STAMP(0);
-                float* dst = tp2 + ((size_t)step * 4 + st) * RT_TAPE2;
+                float* dst = tp2 + ((RT_PROBE & 4) ? (size_t)0 : ((size_t)step * 4 + st) * RT_TAPE2);
                 // the nets are handled one after the other so that only one net's hidden state is live at a time
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
@@ -718,7 +718,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         f32x16 acc;
                         if (ZT) {
                             // the forward kernel taped these pre-activations: 288 MFMAs per stage less than recomputing them
-                            const float* srcz = tpz + ((size_t)step * 4 + st) * RT_TAPE2 + n * 7 * 256;
+                            const float* srcz = tpz + ((RT_PROBE & 1) ? (size_t)0 : ((size_t)step * 4 + st) * RT_TAPE2) + n * 7 * 256;
 #pragma unroll
                             for (int g4 = 0; g4 < 4; g4++) {
                                 if (t * 4 + g4 < 7) {
@@ -809,7 +809,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         // been dead since the physics pullback (ZT) / net 2's layer-1 chains
                         const int qn = step * 4 + st - 1;
                         if (qn >= 0) {
-                            const float* src = tp + (size_t)qn * 3072;
+                            const float* src = tp + ((RT_PROBE & 2) ? (size_t)0 : (size_t)qn * 3072);
 #pragma unroll
                             for (int q = 0; q < 3; q++)
 #pragma unroll
