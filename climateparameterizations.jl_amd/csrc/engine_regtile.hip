@@ -40,9 +40,6 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // Optional "parking" of the flux cotangents / stage cotangents in an L2-resident scratch buffer to free registers.
 // Measured (tools/ab_bench.py, 32,768 columns): park both 126.1 ms, park x̄ only 132.3 ms, park nothing 121.6 ms per adjoint
 // launch, and parking adds 115 GB of scratch traffic: off.
-#ifndef RT_PROBE
-#define RT_PROBE 0     // timing probes only (wrong results): 1 = Z1 tape reads, 2 = X tape reads, 4 = tape2 stores hit one hot slot
-#endif
 #ifndef RT_PARK_DO
 #define RT_PARK_DO 0
 #endif
@@ -464,6 +461,15 @@ __device__ __forceinline__ void rt_act_pair(float z, float& a, float& d) {
     }
 }
 
+// in place on register G' of a two-tile layer-1 block: A <- act(A), D <- act'(A)
+template <int ACT>
+__device__ __forceinline__ void rt_act_pair_at(f32x16 (&A)[2], f32x16 (&D)[2], int G) {
+    float av, dv;
+    rt_act_pair<ACT>(A[G >> 4][G & 15], av, dv);
+    A[G >> 4][G & 15] = av;
+    D[G >> 4][G & 15] = dv;
+}
+
 // Pullback of rt_physics_forward.  On entry kd holds the stage cotangent k̄; on exit it holds dO = the cotangent of the NN
 // face fluxes (0 on face 0) and xb the physics part of the state cotangent (flux-divergence transpose + Coriolis).
 // Ordered so that k̄ is consumed in place (Coriolis first, then F̄ overwrites k̄): this phase is the kernel's
@@ -648,6 +654,18 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     };
     inject(0, false);
 
+    // taped layer-1 pre-activations of net n at (step, stage): registers G' < 25 of Z (padding registers untouched)
+    auto load_z1 = [&](int step, int st, int n, f32x16 (&Z)[2]) {
+        const float* srcz = tpz + ((size_t)step * 4 + st) * RT_TAPE2 + n * 7 * 256;
+#pragma unroll
+        for (int grp = 0; grp < 7; grp++) {
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(srcz + grp * 256);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (4 * grp + e < 25) Z[grp >> 2][(grp & 3) * 4 + e] = v[e];
+        }
+    };
+
     // stage input of the very first stage handled (last step, stage 3)
     {
         const float* src = tp + ((size_t)n_steps * 4 - 1) * 3072;
@@ -696,7 +714,11 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #endif
                 }
                 RT_STAMP(0);
-                float* dst = tp2 + ((RT_PROBE & 4) ? (size_t)0 : ((size_t)step * 4 + st) * RT_TAPE2);
+                float* dst = tp2 + ((size_t)step * 4 + st) * RT_TAPE2;
+                f32x16 A1[2], D1[2];        // net n: act(z1), act'(z1) (then dZ1); register G' = 16 t + r <-> features 2G', 2G'+1
+                f32x16 A1n[2], D1n[2];      // net n + 1, in flight under net n's W1^T products (ZT)
+#pragma unroll
+                for (int r = 9; r < 16; r++) { A1[1][r] = 0.0f; D1[1][r] = 0.0f; A1n[1][r] = 0.0f; D1n[1][r] = 0.0f; }
                 // the nets are handled one after the other so that only one net's hidden state is live at a time
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
@@ -710,37 +732,31 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #else
                     const f32x16 dOn = dOk[n];
 #endif
-                    // (2) forward recompute of the hidden layer 1 (layer 3 enters linearly: not needed); activation and
-                    //     derivative are evaluated once, together, and kept: A1 feeds layer 2 and the dW2 products, D1 the dZ1
-                    f32x16 A1[2], D1[2];
+                    // (2) hidden layer 1 of net n: activation A1 (feeds layer 2 and the dW2 products) and derivative D1 (feeds dZ1),
+                    //     evaluated once, together.  With the Z1 tape (ZT) nets 1 and 2 arrive already activated: their taped
+                    //     pre-activations were fetched and activated in the shadow of the previous net's W1^T products (6).
+                    if (ZT) {
+                        if (n == 0) {
+                            load_z1(step, st, 0, A1);
 #pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        f32x16 acc;
-                        if (ZT) {
-                            // the forward kernel taped these pre-activations: 288 MFMAs per stage less than recomputing them
-                            const float* srcz = tpz + ((RT_PROBE & 1) ? (size_t)0 : ((size_t)step * 4 + st) * RT_TAPE2) + n * 7 * 256;
+                            for (int G = 0; G < 25; G++) rt_act_pair_at<ACT>(A1, D1, G);
+                        }
+                    } else {
 #pragma unroll
-                            for (int g4 = 0; g4 < 4; g4++) {
-                                if (t * 4 + g4 < 7) {
-                                    const f32x4v v = *reinterpret_cast<const f32x4v*>(srcz + (t * 4 + g4) * 256);
-                                    acc[4 * g4] = v[0]; acc[4 * g4 + 1] = v[1]; acc[4 * g4 + 2] = v[2]; acc[4 * g4 + 3] = v[3];
-                                } else {
-                                    acc[4 * g4] = 0.0f; acc[4 * g4 + 1] = 0.0f; acc[4 * g4 + 2] = 0.0f; acc[4 * g4 + 3] = 0.0f;
-                                }
-                            }
-                        } else {
+                        for (int t = 0; t < 2; t++) {
+                            f32x16 acc;
 #pragma unroll
                             for (int r = 0; r < 16; r++) acc[r] = (t * 16 + r < 25) ? wl[RT_B1C + n * 50 + 2 * (t * 16 + r) + h] : 0.0f;
                             const int base = a1n[t] + n * 50 * RT_LD1;
                             acc = rt_chain<48, RT_ADJ_CH>(wl, acc, [=](int k) { return base + (k >> 4) * 32 + RHO0(k & 15); },
                                                           [&](int k) { return X[k >> 4][k & 15]; });
-                        }
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            float av = 0.0f, dv = 0.0f;
-                            if (t * 16 + r < 25) rt_act_pair<ACT>(acc[r], av, dv);
-                            A1[t][r] = av;
-                            D1[t][r] = dv;
+                            for (int r = 0; r < 16; r++) {
+                                float av = 0.0f, dv = 0.0f;
+                                if (t * 16 + r < 25) rt_act_pair<ACT>(acc[r], av, dv);
+                                A1[t][r] = av;
+                                D1[t][r] = dv;
+                            }
                         }
                     }
                     RT_STAMP(1);
@@ -755,6 +771,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     }
                     RT_STAMP(2);
                     // (3) layer 3: weight/bias gradient, then dZ2 = (W3^T dO) .* act'(Z2)
+                    //     (evaluating the layer-2 activation pairs inside the W3^T chain instead was measured slower: 94.8 vs 89.7 ms)
                     {
                         const f32x16 TA = rt_transpose(tb, dOn, wbase, rbase);
                         b3acc[n] += rt_sum16(TA);
@@ -777,6 +794,8 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         for (int r = 0; r < 16; r++) Z2[r] = da[r] * Z2[r];
                     }
                     RT_STAMP(3);
+                    // fetch net n + 1's taped pre-activations now: dW2, W2^T and the first W1^T chunk cover the HBM latency
+                    if (ZT && n < 2) load_z1(step, st, n + 1, A1n);
                     // (4) layer 2: weight/bias gradient
                     {
                         const f32x16 TA = rt_transpose(tb, Z2, wbase, rbase);
@@ -809,7 +828,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         // been dead since the physics pullback (ZT) / net 2's layer-1 chains
                         const int qn = step * 4 + st - 1;
                         if (qn >= 0) {
-                            const float* src = tp + ((RT_PROBE & 2) ? (size_t)0 : (size_t)qn * 3072);
+                            const float* src = tp + (size_t)qn * 3072;
 #pragma unroll
                             for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -823,8 +842,21 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
                         const int base = b1T + q * 32 + n * 50 * RT_LD1;
-                        xb[q] = rt_chain<25, 5>(wl, xb[q], [=](int g) { return base + 2 * g * RT_LD1; },
-                                                [&](int g) { return D1[g >> 4][g & 15]; });
+                        xb[q] = rt_chain_fill<25, 5>(wl, xb[q], [=](int g) { return base + 2 * g * RT_LD1; },
+                                                     [&](int g) { return D1[g >> 4][g & 15]; },
+                                                     [&](int c) {
+                                                         // net n + 1's 25 activation pairs, spread over the 15 chunks
+                                                         if (ZT && n < 2 && (q > 0 || c > 0)) {
+#pragma unroll
+                                                             for (int G = 0; G < 25; G++)
+                                                                 if ((G * 14) / 25 + 1 == q * 5 + c)
+                                                                     rt_act_pair_at<ACT>(A1n, D1n, G);
+                                                         }
+                                                     });
+                    }
+                    if (ZT && n < 2) {
+#pragma unroll
+                        for (int t = 0; t < 2; t++) { A1[t] = A1n[t]; D1[t] = D1n[t]; }
                     }
                 }
                 RT_STAMP(6);
