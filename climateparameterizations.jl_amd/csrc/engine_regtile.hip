@@ -40,6 +40,12 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // Optional "parking" of the flux cotangents / stage cotangents in an L2-resident scratch buffer to free registers.
 // Measured (tools/ab_bench.py, 32,768 columns): park both 126.1 ms, park x̄ only 132.3 ms, park nothing 121.6 ms per adjoint
 // launch, and parking adds 115 GB of scratch traffic: off.
+#ifndef RT_X_AT_TOP
+#define RT_X_AT_TOP 1    // 1: load the stage input at the top of its stage instead of one stage ahead
+#endif
+#ifndef RT_Z_EARLY
+#define RT_Z_EARLY 1
+#endif
 #ifndef RT_PARK_DO
 #define RT_PARK_DO 0
 #endif
@@ -666,9 +672,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
         }
     };
 
-    // stage input of the very first stage handled (last step, stage 3)
-    {
-        const float* src = tp + ((size_t)n_steps * 4 - 1) * 3072;
+    // stage input (taped by the forward kernel)
+    auto load_x = [&](int step, int st) {
+        const float* src = tp + ((size_t)step * 4 + st) * 3072;
 #pragma unroll
         for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -676,7 +682,10 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 const f32x4v v = *reinterpret_cast<const f32x4v*>(src + (q * 4 + g) * 256);
                 X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
             }
-    }
+    };
+#if !RT_X_AT_TOP
+    load_x(n_steps - 1, 3);
+#endif
 
     for (int iv = n_save - 2; iv >= 0; iv--) {
         const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
@@ -688,6 +697,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
                 const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
                 RT_STAMP_BEGIN();
+#if RT_X_AT_TOP
+                load_x(step, st);
+#endif
                 // (1) stage cotangent and the physics pullback: dO = cotangent of the NN fluxes, xb = physics part of x̄
                 // (RT_PARK_DO: dO is parked in an L2-resident scratch slot and re-read one net at a time: 32 fewer live registers)
 #if !RT_PARK_DO
@@ -795,7 +807,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     }
                     RT_STAMP(3);
                     // fetch net n + 1's taped pre-activations now: dW2, W2^T and the first W1^T chunk cover the HBM latency
+#if RT_Z_EARLY
                     if (ZT && n < 2) load_z1(step, st, n + 1, A1n);
+#endif
                     // (4) layer 2: weight/bias gradient
                     {
                         const f32x16 TA = rt_transpose(tb, Z2, wbase, rbase);
@@ -823,21 +837,17 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         *reinterpret_cast<f32x4v*>(dst + (n * 7 + grp) * 256) = v;
                     }
                     RT_STAMP(5);
-                    if (n == 2) {
-                        // fetch the next stage's input under the last W1^T products (75 MFMAs hide the HBM latency); X has
-                        // been dead since the physics pullback (ZT) / net 2's layer-1 chains
+#if !RT_X_AT_TOP
+                    if (n == 2 && step * 4 + st > 0) {
+                        // fetch the next stage's input under the last W1^T products; X has been dead since the physics
+                        // pullback (ZT) / net 2's layer-1 chains
                         const int qn = step * 4 + st - 1;
-                        if (qn >= 0) {
-                            const float* src = tp + (size_t)qn * 3072;
-#pragma unroll
-                            for (int q = 0; q < 3; q++)
-#pragma unroll
-                                for (int g = 0; g < 4; g++) {
-                                    const f32x4v v = *reinterpret_cast<const f32x4v*>(src + (q * 4 + g) * 256);
-                                    X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
-                                }
-                        }
+                        load_x(qn >> 2, qn & 3);
                     }
+#endif
+#if !RT_Z_EARLY
+                    if (ZT && n < 2) load_z1(step, st, n + 1, A1n);
+#endif
                     // (6) x̄ += W1_n^T dZ1_n
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
