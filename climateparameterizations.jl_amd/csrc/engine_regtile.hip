@@ -46,6 +46,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef RT_Z_EARLY
 #define RT_Z_EARLY 1
 #endif
+#ifndef RT_Z0_AT_TOP
+#define RT_Z0_AT_TOP 0
+#endif
+#ifndef RT_TOP_FENCE
+#define RT_TOP_FENCE 0
+#endif
+#ifndef RT16_WAVES
+#define RT16_WAVES 8      // wavefronts per workgroup of the 16-column forward kernel (two per SIMD)
+#endif
 #ifndef RT_PARK_DO
 #define RT_PARK_DO 0
 #endif
@@ -697,8 +706,18 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
                 const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
                 RT_STAMP_BEGIN();
+                f32x16 A1[2], D1[2];        // net n: act(z1), act'(z1) (then dZ1); register G' = 16 t + r <-> features 2G', 2G'+1
+                f32x16 A1n[2], D1n[2];      // net n + 1, in flight under net n's W1^T products (ZT)
+#pragma unroll
+                for (int r = 9; r < 16; r++) { A1[1][r] = 0.0f; D1[1][r] = 0.0f; A1n[1][r] = 0.0f; D1n[1][r] = 0.0f; }
 #if RT_X_AT_TOP
                 load_x(step, st);
+#endif
+#if RT_Z0_AT_TOP
+                if (ZT) load_z1(step, st, 0, A1);
+#endif
+#if RT_TOP_FENCE
+                __builtin_amdgcn_sched_barrier(0);
 #endif
                 // (1) stage cotangent and the physics pullback: dO = cotangent of the NN fluxes, xb = physics part of x̄
                 // (RT_PARK_DO: dO is parked in an L2-resident scratch slot and re-read one net at a time: 32 fewer live registers)
@@ -727,10 +746,6 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 }
                 RT_STAMP(0);
                 float* dst = tp2 + ((size_t)step * 4 + st) * RT_TAPE2;
-                f32x16 A1[2], D1[2];        // net n: act(z1), act'(z1) (then dZ1); register G' = 16 t + r <-> features 2G', 2G'+1
-                f32x16 A1n[2], D1n[2];      // net n + 1, in flight under net n's W1^T products (ZT)
-#pragma unroll
-                for (int r = 9; r < 16; r++) { A1[1][r] = 0.0f; D1[1][r] = 0.0f; A1n[1][r] = 0.0f; D1n[1][r] = 0.0f; }
                 // the nets are handled one after the other so that only one net's hidden state is live at a time
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
@@ -749,7 +764,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     //     pre-activations were fetched and activated in the shadow of the previous net's W1^T products (6).
                     if (ZT) {
                         if (n == 0) {
+#if !RT_Z0_AT_TOP
                             load_z1(step, st, 0, A1);
+#endif
 #pragma unroll
                             for (int G = 0; G < 25; G++) rt_act_pair_at<ACT>(A1, D1, G);
                         }
@@ -909,7 +926,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
         }
     }
 
+#ifndef COLNDE_STAMPS_FWD
     RT_STAMP_FLUSH();
+#endif
     // ---- flush this wave's partial gradients (row `tile` of the slab; dW1/db1 come from rt_dw1_kernel) ----
     float* out = slab + (size_t)tile * (m.n_params + 8);
     const int r_j = (j & 3) + 4 * (j >> 3), h_j = (j >> 2) & 1;     // this lane as a column index n' of a D tile
@@ -1118,7 +1137,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int wt = blockIdx.x * 8 + wave;                 // 16-column tile
+    const int wt = blockIdx.x * RT16_WAVES + wave;        // 16-column tile
     const int tile32 = wt >> 1, half = wt & 1;
     if (tile32 * 32 >= n_col) return;                     // (both halves of a live 32-column tile run: the tape must be whole)
     const int col = wt * 16 + j;
@@ -1159,6 +1178,10 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
             if (sol && valid) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + q * 32 + 16 * tau + 4 * g) = v;
         }
     const int n_steps = (n_save - 1) * substeps;
+    RT_STAMP_DECL;
+#ifdef COLNDE_STAMPS_FWD
+    const unsigned long long rs_k0 = __builtin_amdgcn_s_memtime(), rs_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // 32-column register image: group (q*4 + 2 tau + (g>>1)), lane32 = j + 16 half + 32 (g & 1)
     float* tp = tape ? tape + (size_t)tile32 * n_steps * 4 * 3072 + ((g >> 1) * 64 + j + 16 * half + 32 * (g & 1)) * 4 : nullptr;
     // layer-1 pre-activations, taped in the adjoint kernel's per-net register-image format (same as the delta tape): feature
@@ -1178,6 +1201,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
             for (int st = 0; st < 4; st++) {
                 const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);
                 const float cb = (st == 0 || st == 3) ? 1.0f / 6.0f : 1.0f / 3.0f;
+                RT_STAMP_BEGIN();
                 if (tp) {
                     float* o = tp + ((size_t)step * 4 + st) * 3072;
 #pragma unroll
@@ -1186,6 +1210,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                         for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(o + (q * 4 + 2 * tau) * 256) = Xs[q].t[tau];
                 }
                 bc.t[2] = rt_top_flux(m, bc5, ts + ca * dt);
+                RT_STAMP(0);
                 // ---- three MLPs -------------------------------------------------------------------------------------
                 f32x4t A1[10];
 #pragma unroll
@@ -1210,6 +1235,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
 #pragma unroll
                     for (int r = 0; r < 4; r++) A1[t][r] = rt_act<ACT>(acc[r]);
                 }
+                RT_STAMP(1);
                 V16 O[3];
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
@@ -1235,6 +1261,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                                                      [&](int k) { return A2[k >> 2][k & 3]; });
                     }
                 }
+                RT_STAMP(2);
                 // ---- physics (predict_flux / predict_NDE), face index = level index ----------------------------------
                 V16 F[3];
                 {
@@ -1285,6 +1312,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                             F[k].t[tau][r] = v;                           // F now holds the tendency K
                         }
                 }
+                RT_STAMP(3);
                 // ---- RK4 bookkeeping: accumulate, form the next stage input ------------------------------------------
                 const float can = st == 2 ? 1.0f : 0.5f;                    // abscissa of the NEXT stage
 #pragma unroll
@@ -1294,6 +1322,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                         Kacc[q].t[tau] += cb * F[q].t[tau];
                         Xs[q].t[tau] = Xn[q].t[tau] + (can * dt) * F[q].t[tau];
                     }
+                RT_STAMP(4);
             }
 #pragma unroll
             for (int q = 0; q < 3; q++)
@@ -1308,6 +1337,11 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
             }
         }
     }
+#ifdef COLNDE_STAMPS_FWD
+    rs_acc[6] = __builtin_amdgcn_s_memtime() - rs_k0;          // whole kernel, shader ticks
+    rs_acc[7] = __builtin_amdgcn_s_memrealtime() - rs_r0;      // whole kernel, 100 MHz reference ticks
+    RT_STAMP_FLUSH();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1394,7 +1428,7 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
 #undef RT_FWD
     } else {
         const int n_wt16 = 2 * ((n_col + RT_COLS - 1) / RT_COLS);
-        const dim3 grid((n_wt16 + 7) / 8), block(512);
+        const dim3 grid((n_wt16 + RT16_WAVES - 1) / RT16_WAVES), block(64 * RT16_WAVES);
 #define RT_FWD(A) hipLaunchKernelGGL(rt16_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, tapez, n_col)
         switch (m.acts[0]) {
             case COLNDE_ACT_IDENTITY: RT_FWD(COLNDE_ACT_IDENTITY); break;

@@ -6,7 +6,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import colnde
 from colnde import _lib, synthetic
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcolnde_stamps.so")
+FWD = "--fwd" in sys.argv      # forward-kernel stamps: build with -DCOLNDE_STAMPS -DCOLNDE_STAMPS_FWD into libcolnde_stamps_fwd.so
+if FWD: sys.argv.remove("--fwd")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcolnde_stamps_fwd.so" if FWD else "libcolnde_stamps.so")
 L = _lib.lib()
 L.colnde_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -19,7 +21,9 @@ nde.set_problem(p.x0, p.bcs, truth)
 nde.loss_grad(p.weights, [1, 1, 1, 5e-3, 5e-3, 5e-3])
 buf = (ctypes.c_ulonglong * 16)()
 _lib.check(L.colnde_debug_stamps(nde._h, buf))
-if nde.engine == 2:
+if nde.engine == 2 and FWD:
+    names = ["X tape store + top flux", "layer 1 (10 chains, Z1 tape store, activation)", "layers 2, 3", "physics", "RK4 update"]
+elif nde.engine == 2:
     names = ["kbar + physics pullback + dO park", "dO reload + L1 chains (3 nets)", "X prefetch + L2 chain", "dW3 + W3^T + dZ2",
              "dW2 (transposes + outer)", "W2^T + dZ1 + tape2 store", "W1^T chains"]
 else:
@@ -29,6 +33,9 @@ nstage = p.cfg.n_steps * 4
 for n, x in zip(names, v):
     print("%-28s %10.0f cycles/stage  %5.1f %%" % (n, x / nstage, 100 * x / v.sum()))
 print("total %.0f cycles/stage" % (v.sum() / nstage))
+if FWD:
+    print("whole kernel (workgroup 0, wave 0): %d s_memtime ticks in %.3f ms (s_memrealtime, 100 MHz) -> %.3f ticks/ns; stage loop share %.1f %%"
+          % (buf[6], buf[7] / 1e5, buf[6] / (buf[7] * 10.0), 100.0 * v.sum() / buf[6]))
 if nde.engine == 2:
     raise SystemExit(0)
 fine = np.array(list(buf)[8:13], dtype=np.float64)
