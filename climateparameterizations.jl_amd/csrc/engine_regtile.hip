@@ -1137,7 +1137,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int wt = blockIdx.x * RT16_WAVES + wave;        // 16-column tile
+    const int wt = blockIdx.x * (blockDim.x >> 6) + wave; // 16-column tile (1..RT16_WAVES wavefronts per workgroup)
     const int tile32 = wt >> 1, half = wt & 1;
     if (tile32 * 32 >= n_col) return;                     // (both halves of a live 32-column tile run: the tape must be whole)
     const int col = wt * 16 + j;
@@ -1428,7 +1428,10 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
 #undef RT_FWD
     } else {
         const int n_wt16 = 2 * ((n_col + RT_COLS - 1) / RT_COLS);
-        const dim3 grid((n_wt16 + RT16_WAVES - 1) / RT16_WAVES), block(64 * RT16_WAVES);
+        // small problems spread over the CUs first (one wavefront per workgroup up to 256 tiles), then fill the SIMDs
+        int wpw = (n_wt16 + 255) / 256;
+        wpw = wpw < 1 ? 1 : (wpw > RT16_WAVES ? RT16_WAVES : wpw);
+        const dim3 grid((n_wt16 + wpw - 1) / wpw), block(64 * wpw);
 #define RT_FWD(A) hipLaunchKernelGGL(rt16_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, tapez, n_col)
         switch (m.acts[0]) {
             case COLNDE_ACT_IDENTITY: RT_FWD(COLNDE_ACT_IDENTITY); break;

@@ -1,0 +1,59 @@
+"""Throughput of the BASELINE configs other than the headline one (parity-test cases; this is a diagnostic, not bench.py).
+usage: bench_configs.py [2|4|4ca|4s|5] ..."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import colnde
+from colnde import synthetic
+
+dev = torch.device("cuda", 0)
+which = sys.argv[1:] or ["2", "4s", "5"]
+
+
+def timed(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+for c in which:
+    if c == "2":      # forward only, 4,096 columns x 32 levels, 288 frames x 2 sub-steps
+        p = synthetic.wind_mixing_problem(4096)
+        nde = colnde.ColumnNDE(p.cfg, 4096)
+        x0, bcs, w = (torch.from_numpy(a).to(dev) for a in (p.x0, p.bcs, p.weights))
+        nde.set_problem(x0, bcs)
+        sol = nde.forward(w)
+        dt = timed(lambda: nde.forward(w, out=sol))
+        cs = 4096 * p.cfg.n_steps
+        print("config 2: forward 4096 columns: %.2f ms -> %.1f M column-timesteps/s, %.1f TFLOP/s (engine %d)" % (dt * 1e3, cs / dt / 1e6, cs * 154080 / dt / 1e12, nde.engine), flush=True)
+        nde.close()
+    if c in ("4", "4ca", "4s"):   # free convection, 64 levels, 64-256-256-63 relu, 129 save points; 16,384 columns = one GPU's shard of 65,536
+        ncol = 4096 if c == "4s" else 16384
+        p = synthetic.free_convection_problem(ncol, Nz=64, convective_adjustment=(c == "4ca"))
+        nde = colnde.ColumnNDE(p.cfg, ncol)
+        x0, bcs, w, wt = (torch.from_numpy(a).to(dev) for a in (p.x0, p.bcs, p.weights, p.weights_truth))
+        nde.set_problem(x0, bcs)
+        truth = nde.forward(wt)
+        nde.set_problem(x0, bcs, truth)
+        out = torch.empty(p.cfg.n_params + 8, device=dev)
+        sc = [0, 0, 1, 0, 0, 0]
+        nde.set_profiling(True)
+        dt = timed(lambda: nde.loss_grad(w, sc, out=out), n=2)
+        cs = ncol * p.cfg.n_steps
+        mlp = 2 * (64 * 256 + 256 * 256 + 256 * 63)
+        kt = {k: round(nde.kernel_time(k)[0] / max(nde.kernel_time(k)[1], 1), 2) for k in ("forward", "adjoint", "reduce")}
+        print("config %s: fwd+adjoint %d columns x 64 levels x %d RK4 steps: %.1f ms -> %.2f M column-timesteps/s, %.1f TFLOP/s at 3x forward flops (engine %d) %s"
+              % (c, ncol, p.cfg.n_steps, dt * 1e3, cs / dt / 1e6, cs * 4 * 3 * mlp / dt / 1e12, nde.engine, kt), flush=True)
+        nde.close()
+    if c == "5":      # inference forcing, 256 x 256 columns x 32 levels, 32-128-128-31
+        cfg, T, tf, w = synthetic.inference_problem(256, 256)
+        nde = colnde.ColumnNDE(cfg, 65536)
+        Td, tfd, wd = (torch.from_numpy(a).to(dev) for a in (T, tf, w))
+        dt = timed(lambda: nde.infer_forcing(wd, Td, tfd, 1024.0), n=10)
+        mlp = 2 * (32 * 128 + 128 * 128 + 128 * 31)
+        print("config 5: inference 65536 columns: %.3f ms -> %.1f M columns/s, %.1f TFLOP/s, %.1f GB/s algorithmic (260 B/column)"
+              % (dt * 1e3, 65536 / dt / 1e6, 65536 * mlp / dt / 1e12, 65536 * 260 / dt / 1e9), flush=True)
+        nde.close()
