@@ -34,6 +34,9 @@ SYMBOLS = [
     ("colnde_loss_dev", ctypes.c_int, [_V, _V, _F, _V]),
     ("colnde_loss_grad_dev", ctypes.c_int, [_V, _V, _F, _V]),
     ("colnde_infer_forcing_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_convective_adjustment", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, ctypes.c_float, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_convective_adjustment_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, ctypes.c_float, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_adam_step_dev", ctypes.c_int, [_V, _V, _V, _V, _V] + [ctypes.c_float] * 6 + [ctypes.c_int]),
     ("colnde_set_profiling", ctypes.c_int, [_V, ctypes.c_int]),
     ("colnde_kernel_time", ctypes.c_int, [_V, ctypes.c_int, _F, ctypes.POINTER(ctypes.c_int)]),
     ("colnde_reset_kernel_times", ctypes.c_int, [_V]),

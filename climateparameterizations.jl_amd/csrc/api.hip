@@ -11,6 +11,7 @@
 
 #include "engine_tile16.h"
 #include "engine_regtile.h"
+#include "column_ops.h"
 
 static thread_local std::string g_err;
 
@@ -30,7 +31,7 @@ static int fail(const char* fmt, ...) {
         if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-enum { K_FORWARD = 0, K_ADJOINT = 1, K_REDUCE = 2, K_RHS = 3, K_INFER = 4, K_DW1 = 5, K_COUNT = 6 };
+enum { K_FORWARD = 0, K_ADJOINT = 1, K_REDUCE = 2, K_RHS = 3, K_INFER = 4, K_DW1 = 5, K_CONVADJ = 6, K_ADAM = 7, K_COUNT = 8 };
 
 struct PendingEvent { hipEvent_t a, b; int which; };
 
@@ -650,6 +651,60 @@ extern "C" int colnde_infer_forcing(colnde_handle* h, const float* weights, cons
     if (colnde_infer_forcing_dev(h, h->d_w, h->d_tmp_a, h->d_tmp_b, Lz, h->d_tmp_c, n_columns)) return 1;
     HIPCHK(hipMemcpyAsync(out, h->d_tmp_c, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- the steps either side of the hot path ---------------------------------------------------
+extern "C" int colnde_convective_adjustment_dev(colnde_handle* h, const float* d_T, const float* d_halo_bottom,
+                                                const float* d_halo_top, float dt, float dz, float K, float* d_out, int n_columns) {
+    if (!h) return fail("null handle");
+    if (!d_T || !d_out) return fail("null pointer argument");
+    if (n_columns < 1) return fail("n_columns must be >= 1");
+    if (!(dt > 0.0f) || !(dz > 0.0f) || !(K >= 0.0f)) return fail("dt > 0, dz > 0 and K >= 0 required");
+    if (h->m.Nz < 2 || h->m.Nz > 128) return fail("convective adjustment supports 2 <= Nz <= 128 (Nz = %d)", h->m.Nz);
+    HIPCHK(hipSetDevice(h->device));
+    Timed tm(h, K_CONVADJ);
+    hipError_t e = launch_convective_adjustment(d_T, d_halo_bottom, d_halo_top, dt / (dz * dz), K, d_out, h->m.Nz, n_columns, h->stream);
+    if (e != hipSuccess) return fail("convective adjustment launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_convective_adjustment(colnde_handle* h, const float* T, const float* halo_bottom, const float* halo_top,
+                                            float dt, float dz, float K, float* out, int n_columns) {
+    if (!h) return fail("null handle");
+    if (!T || !out) return fail("null pointer argument");
+    if (n_columns < 1) return fail("n_columns must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    if (ensure_tmp(h, (size_t)n_columns)) return 1;
+    const int Nz = h->m.Nz;
+    HIPCHK(hipMemcpyAsync(h->d_tmp_a, T, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyHostToDevice, h->stream));
+    float* d_hb = nullptr;
+    float* d_ht = nullptr;
+    if (halo_bottom) {
+        d_hb = h->d_tmp_b;
+        HIPCHK(hipMemcpyAsync(d_hb, halo_bottom, sizeof(float) * (size_t)n_columns, hipMemcpyHostToDevice, h->stream));
+    }
+    if (halo_top) {
+        d_ht = h->d_tmp_b + n_columns;
+        HIPCHK(hipMemcpyAsync(d_ht, halo_top, sizeof(float) * (size_t)n_columns, hipMemcpyHostToDevice, h->stream));
+    }
+    if (colnde_convective_adjustment_dev(h, h->d_tmp_a, d_hb, d_ht, dt, dz, K, h->d_tmp_c, n_columns)) return 1;
+    HIPCHK(hipMemcpyAsync(out, h->d_tmp_c, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int colnde_adam_step_dev(colnde_handle* h, float* d_weights, const float* d_grad, float* d_m, float* d_v, float eta,
+                                    float beta1, float beta2, float eps, float beta1_t, float beta2_t, int n) {
+    if (!h) return fail("null handle");
+    if (!d_weights || !d_grad || !d_m || !d_v) return fail("null pointer argument");
+    if (n < 1) return fail("n must be >= 1");
+    if (!(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f)) return fail("0 <= beta < 1 required");
+    if (!(beta1_t < 1.0f && beta2_t < 1.0f)) return fail("running powers beta^t must be < 1");
+    HIPCHK(hipSetDevice(h->device));
+    Timed tm(h, K_ADAM);
+    hipError_t e = launch_adam_step(d_weights, d_grad, d_m, d_v, eta, beta1, beta2, eps, beta1_t, beta2_t, n, h->stream);
+    if (e != hipSuccess) return fail("ADAM launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 

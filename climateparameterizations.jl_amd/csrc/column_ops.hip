@@ -1,0 +1,135 @@
+// column_ops.hip — gfx950 kernels for the steps either side of the NDE hot path.
+#include "column_ops.h"
+
+// ------------------------------------------------------------------------------------------------
+// convective_adjustment!(model, Δt, K): free_convection/double_gyre_nn.jl:27-62 (3-D), free_convection/src/oceananigans_nn.jl:13-40
+// (1-D).  Per column: the centred vertical gradient (zero-gradient halos) marks the statically unstable cells,
+// κ_k = K there and 0 elsewhere, and T' = L \ T with the reference's tridiagonal
+//     lower_k = -c κ_k (k >= 1),  diag_k = 1 + c (κ_k + κ_{k+1}) (k < Nz-1),  diag_{Nz-1} = 1 + c κ_{Nz-1},  upper_k = -c κ_{k+1},
+// c = Δt/Δz².  L is strictly diagonally dominant by rows and columns, so the reference's pivoted LU (`Tridiagonal \`)
+// never pivots and the Thomas recurrence below is the same elimination.
+//
+// HBM-bound (2·4·Nz bytes per column, ~8 flop per level).  A workgroup of 256 threads stages 256 columns through LDS with
+// coalesced float4 traffic (rows padded to NZ+1 floats: conflict-free per-thread column walks), one thread solves one column.
+// ------------------------------------------------------------------------------------------------
+template <int NZ>
+__global__ void __launch_bounds__(256) convadj_kernel(const float* __restrict__ T, const float* __restrict__ halo_bottom,
+                                                      const float* __restrict__ halo_top, float c, float K, float* __restrict__ out, int n_col) {
+    extern __shared__ float cs_smem[];
+    constexpr int LD = NZ + 1;
+    const int col0 = blockIdx.x * 256;
+    const int ncol = min(256, n_col - col0);
+    const float4* src = reinterpret_cast<const float4*>(T + (size_t)col0 * NZ);
+    for (int e = threadIdx.x; e < ncol * (NZ / 4); e += 256) {
+        const float4 v = src[e];
+        const int cl = e / (NZ / 4), k = (e % (NZ / 4)) * 4;
+        float* d = cs_smem + cl * LD + k;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ncol) {
+        float* t = cs_smem + threadIdx.x * LD;
+        float x[NZ], cp[NZ];
+#pragma unroll
+        for (int k = 0; k < NZ; k++) x[k] = t[k];
+        const float ck = c * K;
+        // κ of cell k as c·κ_k: statically unstable where T[k+1] - T[k-1] < 0; the halo cells are the caller's (they carry
+        // the field's boundary conditions) or, absent, the nearest interior value (zero-gradient fill)
+        const float below = halo_bottom ? halo_bottom[col0 + threadIdx.x] : x[0];
+        const float above = halo_top ? halo_top[col0 + threadIdx.x] : x[NZ - 1];
+        float kk[NZ];
+#pragma unroll
+        for (int k = 0; k < NZ; k++) kk[k] = ((k + 1 < NZ ? x[k + 1] : above) - (k > 0 ? x[k - 1] : below)) < 0.0f ? ck : 0.0f;
+        // forward elimination
+        float inv = 1.0f / (1.0f + kk[0] + kk[1]);
+        cp[0] = -kk[1] * inv;
+        x[0] = x[0] * inv;
+#pragma unroll
+        for (int k = 1; k < NZ; k++) {
+            const float a = -kk[k];
+            const float b = 1.0f + kk[k] + (k < NZ - 1 ? kk[k + 1] : 0.0f);
+            inv = 1.0f / (b - a * cp[k - 1]);
+            cp[k] = (k < NZ - 1 ? -kk[k + 1] : 0.0f) * inv;
+            x[k] = (x[k] - a * x[k - 1]) * inv;
+        }
+        // back substitution
+#pragma unroll
+        for (int k = NZ - 2; k >= 0; k--) x[k] -= cp[k] * x[k + 1];
+#pragma unroll
+        for (int k = 0; k < NZ; k++) t[k] = x[k];
+    }
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)col0 * NZ);
+    for (int e = threadIdx.x; e < ncol * (NZ / 4); e += 256) {
+        const int cl = e / (NZ / 4), k = (e % (NZ / 4)) * 4;
+        const float* d = cs_smem + cl * LD + k;
+        dst[e] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+}
+
+// any Nz <= 128 (not a multiple of 4, or none of the instantiated sizes): one thread per column straight from HBM
+__global__ void __launch_bounds__(256) convadj_generic_kernel(const float* __restrict__ T, const float* __restrict__ halo_bottom,
+                                                               const float* __restrict__ halo_top, float c, float K,
+                                                               float* __restrict__ out, int Nz, int n_col) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= n_col) return;
+    const float* t = T + (size_t)col * Nz;
+    float* o = out + (size_t)col * Nz;
+    float x[128], cp[128], kk[128];
+    for (int k = 0; k < Nz; k++) x[k] = t[k];
+    const float ck = c * K;
+    const float below = halo_bottom ? halo_bottom[col] : x[0], above = halo_top ? halo_top[col] : x[Nz - 1];
+    for (int k = 0; k < Nz; k++) kk[k] = ((k + 1 < Nz ? x[k + 1] : above) - (k > 0 ? x[k - 1] : below)) < 0.0f ? ck : 0.0f;
+    float inv = 1.0f / (1.0f + kk[0] + (Nz > 1 ? kk[1] : 0.0f));
+    cp[0] = (Nz > 1 ? -kk[1] : 0.0f) * inv;
+    x[0] *= inv;
+    for (int k = 1; k < Nz; k++) {
+        const float a = -kk[k];
+        const float b = 1.0f + kk[k] + (k < Nz - 1 ? kk[k + 1] : 0.0f);
+        inv = 1.0f / (b - a * cp[k - 1]);
+        cp[k] = (k < Nz - 1 ? -kk[k + 1] : 0.0f) * inv;
+        x[k] = (x[k] - a * x[k - 1]) * inv;
+    }
+    for (int k = Nz - 2; k >= 0; k--) x[k] -= cp[k] * x[k + 1];
+    for (int k = 0; k < Nz; k++) o[k] = x[k];
+}
+
+hipError_t launch_convective_adjustment(const float* T, const float* halo_bottom, const float* halo_top, float c, float K, float* out,
+                                        int Nz, int n_col, hipStream_t stream) {
+    if (Nz < 2 || Nz > 128 || n_col < 1) return hipErrorInvalidValue;
+    const dim3 grid((n_col + 255) / 256), block(256);
+#define CA_LAUNCH(N) hipLaunchKernelGGL(convadj_kernel<N>, grid, block, 256 * (N + 1) * sizeof(float), stream, T, halo_bottom, halo_top, c, K, out, n_col)
+    const bool aligned = (((uintptr_t)T | (uintptr_t)out) & 15) == 0;
+    if (aligned && Nz == 16) CA_LAUNCH(16);
+    else if (aligned && Nz == 32) CA_LAUNCH(32);
+    else if (aligned && Nz == 64) CA_LAUNCH(64);
+    else hipLaunchKernelGGL(convadj_generic_kernel, grid, block, 0, stream, T, halo_bottom, halo_top, c, K, out, Nz, n_col);
+#undef CA_LAUNCH
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flux.Optimise.ADAM `apply!` followed by `update!` (Flux 0.11.6, src/optimise/optimisers.jl; call sites
+// wind_mixing/src/NDE_training.jl:340-372, free_convection/src/training.jl:71): one fused pass over the parameter vector.
+// beta1_t / beta2_t are the running powers β₁ᵗ, β₂ᵗ the optimiser state carries (β on the first step).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, float eta, float b1, float b2, float eps, float c1, float c2,
+                                                    int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] -= mi * c1 / (sqrtf(vi * c2) + eps) * eta;      // c1 = 1/(1-β₁ᵗ), c2 = 1/(1-β₂ᵗ)
+}
+
+hipError_t launch_adam_step(float* w, const float* grad, float* m, float* v, float eta, float beta1, float beta2, float eps,
+                            float beta1_t, float beta2_t, int n, hipStream_t stream) {
+    if (n < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, w, grad, m, v, eta, beta1, beta2, eps,
+                       1.0f / (1.0f - beta1_t), 1.0f / (1.0f - beta2_t), n);
+    return hipGetLastError();
+}

@@ -634,7 +634,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 
     const int n_steps = (n_save - 1) * substeps;
     const float* tp = tape + (size_t)tile * n_steps * 4 * 3072 + lane * 4;
-    float* xs4 = xscr + (size_t)tile * 5 * 3072 + lane * 4;
+    [[maybe_unused]] float* xs4 = xscr + (size_t)tile * 5 * 3072 + lane * 4;    // RT_PARK_* variants only
     float* tp2 = tape2 + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4;
     const float* tpz = ZT ? tapez + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4 : nullptr;
 

@@ -6,6 +6,7 @@
     solve_nde(nde, NN, T₀, alg, nde_params)                              free_convection/src/solve.jl:1-6
     nde_loss()  and the Flux.train! loop                                  free_convection/src/training.jl:44-74
     compute_neural_network_forcing!                                       free_convection/double_gyre_nn.jl:149-168
+    convective_adjustment!(model, Δt, K)                                  free_convection/double_gyre_nn.jl:27-62, src/oceananigans_nn.jl:13-40
 
 The Oceananigans `FieldDataset` wrangling and DataDeps download stay outside (network + foreign types).
 """
@@ -84,3 +85,15 @@ def compute_neural_network_forcing(engine: ColumnNDE, weights, T_interior, surfa
     nx, ny, nz = T.shape
     out = engine.infer_forcing(weights, T.reshape(nx * ny, nz), np.asarray(surface_flux, np.float32).reshape(-1), Lz)
     return out.reshape(nx, ny, nz)
+
+
+def convective_adjustment(engine: ColumnNDE, T_interior, dt: float, K: float, dz: float, halo_bottom=None, halo_top=None):
+    """`convective_adjustment!(model, Δt, K)` (double_gyre_nn.jl:27-62; 1-D: src/oceananigans_nn.jl:13-40) on the T
+    interior [Nx, Ny, Nz] (or [n, Nz]): returns Tⁿ⁺¹ of the same shape.  halo_bottom / halo_top [Nx, Ny]: the halo
+    cells Oceananigans filled for T's boundary conditions (None: zero-gradient fill)."""
+    T = np.asarray(T_interior, dtype=np.float32)
+    shape = T.shape
+    T2 = T.reshape(-1, shape[-1])
+    hb = None if halo_bottom is None else np.asarray(halo_bottom, np.float32).reshape(-1)
+    ht = None if halo_top is None else np.asarray(halo_top, np.float32).reshape(-1)
+    return engine.convective_adjustment(T2, dt, dz, K, hb, ht).reshape(shape)

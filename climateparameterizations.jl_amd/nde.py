@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from .config import NDEConfig, to_c_config
 
-KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4, "dw1": 5}
+KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4, "dw1": 5, "convadj": 6, "adam": 7}
 ENGINE_AUTO, ENGINE_TILE16, ENGINE_REGTILE = 0, 1, 2
 
 
@@ -214,3 +214,46 @@ class ColumnNDE:
         out = np.empty_like(T)
         _lib.check(self._L.colnde_infer_forcing(self._h, _ptr(w), _ptr(T), _ptr(tf), float(Lz), _ptr(out), n))
         return out
+
+    # ---- the steps either side of the hot path --------------------------------------------
+    def convective_adjustment(self, T, dt: float, dz: float, K: float, halo_bottom=None, halo_top=None, out=None):
+        """`convective_adjustment!(model, Δt, K)` (free_convection/double_gyre_nn.jl:27-62) on [n][Nz] columns."""
+        Nz = self.cfg.Nz
+        if _is_torch(T):
+            import torch
+            n = T.shape[0]
+            self._chk_dev(T, (n, Nz))
+            for hl in (halo_bottom, halo_top):
+                if hl is not None:
+                    self._chk_dev(hl, (n,))
+            if out is None:
+                out = torch.empty_like(T)
+            self._chk_dev(out, (n, Nz))
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_convective_adjustment_dev(
+                self._h, T.data_ptr(), halo_bottom.data_ptr() if halo_bottom is not None else None,
+                halo_top.data_ptr() if halo_top is not None else None, float(dt), float(dz), float(K), out.data_ptr(), n))
+            return out
+        T = _f32(T)
+        n = T.shape[0]
+        T = _f32(T, (n, Nz))
+        hb = _f32(halo_bottom, (n,)) if halo_bottom is not None else None
+        ht = _f32(halo_top, (n,)) if halo_top is not None else None
+        res = np.empty_like(T)
+        _lib.check(self._L.colnde_convective_adjustment(self._h, _ptr(T), _ptr(hb), _ptr(ht), float(dt), float(dz), float(K),
+                                                        _ptr(res), n))
+        return res
+
+    def adam_step(self, weights, grad, m, v, eta: float, beta=(0.9, 0.999), eps: float = 1e-8, beta_t=None):
+        """One fused `Flux.Optimise.ADAM` apply!/update! on device vectors (in place).  beta_t = running powers (β₁ᵗ, β₂ᵗ)."""
+        import torch
+        n = weights.numel()
+        for t in (weights, m, v):
+            self._chk_dev(t, (n,))
+        if not (grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() >= n):
+            raise ValueError("grad must be a contiguous float32 device tensor with at least %d elements" % n)
+        bt = beta if beta_t is None else beta_t
+        self.use_torch_stream()
+        _lib.check(self._L.colnde_adam_step_dev(self._h, weights.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), float(eta),
+                                                float(beta[0]), float(beta[1]), float(eps), float(bt[0]), float(bt[1]), n))
+        return weights

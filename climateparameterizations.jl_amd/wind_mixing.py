@@ -155,3 +155,47 @@ def train_NDE(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epoch
                 opt.update(theta, grad.astype(np.float64))
             theta = best_theta
     return TrainResult(theta, history)
+
+
+def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epochs: int = 1, maxiters: int = 500,
+                     process_group=None) -> TrainResult:
+    """`train_NDE`'s optimiser loop (NDE_training.jl:340-372) with θ, the ADAM state and the best-loss copy resident on the
+    GPU: per iteration one `colnde_loss_grad_dev`, [one SUM all-reduce of the gradient buffer when the columns are sharded
+    over `process_group`], one fused `colnde_adam_step_dev`; nothing crosses PCIe until the end.  Same update rule and
+    best-θ selection (`res.minimizer`, :371) as `train_NDE`; the per-iteration callback is not available here."""
+    import torch
+    eng = problem.engine
+    dev = torch.device("cuda", eng.device)
+    n = eng.n_params
+    theta = torch.as_tensor(np.asarray(weights, dtype=np.float32)).to(dev).contiguous()
+    out = torch.empty(n + 8, dtype=torch.float32, device=dev)
+    sc = problem.loss_scalings.copy()
+    if not problem.cfg.train_gradient:
+        sc[3:] = 0.0
+    hist = []
+    for opt in optimizers:
+        for _ in range(epochs):
+            m = torch.zeros(n, dtype=torch.float32, device=dev)
+            v = torch.zeros(n, dtype=torch.float32, device=dev)
+            if opt.m is not None:            # continue an optimiser that has state (Flux keeps it across `solve` calls)
+                m.copy_(torch.as_tensor(opt.m, dtype=torch.float32)); v.copy_(torch.as_tensor(opt.v, dtype=torch.float32))
+            best = torch.full((), float("inf"), dtype=torch.float32, device=dev)
+            best_theta = theta.clone()
+            for it in range(maxiters):
+                eng.loss_grad(theta, sc, out=out)
+                if process_group is not None:
+                    import torch.distributed as dist
+                    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
+                total = out[n + 6]
+                hist.append(out[n:n + 7].clone())
+                better = total < best
+                best = torch.where(better, total, best)
+                best_theta = torch.where(better, theta, best_theta)
+                eng.adam_step(theta, out, m, v, opt.eta, opt.beta, opt.eps, beta_t=tuple(opt.beta_t))
+                opt.beta_t[0] *= opt.beta[0]
+                opt.beta_t[1] *= opt.beta[1]
+            theta = best_theta.clone()
+            opt.m, opt.v = m.double().cpu().numpy(), v.double().cpu().numpy()
+    H = torch.stack(hist).cpu().numpy() if hist else np.zeros((0, 7), np.float32)
+    history = [dict(total=float(r[6]), **{k: float(r[i]) for i, k in enumerate(LOSS_KEYS)}) for r in H]
+    return TrainResult(theta.cpu().numpy(), history)

@@ -120,9 +120,29 @@ int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, const float s
 int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux,
                              float Lz, float* d_out, int n_columns);
 
+/* ---- the steps either side of the hot path --------------------------------------------------------
+ *
+ * convective_adjustment!(model, Δt, K) — free_convection/double_gyre_nn.jl:27-62 (every (i,j) column of the 3-D model),
+ * 1-D twin free_convection/src/oceananigans_nn.jl:13-40: κ_k = K where the centred ∂T/∂z of cell k is negative, 0 elsewhere,
+ * then one backward-Euler step T' = L \ T with lower_k = -cκ_k, diag_k = 1 + c(κ_k + κ_{k+1}) (last row 1 + cκ_Nz),
+ * upper_k = -cκ_{k+1}, c = Δt/Δz².  T, out: [n_col][Nz] (k = 0 deepest; out may alias T).  halo_bottom / halo_top: [n_col] values
+ * of the halo cells below k = 0 / above k = Nz-1 as the ocean model filled them for the field's boundary conditions, or NULL for
+ * the zero-gradient fill (nearest interior value).  Nz is the handle's. */
+int colnde_convective_adjustment(colnde_handle* h, const float* T, const float* halo_bottom, const float* halo_top, float dt,
+                                 float dz, float K, float* out, int n_columns);
+int colnde_convective_adjustment_dev(colnde_handle* h, const float* d_T, const float* d_halo_bottom, const float* d_halo_top,
+                                     float dt, float dz, float K, float* d_out, int n_columns);
+
+/* Flux.Optimise.ADAM apply! + update! (Flux 0.11.6 src/optimise/optimisers.jl; used at wind_mixing/src/NDE_training.jl:340-372,
+ * free_convection/src/training.jl:71) on device vectors of n floats: m ← β₁m + (1-β₁)g, v ← β₂v + (1-β₂)g²,
+ * w ← w - η·m/(1-β₁ᵗ)/(√(v/(1-β₂ᵗ)) + ϵ).  beta1_t / beta2_t are the running powers the optimiser state carries (β₁, β₂ on the
+ * first call; the caller multiplies them by β after each call, as Flux does).  Enqueued on the handle's stream. */
+int colnde_adam_step_dev(colnde_handle* h, float* d_weights, const float* d_grad, float* d_m, float* d_v, float eta, float beta1,
+                         float beta2, float eps, float beta1_t, float beta2_t, int n);
+
 /* ---- measurement: HIP-event timing of the handle's kernels on its stream.
  * which: 0 = forward solve kernel, 1 = adjoint kernel, 2 = gradient reduce, 3 = rhs, 4 = inference,
- * 5 = streaming dW1 GEMM (regtile engine only).
+ * 5 = streaming dW1 GEMM (regtile engine only), 6 = convective adjustment, 7 = ADAM step.
  * Returns accumulated milliseconds and launch count since the last reset (synchronises the stream). */
 int colnde_set_profiling(colnde_handle* h, int enabled);
 int colnde_kernel_time(colnde_handle* h, int which, float* ms_total, int* n_launches);

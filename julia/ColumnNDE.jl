@@ -94,4 +94,23 @@ function ChainRulesCore.rrule(::typeof(loss_gradient_NDE), h::Handle, weights, l
     (total, losses, loss_scalings), pullback
 end
 
+"convective_adjustment!(model, Δt, K) — free_convection/double_gyre_nn.jl:27-62: T is `interior(model.tracers.T)` permuted to
+(Nz, Nx·Ny) column-major (= C-order [column][level]); halos are `nothing` for flux-bounded T (zero-gradient fill) or the two
+halo planes Oceananigans filled"
+function convective_adjustment!(h::Handle, T::Matrix{Float32}, Δt, Δz, K; halo_bottom=nothing, halo_top=nothing)
+    hb = halo_bottom === nothing ? C_NULL : pointer(halo_bottom); ht = halo_top === nothing ? C_NULL : pointer(halo_top)
+    GC.@preserve halo_bottom halo_top check(ccall((:colnde_convective_adjustment, libcolnde), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Cfloat, Cfloat, Ptr{Float32}, Cint),
+        h.ptr, T, hb, ht, Δt, Δz, K, T, size(T, 2)))
+    T
+end
+
+"Flux.Optimise.ADAM apply!/update! on device pointers (θ, ∇, m, v resident on the GPU); βᵗ = running powers kept by the caller"
+function adam_step!(h::Handle, dθ::Ptr{Float32}, dg::Ptr{Float32}, dm::Ptr{Float32}, dv::Ptr{Float32}, η, β, ϵ, βᵗ, n)
+    check(ccall((:colnde_adam_step_dev, libcolnde), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Cfloat, Cfloat, Cfloat, Cfloat, Cfloat, Cint),
+        h.ptr, dθ, dg, dm, dv, η, β[1], β[2], ϵ, βᵗ[1], βᵗ[2], n))
+    βᵗ .* β
+end
+
 end # module

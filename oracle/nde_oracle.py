@@ -531,3 +531,47 @@ def infer_forcing(cfg, T, top_flux, theta, Lz, dtype=np.float64):
     wT[:, cfg.Nz] = np.asarray(top_flux, dtype)
     dz = Lz / cfg.Nz
     return -(wT[:, 1:] - wT[:, :-1]) / dz
+
+
+# ----------------------------------------------------------------------------------------------
+# the steps either side of the hot path
+# ----------------------------------------------------------------------------------------------
+def convective_adjustment(T, dt, dz, K, halo_bottom=None, halo_top=None, dtype=np.float64):
+    """`convective_adjustment!(model, Δt, K)` — free_convection/double_gyre_nn.jl:27-62, 1-D twin
+    free_convection/src/oceananigans_nn.jl:13-40 — restated literally: the centred `∂z(T)` (:34, mean of the two face
+    gradients = (T[k+1] − T[k−1])/(2Δz) with halo cells at the ends), `κ[k] = ∂T∂z[k] < 0 ? K : 0` (:37-40),
+    `ld`, `ud`, `d` (:46-53) assembled into a DENSE matrix and solved with LAPACK (`Tridiagonal \\`, :55-57).
+    T [n_col, Nz], k = 0 deepest.  Halo cells default to the nearest interior value (Oceananigans fills the halos of
+    flux-bounded fields with zero normal gradient; Value/Gradient boundary conditions give other halo values, which the
+    caller passes in)."""
+    T = np.asarray(T, dtype)
+    n, Nz = T.shape
+    hb = T[:, 0] if halo_bottom is None else np.asarray(halo_bottom, dtype)
+    ht = T[:, -1] if halo_top is None else np.asarray(halo_top, dtype)
+    Text = np.concatenate([hb[:, None], T, ht[:, None]], axis=1)
+    dTdz = (Text[:, 2:] - Text[:, :-2]) / (2.0 * dz)
+    kappa = np.where(dTdz < 0, dtype(K), dtype(0))
+    c = dtype(dt) / dtype(dz) ** 2
+    out = np.empty_like(T)
+    for i in range(n):
+        k = kappa[i]
+        L = np.zeros((Nz, Nz), dtype)
+        for r in range(1, Nz):
+            L[r, r - 1] = -c * k[r]                 # ld[k] = -Δt/Δz² κ[k], k in 2:Nz
+        for r in range(Nz - 1):
+            L[r, r + 1] = -c * k[r + 1]             # ud[k] = -Δt/Δz² κ[k+1], k in 1:Nz-1
+            L[r, r] = 1 + c * (k[r] + k[r + 1])
+        L[Nz - 1, Nz - 1] = 1 + c * k[Nz - 1]
+        out[i] = np.linalg.solve(L, T[i])
+    return out
+
+
+def adam_step(theta, grad, m, v, eta, beta, eps, beta_t):
+    """Flux.Optimise.ADAM `apply!` + `update!` (Flux 0.11.6, src/optimise/optimisers.jl — third-party, pinned in
+    wind_mixing/Manifest.toml; call sites NDE_training.jl:340-372, training.jl:71).  Returns (theta, m, v, beta_t) after
+    one step; beta_t = running powers (β₁ᵗ, β₂ᵗ), (β₁, β₂) on the first step."""
+    theta, grad, m, v = (np.asarray(a, np.float64) for a in (theta, grad, m, v))
+    m = beta[0] * m + (1 - beta[0]) * grad
+    v = beta[1] * v + (1 - beta[1]) * grad * grad
+    delta = m / (1 - beta_t[0]) / (np.sqrt(v / (1 - beta_t[1])) + eps) * eta
+    return theta - delta, m, v, (beta_t[0] * beta[0], beta_t[1] * beta[1])

@@ -1,5 +1,5 @@
 """Throughput of the BASELINE configs other than the headline one (parity-test cases; this is a diagnostic, not bench.py).
-usage: bench_configs.py [2|4|4ca|4s|5] ..."""
+usage: bench_configs.py [2|4|4ca|4s|5|ca|adam] ..."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -56,4 +56,30 @@ for c in which:
         mlp = 2 * (32 * 128 + 128 * 128 + 128 * 31)
         print("config 5: inference 65536 columns: %.3f ms -> %.1f M columns/s, %.1f TFLOP/s, %.1f GB/s algorithmic (260 B/column)"
               % (dt * 1e3, 65536 / dt / 1e6, 65536 * mlp / dt / 1e12, 65536 * 260 / dt / 1e9), flush=True)
+        nde.close()
+    if c == "ca":     # implicit convective-adjustment step (double_gyre_nn.jl:27-62) on the config-5 grid and on a large batch
+        cfg = synthetic.free_convection_problem(1, Nz=32, n_save=2).cfg
+        nde = colnde.ColumnNDE(cfg, 1)
+        for ncol in (65536, 4 * 1024 * 1024):
+            g = torch.Generator(device="cpu").manual_seed(1)
+            T = (torch.linspace(5.0, 25.0, 32)[None, :] + 1.5 * torch.randn(ncol, 32, generator=g)).to(dev)
+            out = torch.empty_like(T)
+            nde.set_profiling(True); nde.reset_kernel_times()
+            dt = timed(lambda: nde.convective_adjustment(T, 1200.0, 62.5, 10.0, out=out), n=20)
+            ms, nl = nde.kernel_time("convadj")
+            kt = ms / nl * 1e-3
+            print("convective adjustment: %d columns x 32 levels: kernel %.4f ms -> %.0f M columns/s, %.0f GB/s of 8000 (256 B/column algorithmic) = %.1f %% of HBM peak; wall %.4f ms"
+                  % (ncol, kt * 1e3, ncol / kt / 1e6, ncol * 256 / kt / 1e9, ncol * 256 / kt / 1e9 / 80.0, dt * 1e3), flush=True)
+        nde.close()
+    if c == "adam":   # fused ADAM update on the 19,563-parameter vector and on a large one
+        p = synthetic.wind_mixing_problem(2, n_frames=3)
+        nde = colnde.ColumnNDE(p.cfg, 2)
+        for n in (p.cfg.n_params, 64 * 1024 * 1024):
+            w, g, m, v = (torch.randn(n, device=dev) for _ in range(4))
+            v.abs_()
+            nde.set_profiling(True); nde.reset_kernel_times()
+            dt = timed(lambda: nde.adam_step(w, g, m, v, 1e-3), n=20)
+            ms, nl = nde.kernel_time("adam")
+            kt = ms / nl * 1e-3
+            print("ADAM step: %d parameters: kernel %.4f ms -> %.0f GB/s (28 B/parameter); wall %.4f ms" % (n, kt * 1e3, n * 28 / kt / 1e9, dt * 1e3), flush=True)
         nde.close()
