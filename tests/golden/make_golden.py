@@ -49,6 +49,21 @@ def main():
     cfg, T, top, w = synthetic.inference_problem(6, 5)
     np.savez_compressed(os.path.join(HERE, "infer_forcing_32.npz"), T=T, top_flux=top, weights=w, Lz=np.float64(1000.0),
                         forcing=O.infer_forcing(cfg, T, top, w, 1000.0).astype(np.float32))
+    # the steps either side of the hot path: implicit convective adjustment, ADAM
+    r = np.random.default_rng(synthetic.SEED + 7)
+    Tc = (np.linspace(5.0, 25.0, 32)[None, :] + 1.5 * r.standard_normal((7, 32))).astype(np.float32)
+    hb = (Tc[:, 0] + r.standard_normal(7)).astype(np.float32)
+    ht = (Tc[:, -1] + r.standard_normal(7)).astype(np.float32)
+    th, g = r.standard_normal(101), 1e-2 * r.standard_normal((3, 101))
+    m, v, bt, ths = np.zeros(101), np.zeros(101), (0.9, 0.999), []
+    th_run = th.copy()
+    for i in range(3):
+        th_run, m, v, bt = O.adam_step(th_run, g[i], m, v, 1e-3, (0.9, 0.999), 1e-8, bt)
+        ths.append(th_run.copy())
+    np.savez_compressed(os.path.join(HERE, "column_ops.npz"), T=Tc, halo_bottom=hb, halo_top=ht, dt=np.float64(1200.0),
+                        dz=np.float64(62.5), K=np.float64(10.0), T_adjusted=O.convective_adjustment(Tc, 1200.0, 62.5, 10.0),
+                        T_adjusted_halo=O.convective_adjustment(Tc, 1200.0, 62.5, 10.0, hb, ht),
+                        adam_theta0=th, adam_grads=g, adam_thetas=np.array(ths), adam_m=m, adam_v=v)
 
 
 if __name__ == "__main__":

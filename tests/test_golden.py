@@ -78,3 +78,33 @@ def test_infer_golden_oracle():
     g = np.load(os.path.join(HERE, "infer_forcing_32.npz"))
     cfg, T, top, w = synthetic.inference_problem(6, 5)
     np.testing.assert_allclose(O.infer_forcing(cfg, g["T"], g["top_flux"], g["weights"], float(g["Lz"])), g["forcing"], rtol=1e-5, atol=1e-9)
+
+
+def test_column_ops_golden_oracle():
+    g = np.load(os.path.join(HERE, "column_ops.npz"))
+    args = (g["T"], float(g["dt"]), float(g["dz"]), float(g["K"]))
+    np.testing.assert_allclose(O.convective_adjustment(*args), g["T_adjusted"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(O.convective_adjustment(*args, g["halo_bottom"], g["halo_top"]), g["T_adjusted_halo"], rtol=1e-12, atol=1e-12)
+    assert not np.allclose(g["T_adjusted"], g["T"])
+    th, m, v, bt = g["adam_theta0"], np.zeros(101), np.zeros(101), (0.9, 0.999)
+    for i in range(3):
+        th, m, v, bt = O.adam_step(th, g["adam_grads"][i], m, v, 1e-3, (0.9, 0.999), 1e-8, bt)
+        np.testing.assert_allclose(th, g["adam_thetas"][i], rtol=1e-13)
+
+
+@pytest.mark.gpu
+def test_hip_column_ops_match_golden():
+    import torch
+    g = np.load(os.path.join(HERE, "column_ops.npz"))
+    cfg = synthetic.free_convection_problem(1, Nz=32, n_save=2).cfg
+    with colnde.ColumnNDE(cfg, 1) as nde:
+        out = nde.convective_adjustment(g["T"], float(g["dt"]), float(g["dz"]), float(g["K"]))
+        assert _rel(out, g["T_adjusted"]) < 2e-5
+        out = nde.convective_adjustment(g["T"], float(g["dt"]), float(g["dz"]), float(g["K"]), g["halo_bottom"], g["halo_top"])
+        assert _rel(out, g["T_adjusted_halo"]) < 2e-5
+        th = torch.from_numpy(g["adam_theta0"].astype(np.float32)).cuda()
+        m, v, bt = torch.zeros(101, device="cuda"), torch.zeros(101, device="cuda"), [0.9, 0.999]
+        for i in range(3):
+            nde.adam_step(th, torch.from_numpy(g["adam_grads"][i].astype(np.float32)).cuda(), m, v, 1e-3, beta_t=tuple(bt))
+            bt = [bt[0] * 0.9, bt[1] * 0.999]
+            np.testing.assert_allclose(th.cpu().numpy(), g["adam_thetas"][i], rtol=2e-5, atol=2e-6)
