@@ -52,6 +52,7 @@ struct colnde_handle {
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
     float* d_wimg = nullptr;
     float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_xscr = nullptr, *d_rt_tapez = nullptr;
+    bool rt_fwd32 = false;         // COLNDE_RT_FWD=32 at creation: the 32-column forward kernel (no Z1 tape)
     bool rt_ztape = false;         // layer-1 pre-activations taped by the forward kernel instead of recomputed by the adjoint
     int rt_rows = 0;
     float *d_w = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_x0 = nullptr, *d_bcs = nullptr, *d_truth = nullptr,
@@ -245,6 +246,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); }
     }
     h->use_rt = rt_supported(h->m) && cfg->engine != COLNDE_ENGINE_GENERIC;
+    h->rt_fwd32 = h->use_rt && rt_forward_is32();
     if (cfg->engine == COLNDE_ENGINE_MFMA && !h->use_rt) {
         delete h;
         return fail("engine = regtile requested, but it covers only Nz=32, three 96-50-20-31 nets, no smoothing, training RHS");
@@ -464,7 +466,7 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
             // Z1 tape: COLNDE_RT_ZTAPE=0 disables it (the adjoint then recomputes layer 1); it is also dropped when the
             // allocation does not fit (it trades n2 more floats of HBM for 288 of the adjoint's 840 MFMAs per stage)
             const char* ez = getenv("COLNDE_RT_ZTAPE");
-            h->rt_ztape = !rt_forward_is32() && !(ez && atoi(ez) == 0);
+            h->rt_ztape = !h->rt_fwd32 && !(ez && atoi(ez) == 0);
             if (e == hipSuccess && h->rt_ztape && hipMalloc((void**)&h->d_rt_tapez, n2 * sizeof(float)) != hipSuccess) {
                 (void)hipGetLastError();
                 h->d_rt_tapez = nullptr;
@@ -475,7 +477,7 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
         Timed tm(h, K_FORWARD);
         e = rt_launch_forward(h->m, h->d_wimg, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, d_sol,
                               with_tape ? h->d_rt_tape : nullptr, (with_tape && h->rt_ztape) ? h->d_rt_tapez : nullptr, h->n_col,
-                              h->stream);
+                              h->rt_fwd32, h->stream);
         if (e != hipSuccess) return fail("rt forward launch failed: %s", hipGetErrorString(e));
         return 0;
     }

@@ -1403,16 +1403,16 @@ hipError_t rt_launch_pack(const DevModel& m, const float* w, float* wimg, hipStr
 
 // COLNDE_RT_FWD=32 selects the one-wave-per-SIMD 32-column forward kernel (A/B aid; it does not tape Z1)
 bool rt_forward_is32() {
-    static const bool v = getenv("COLNDE_RT_FWD") && atoi(getenv("COLNDE_RT_FWD")) == 32;
-    return v;
+    const char* e = getenv("COLNDE_RT_FWD");
+    return e && atoi(e) == 32;
 }
 
 hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* x0, const float* bcs,
                              const float* save_times, int n_save, int substeps, float* sol, float* tape, float* tapez,
-                             int n_col, hipStream_t stream) {
+                             int n_col, bool fwd32, hipStream_t stream) {
     const size_t lds = rt_forward_lds_bytes();
     // COLNDE_RT_FWD=32 selects the one-wave-per-SIMD 32-column kernel (A/B aid); default: 16-column tiles, two waves per SIMD
-    if (rt_forward_is32()) {
+    if (fwd32) {
         const int n_wtiles = (n_col + RT_COLS - 1) / RT_COLS;
         const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
 #define RT_FWD(A) hipLaunchKernelGGL(rt_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, n_col)

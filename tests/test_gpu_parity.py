@@ -115,10 +115,31 @@ def test_engine_selection_and_cross_check():
         colnde.ColumnNDE(ps.cfg, 8, engine=ENGINE_REGTILE)
 
 
-@pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "diurnal", "conv_adj_branch", "swish", "raw", "dRi_small"])
+@pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "diurnal", "conv_adj_branch", "swish", "raw", "dRi_small", "relu",
+                                  "tanh", "leakyrelu"])
 def test_regtile_engine_against_oracle(name):
     from colnde.nde import ENGINE_REGTILE
     p = synthetic.wind_mixing_problem(45, n_frames=9, weight_divisor=1e2, **VARIANTS[name])
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    np.testing.assert_allclose(terms_g, terms, rtol=LOSS_RTOL, atol=1e-12)
+    assert _rel(grad_g, g) < GRAD_REL
+
+
+@pytest.mark.parametrize("env", [{"COLNDE_RT_ZTAPE": "0"}, {"COLNDE_RT_FWD": "32"}])
+def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
+    """The leaner variants behind environment switches: no Z1 tape (the adjoint recomputes layer 1) and the 32-column
+    forward kernel (one wave per SIMD; implies no Z1 tape)."""
+    from colnde.nde import ENGINE_REGTILE
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    p = synthetic.wind_mixing_problem(70, n_frames=9, weight_divisor=1e2)
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
     sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
     tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)

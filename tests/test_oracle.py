@@ -95,6 +95,9 @@ VARIANTS = {
     "smooth_Ri": dict(smooth_Ri=True),
     "diurnal": dict(diurnal=True),
     "swish": dict(activations=("swish", "swish", "identity")),
+    "relu": dict(activations=("relu", "relu", "identity")),
+    "tanh": dict(activations=("tanh", "tanh", "identity")),
+    "leakyrelu": dict(activations=("leakyrelu", "leakyrelu", "identity")),
     "dRi_small": dict(dRi=0.1),
 }
 
