@@ -1,5 +1,6 @@
 // api.hip — the C ABI of include/colnde.h on top of the MFMA tile engine.  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -55,6 +56,8 @@ struct colnde_handle {
     bool rt_fwd32 = false;         // COLNDE_RT_FWD=32 at creation: the 32-column forward kernel (no Z1 tape)
     bool rt_ztape = false;         // layer-1 pre-activations taped by the forward kernel instead of recomputed by the adjoint
     int rt_rows = 0;
+    int rt_block = 0;              // columns per pass of the gradient path (multiple of 32): the tapes hold one block at a time
+    int rt_nblocks = 0;
     float *d_w = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_x0 = nullptr, *d_bcs = nullptr, *d_truth = nullptr,
           *d_sol = nullptr, *d_tape = nullptr, *d_slab = nullptr, *d_out = nullptr, *d_times = nullptr,
           *d_partial = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
@@ -451,35 +454,71 @@ extern "C" int colnde_rhs(colnde_handle* h, const float* x, const float* weights
     return 0;
 }
 
+// Sizes the regtile engine's tapes.  They hold ONE block of columns; a problem whose tapes exceed the free HBM (many columns, or a
+// long horizon: 1,153 frames need 4x the bytes per column of the 2-day suite) runs its gradient path block after block into the same
+// buffers.  COLNDE_RT_BLOCK=<columns> forces a block size (testing aid).
+static int rt_plan_tapes(colnde_handle* h) {
+    if (h->d_rt_tape) return 0;
+    const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+    const char* ez = getenv("COLNDE_RT_ZTAPE");
+    bool want_z = !h->rt_fwd32 && !(ez && atoi(ez) == 0);
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t margin = (size_t)2 << 30;
+    const size_t budget = free_b > margin ? free_b - margin : 0;
+    const size_t per_col_x = (size_t)n_steps * 4 * 96 * sizeof(float), per_col_2 = (size_t)n_steps * 4 * ((21 * 256) / 32) * sizeof(float);
+    const int n32 = ((h->n_col + 31) / 32) * 32;
+    int block = 0;
+    for (int pass = 0; pass < 2 && block == 0; pass++) {
+        const size_t per_col = per_col_x + per_col_2 * (want_z ? 2 : 1) + 5 * 96 * sizeof(float);
+        const size_t fit = budget / per_col;
+        if (fit >= (size_t)n32) block = n32;
+        else if (fit >= 1024) {
+            const int nb = (int)(((size_t)n32 + fit - 1) / fit);
+            block = (((n32 + nb - 1) / nb) + 1023) / 1024 * 1024;
+            if ((size_t)block > fit) block = (int)(fit / 1024) * 1024;
+        } else if (want_z) want_z = false;       // not even 1,024 columns with the Z1 tape: try without it
+    }
+    const char* eb = getenv("COLNDE_RT_BLOCK");
+    if (eb && atoi(eb) >= 32) block = std::min(n32, (atoi(eb) / 32) * 32);
+    if (block == 0) return fail("the stage tapes of even 1,024 columns (%zu bytes per column) do not fit in %zu free bytes of HBM",
+                                per_col_x + per_col_2, free_b);
+    const size_t n1 = rt_tape_floats(block, n_steps), n2 = rt_tape2_floats(block, n_steps);
+    hipError_t e = hipMalloc((void**)&h->d_rt_tape, n1 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_tape2, n2 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_xscr, (size_t)rt_n_wtiles(block) * 5 * 3072 * sizeof(float));
+    h->rt_ztape = want_z;
+    if (e == hipSuccess && h->rt_ztape && hipMalloc((void**)&h->d_rt_tapez, n2 * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        h->d_rt_tapez = nullptr;
+        h->rt_ztape = false;
+    }
+    if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tapes failed: %s", (n1 + n2) * sizeof(float), hipGetErrorString(e));
+    h->rt_block = block;
+    h->rt_nblocks = (n32 + block - 1) / block;
+    return 0;
+}
+
+// regtile forward solve of columns [c0, c0 + nc): sol rows and, when taping, the block's tapes
+static int rt_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int c0, int nc) {
+    const size_t ns = h->m.ns;
+    Timed tm(h, K_FORWARD);
+    hipError_t e = rt_launch_forward(h->m, h->d_wimg, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
+                                     h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
+                                     with_tape ? h->d_rt_tape : nullptr, (with_tape && h->rt_ztape) ? h->d_rt_tapez : nullptr, nc,
+                                     h->rt_fwd32, h->stream);
+    if (e != hipSuccess) return fail("rt forward launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // ---- forward solve -------------------------------------------------------------------------------------
 static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape) {
     if (!h->have_problem) return fail("colnde_set_problem has not been called");
     if (h->use_rt) {
+        // (the gradient path tapes block by block: colnde_loss_grad_dev drives rt_forward_range itself)
         hipError_t e = rt_launch_pack(h->m, d_weights, h->d_wimg, h->stream);
         if (e != hipSuccess) return fail("rt pack launch failed: %s", hipGetErrorString(e));
-        const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
-        if (with_tape && !h->d_rt_tape) {
-            const size_t n1 = rt_tape_floats(h->n_col, n_steps), n2 = rt_tape2_floats(h->n_col, n_steps);
-            e = hipMalloc((void**)&h->d_rt_tape, n1 * sizeof(float));
-            if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_tape2, n2 * sizeof(float));
-            if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_xscr, (size_t)rt_n_wtiles(h->n_col) * 5 * 3072 * sizeof(float));
-            // Z1 tape: COLNDE_RT_ZTAPE=0 disables it (the adjoint then recomputes layer 1); it is also dropped when the
-            // allocation does not fit (it trades n2 more floats of HBM for 288 of the adjoint's 840 MFMAs per stage)
-            const char* ez = getenv("COLNDE_RT_ZTAPE");
-            h->rt_ztape = !h->rt_fwd32 && !(ez && atoi(ez) == 0);
-            if (e == hipSuccess && h->rt_ztape && hipMalloc((void**)&h->d_rt_tapez, n2 * sizeof(float)) != hipSuccess) {
-                (void)hipGetLastError();
-                h->d_rt_tapez = nullptr;
-                h->rt_ztape = false;
-            }
-            if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tapes failed: %s", (n1 + n2) * sizeof(float), hipGetErrorString(e));
-        }
-        Timed tm(h, K_FORWARD);
-        e = rt_launch_forward(h->m, h->d_wimg, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, d_sol,
-                              with_tape ? h->d_rt_tape : nullptr, (with_tape && h->rt_ztape) ? h->d_rt_tapez : nullptr, h->n_col,
-                              h->rt_fwd32, h->stream);
-        if (e != hipSuccess) return fail("rt forward launch failed: %s", hipGetErrorString(e));
-        return 0;
+        return rt_forward_range(h, d_sol, false, 0, h->n_col);
     }
     if (pack(h, d_weights)) return 1;
     if (with_tape && !h->d_tape) {
@@ -552,39 +591,50 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
     if (!h->geo_ok && !h->use_rt)
         return fail("network too large for the tile engine's adjoint: %d weight-gradient tiles, %zu B of LDS", h->m.n_tiles, h->lds_adj);
     HIPCHK(hipSetDevice(h->device));
-    if (forward_impl(h, d_weights, h->d_sol, true)) return 1;
     const int stride = h->m.n_params + 8;
     if (h->use_rt) {
+        if (!h->have_problem) return fail("colnde_set_problem has not been called");
+        if (rt_plan_tapes(h)) return 1;
         const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
-        const int n_wt = rt_n_wtiles(h->n_col), n_dw = rt_dw1_waves(h->n_col, n_steps);
+        const int n_wt = rt_n_wtiles(h->n_col), n_dw = rt_dw1_waves(h->rt_block, n_steps);
         if (!h->d_rt_slab) {
-            h->rt_rows = n_wt + n_dw;
+            h->rt_rows = n_wt + h->rt_nblocks * n_dw;
             hipError_t e = hipMalloc((void**)&h->d_rt_slab, (size_t)h->rt_rows * stride * sizeof(float));
             if (e != hipSuccess) return fail("hipMalloc of the partial-gradient slab failed: %s", hipGetErrorString(e));
         }
         LossWeights lw;
         loss_weights(h, scalings, &lw);
+        hipError_t e = rt_launch_pack(h->m, d_weights, h->d_wimg, h->stream);
+        if (e != hipSuccess) return fail("rt pack launch failed: %s", hipGetErrorString(e));
         HIPCHK(hipMemsetAsync(h->d_rt_slab, 0, (size_t)h->rt_rows * stride * sizeof(float), h->stream));
-        {
-            Timed tm(h, K_ADJOINT);
-            hipError_t e = rt_launch_adjoint(h->m, h->d_wimg, h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol,
-                                             h->d_truth, h->d_rt_tape, h->d_rt_tape2, h->d_rt_xscr, h->rt_ztape ? h->d_rt_tapez : nullptr, lw,
-                                             h->d_rt_slab, h->n_col, h->stream);
-            if (e != hipSuccess) return fail("rt adjoint launch failed: %s", hipGetErrorString(e));
-        }
-        {
-            Timed tm(h, K_DW1);
-            hipError_t e = rt_launch_dw1(h->m, h->d_rt_tape, h->d_rt_tape2, h->n_col, n_steps,
-                                         h->d_rt_slab + (size_t)n_wt * stride, h->stream);
-            if (e != hipSuccess) return fail("rt dW1 launch failed: %s", hipGetErrorString(e));
+        const size_t ns = h->m.ns;
+        for (int b = 0; b < h->rt_nblocks; b++) {
+            const int c0 = b * h->rt_block, nc = std::min(h->rt_block, h->n_col - c0);
+            if (nc <= 0) break;
+            if (rt_forward_range(h, h->d_sol, true, c0, nc)) return 1;
+            {
+                Timed tm(h, K_ADJOINT);
+                e = rt_launch_adjoint(h->m, h->d_wimg, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
+                                      h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_rt_tape,
+                                      h->d_rt_tape2, h->d_rt_xscr, h->rt_ztape ? h->d_rt_tapez : nullptr, lw,
+                                      h->d_rt_slab + (size_t)(c0 / 32) * stride, nc, h->stream);
+                if (e != hipSuccess) return fail("rt adjoint launch failed: %s", hipGetErrorString(e));
+            }
+            {
+                Timed tm(h, K_DW1);
+                e = rt_launch_dw1(h->m, h->d_rt_tape, h->d_rt_tape2, nc, n_steps, h->d_rt_slab + ((size_t)n_wt + (size_t)b * n_dw) * stride,
+                                  h->stream);
+                if (e != hipSuccess) return fail("rt dW1 launch failed: %s", hipGetErrorString(e));
+            }
         }
         {
             Timed tm(h, K_REDUCE);
-            hipError_t e = launch_reduce(h->d_rt_slab, h->rt_rows, h->m.n_params, stride, lw, d_out, h->stream);
+            e = launch_reduce(h->d_rt_slab, h->rt_rows, h->m.n_params, stride, lw, d_out, h->stream);
             if (e != hipSuccess) return fail("reduce launch failed: %s", hipGetErrorString(e));
         }
         return 0;
     }
+    if (forward_impl(h, d_weights, h->d_sol, true)) return 1;
     if (!h->d_slab) {
         hipError_t e = hipMalloc((void**)&h->d_slab, (size_t)h->n_tiles * stride * sizeof(float));
         if (e != hipSuccess) return fail("hipMalloc of the partial-gradient slab failed: %s", hipGetErrorString(e));

@@ -132,10 +132,12 @@ def test_regtile_engine_against_oracle(name):
     assert _rel(grad_g, g) < GRAD_REL
 
 
-@pytest.mark.parametrize("env", [{"COLNDE_RT_ZTAPE": "0"}, {"COLNDE_RT_FWD": "32"}])
+@pytest.mark.parametrize("env", [{"COLNDE_RT_ZTAPE": "0"}, {"COLNDE_RT_FWD": "32"}, {"COLNDE_RT_BLOCK": "32"},
+                                 {"COLNDE_RT_BLOCK": "64", "COLNDE_RT_ZTAPE": "0"}])
 def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
-    """The leaner variants behind environment switches: no Z1 tape (the adjoint recomputes layer 1) and the 32-column
-    forward kernel (one wave per SIMD; implies no Z1 tape)."""
+    """The variants behind environment switches: no Z1 tape (the adjoint recomputes layer 1), the 32-column forward kernel
+    (one wave per SIMD; implies no Z1 tape), and the column-blocked gradient path that problems larger than the free HBM
+    take (70 columns as blocks of 32 + 32 + 6 / 64 + 6 through one set of tapes)."""
     from colnde.nde import ENGINE_REGTILE
     for k, v in env.items():
         monkeypatch.setenv(k, v)
