@@ -63,6 +63,11 @@ struct colnde_handle {
           *d_partial = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
     size_t tmp_cols = 0;
     TileDesc* d_tiles = nullptr;
+    // tile16 taped-dW mode (networks whose weight-gradient tiles overflow the register file)
+    int t16_dwtape = -1;            // -1 undecided, 0 off, 1 on
+    float* d_dwtape = nullptr;
+    DwMacro* d_macros = nullptr;
+    int n_macros = 0, dw_slices = 0, t16_rows = 0;
     int *d_bias_zoff = nullptr, *d_bias_goff = nullptr;
     bool have_problem = false, have_truth = false;
     bool prof = false;
@@ -304,7 +309,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     (void)hipSetDevice(h->device);
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_xscr, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
-                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff};
+                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -583,13 +588,71 @@ extern "C" int colnde_loss(colnde_handle* h, const float* weights, const float s
     return 0;
 }
 
+// tile16, taped weight gradients: decide once per handle.  On for networks whose 16x16 weight-gradient tiles would spill in
+// adjoint_kernel (more than 256 of them: 64-256-256-63 has 384) when the delta tape fits in the free HBM;
+// COLNDE_T16_DWTAPE=1 / 0 forces it on / off.
+static int t16_plan_dwtape(colnde_handle* h) {
+    if (h->t16_dwtape >= 0) return 0;
+    const DevModel& m = h->m;
+    const char* ev = getenv("COLNDE_T16_DWTAPE");
+    bool want = ev ? atoi(ev) != 0 : (m.n_tiles > 256 || !h->geo_ok);
+    const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+    const size_t n_rec = (size_t)h->n_tiles * n_steps * 4, R = dwtape_row_floats(m);
+    const size_t need = n_rec * CT * R * sizeof(float);
+    if (want && (size_t)CT * m.ns > 6 * 512) want = false;
+    if (want && (MODEL_FLOATS + lds_floats_adjoint(m)) * sizeof(float) > 160 * 1024) want = false;
+    if (want) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t other = (size_t)h->n_tiles * n_steps * 4 * CT * m.ns * sizeof(float) + ((size_t)2 << 30);   // stage tape + margin
+        if (need + other > free_b) want = false;
+    }
+    if (!want) { h->t16_dwtape = 0; return 0; }
+    // 64x64 blocks of every layer's weight matrix
+    std::vector<DwMacro> mac;
+    for (int net = 0; net < m.n_nets; net++)
+        for (int l = 0; l < m.n_layers; l++) {
+            const int ni = m.sizes[l], no = m.sizes[l + 1];
+            for (int i0 = 0; i0 < ni; i0 += 64)
+                for (int j0 = 0; j0 < no; j0 += 64) {
+                    DwMacro d;
+                    d.a_feat = l == 0 ? i0 : dwtape_ns4(m) + net * dwtape_act4(m) + m.act_off[l - 1] + i0;
+                    d.d_feat = dwtape_ns4(m) + (m.n_nets + net) * dwtape_act4(m) + m.act_off[l] + j0;
+                    d.ni_rem = std::min(64, ni - i0);
+                    d.no_rem = std::min(64, no - j0);
+                    d.g_off = net * m.net_size + m.w_off[l] + i0 * no + j0;
+                    d.no = no;
+                    mac.push_back(d);
+                }
+        }
+    h->n_macros = (int)mac.size();
+    const int n_groups = (h->n_macros + 3) / 4;
+    size_t slices = std::max<size_t>(8, ((size_t)2048 / n_groups + 7) / 8 * 8);
+    slices = std::min(slices, std::max<size_t>(8, (n_rec / 8 + 7) / 8 * 8));
+    if (dw_gemm_lds_fits((int)R, h->n_macros))       // one workgroup per CU (two records in LDS): two rounds of slices
+        slices = std::min<size_t>(512, std::max<size_t>(1, n_rec));
+    h->dw_slices = (int)slices;
+    h->t16_rows = h->n_tiles + h->dw_slices;
+    const int stride = m.n_params + 8;
+    hipError_t e = hipMalloc((void**)&h->d_dwtape, need);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_macros, mac.size() * sizeof(DwMacro));
+    if (e == hipSuccess) e = hipMemcpy(h->d_macros, mac.data(), mac.size() * sizeof(DwMacro), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !h->d_slab) e = hipMalloc((void**)&h->d_slab, (size_t)h->t16_rows * stride * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->d_dwtape) { (void)hipFree(h->d_dwtape); h->d_dwtape = nullptr; }
+        h->t16_dwtape = 0;
+        return 0;
+    }
+    h->t16_dwtape = 1;
+    return 0;
+}
+
 extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, const float scalings[6], float* d_out) {
     if (!h) return fail("null handle");
     if (!d_weights || !scalings || !d_out) return fail("null pointer argument");
     if (!h->have_truth) return fail("no truth trajectories: pass truth to colnde_set_problem");
     if (h->m.inplace) return fail("the in-place NDE! variant is an evaluation RHS; gradients use the training RHS (inplace_variant = 0)");
-    if (!h->geo_ok && !h->use_rt)
-        return fail("network too large for the tile engine's adjoint: %d weight-gradient tiles, %zu B of LDS", h->m.n_tiles, h->lds_adj);
     HIPCHK(hipSetDevice(h->device));
     const int stride = h->m.n_params + 8;
     if (h->use_rt) {
@@ -634,7 +697,38 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         }
         return 0;
     }
+    if (t16_plan_dwtape(h)) return 1;
     if (forward_impl(h, d_weights, h->d_sol, true)) return 1;
+    if (h->t16_dwtape == 1) {
+        LossWeights lw;
+        loss_weights(h, scalings, &lw);
+        const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+        HIPCHK(hipMemsetAsync(h->d_slab, 0, (size_t)h->t16_rows * stride * sizeof(float), h->stream));
+        {
+            Timed tm(h, K_ADJOINT);
+            AdjointGeom g = {512, 1, 3, 0};
+            hipError_t e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
+                                          h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol, h->d_truth, h->d_tape,
+                                          lw, h->d_slab, h->n_col, g, (MODEL_FLOATS + lds_floats_adjoint(h->m)) * sizeof(float), h->stream,
+                                          h->d_dwtape);
+            if (e != hipSuccess) return fail("adjoint (taped dW) launch failed: %s", hipGetErrorString(e));
+        }
+        {
+            Timed tm(h, K_DW1);
+            hipError_t e = launch_dw_gemm(h->d_dwtape, (size_t)h->n_tiles * n_steps * 4, (int)dwtape_row_floats(h->m), h->d_macros,
+                                          h->n_macros, h->dw_slices, h->d_slab + (size_t)h->n_tiles * stride, stride, h->stream);
+            if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
+        }
+        {
+            Timed tm(h, K_REDUCE);
+            hipError_t e = launch_reduce(h->d_slab, h->t16_rows, h->m.n_params, stride, lw, d_out, h->stream);
+            if (e != hipSuccess) return fail("reduce launch failed: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    if (!h->geo_ok)
+        return fail("network too large for the tile engine's in-register adjoint (%d weight-gradient tiles, %zu B of LDS) and its "
+                    "delta tape does not fit in HBM", h->m.n_tiles, h->lds_adj);
     if (!h->d_slab) {
         hipError_t e = hipMalloc((void**)&h->d_slab, (size_t)h->n_tiles * stride * sizeof(float));
         if (e != hipSuccess) return fail("hipMalloc of the partial-gradient slab failed: %s", hipGetErrorString(e));

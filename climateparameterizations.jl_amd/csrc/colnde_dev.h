@@ -21,6 +21,17 @@ struct TileDesc {
     int no;       // leading dimension (layer outputs)
 };
 
+// One 64x64 block of a layer's weight gradient, contracted by one wavefront of dw_gemm_kernel from the taped rows
+// [xs | A of every net | dZ of every net] (see adjoint_kernel<..., TAPEDW>).
+struct DwMacro {
+    int a_feat;   // offset of the block's first input feature inside a taped row
+    int d_feat;   // offset of the block's first delta feature inside a taped row
+    int ni_rem;   // valid input features (<= 64)
+    int no_rem;   // valid output features (<= 64)
+    int g_off;    // offset in the flat gradient of W[out j0][in i0] (element (i, j) at g_off + i*no + j)
+    int no;       // leading dimension (layer outputs)
+};
+
 struct DevModel {
     int model, Nz, ns, n_nets, n_bc, n_layers;
     int sizes[COLNDE_MAX_LAYERS + 1];

@@ -37,7 +37,14 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
                           const TileDesc* tiles, const int* bias_zoff, const int* bias_goff, const float* bcs,
                           const float* save_times, int n_save, int substeps, const float* sol, const float* truth,
                           const float* tape, const LossWeights& lw, float* slab, int n_col, const AdjointGeom& geo,
-                          size_t lds_bytes, hipStream_t stream);
+                          size_t lds_bytes, hipStream_t stream, float* dwtape = nullptr);
+// taped-dW mode (dwtape != nullptr above): floats per 16-column tile and stage, and the contraction kernel
+static inline int dwtape_ns4(const DevModel& m) { return (m.ns + 3) & ~3; }
+static inline int dwtape_act4(const DevModel& m) { return (m.act_total + 3) & ~3; }
+static inline size_t dwtape_row_floats(const DevModel& m) { return (size_t)dwtape_ns4(m) + (size_t)2 * m.n_nets * dwtape_act4(m); }
+bool dw_gemm_lds_fits(int row_floats, int n_macros);     // the LDS-staged dW kernel applies (else the L2-streaming one)
+hipError_t launch_dw_gemm(const float* dwtape, size_t n_records, int row_floats, const DwMacro* macros, int n_macros, int n_slices,
+                          float* slab_rows, int slab_stride, hipStream_t stream);
 hipError_t launch_reduce(const float* slab, int n_tiles, int n_params, int stride, const LossWeights& lw, float* out,
                          hipStream_t stream);
 hipError_t launch_infer(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* T,

@@ -17,6 +17,7 @@
 //   src/differentiation_operators.jl:6-29, wind_mixing/src/filtering_operators.jl:1-14, wind_mixing/src/loss.jl:1-9,
 //   wind_mixing/src/NDE_training.jl:290-323 (losses), free_convection/double_gyre_nn.jl:149-168 (inference).
 #include "colnde_dev.h"
+#include <cstdlib>
 #include "engine_tile16.h"
 
 #define FWD_MAXR 12   // owner-thread register items per state array in the forward kernel: CT*ns <= FWD_MAXR*blockDim
@@ -663,14 +664,17 @@ __global__ void loss_kernel(DevModel m, const float* __restrict__ sol, const flo
 // ------------------------------------------------------------------------------------------------
 // adjoint: back-propagation through the RK4 steps, replaying the stage-input tape
 // ------------------------------------------------------------------------------------------------
-template <int MAXT, int NTH, int MAXR, bool WLDS>
+// TAPEDW: the weight gradients are not accumulated here.  Each stage's layer inputs and deltas are written to `dwtape` as
+// [tile][step][stage][CT columns][xs | A of every net | dZ of every net] and contracted by dw_gemm_kernel (networks whose
+// weight-gradient tiles would not fit the register file: 64-256-256-63 has 384 of them).
+template <int MAXT, int NTH, int MAXR, bool WLDS, bool TAPEDW = false>
 __global__ void __launch_bounds__(NTH)
 adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                const float* __restrict__ wb, const TileDesc* __restrict__ tiles, const int* __restrict__ bias_zoff,
                const int* __restrict__ bias_goff, const float* __restrict__ bcs, const float* __restrict__ save_times,
                int n_save, int substeps, const float* __restrict__ sol, const float* __restrict__ truth,
                const float* __restrict__ tape, LossWeights lw, float* __restrict__ slab /* [grid][n_params+8] */,
-               int n_col) {
+               int n_col, float* __restrict__ dwtape = nullptr) {
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
     // the model description lives in LDS: per-layer fields indexed with a runtime layer number would otherwise be
@@ -721,7 +725,7 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
     // per-slot LDS addresses (float indices into smem, lane part folded in) of this wave's weight-gradient tiles
     int a_ad[MAXT], d_ad[MAXT];
     unsigned long long a_is_act = 0ull;
-    {
+    if (!TAPEDW) {
         const int cq = lane >> 4;
 #pragma unroll
         for (int sl = 0; sl < MAXT; sl++) {
@@ -816,7 +820,27 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                 STAMP(3);
                 // weight gradients: dW += A_{l-1}^T dZ_l over the tile's 16 columns; operands of slot sl+1 are read
                 // while the MFMAs of slot sl run
-                {
+                if (TAPEDW) {
+                    // row = [xs (ns4) | A of every net (act4 each) | dZ of every net (act4 each)], every segment padded to a multiple of
+                    // 4 floats (the pads copy LDS row padding: finite, never stored by dw_gemm).  LDS rows are 8-byte aligned (stride
+                    // == 2 mod 4), tape rows 16-byte aligned: copied two floats at a time
+                    const int ns4 = (m.ns + 3) & ~3, act4 = (m.act_total + 3) & ~3;
+                    const int R = ns4 + 2 * m.n_nets * act4;
+                    float* rec = dwtape + ((size_t)blockIdx.x * n_steps * 4 + (size_t)step * 4 + st) * ((size_t)CT * R);
+                    const int hx = ns4 >> 1, ha = act4 >> 1;                                        // float2 items per segment
+                    for (int c = wave; c < CT; c += nwaves) {                                       // one wave per column
+                        float* row = rec + (size_t)c * R;
+                        for (int q = lane; q < hx; q += 64)
+                            *reinterpret_cast<float2*>(row + 2 * q) = *reinterpret_cast<const float2*>(xs + c * m.ld_x + 2 * q);
+                        for (int seg = 0; seg < 2 * m.n_nets; seg++) {                              // A of every net, then dZ of every net
+                            const int net = seg < m.n_nets ? seg : seg - m.n_nets;
+                            const float* src = (seg < m.n_nets ? A : Z) + (net * CT + c) * m.ld_a;
+                            float* dst = row + ns4 + seg * act4;
+                            for (int o = lane; o < ha; o += 64)
+                                *reinterpret_cast<float2*>(dst + 2 * o) = *reinterpret_cast<const float2*>(src + 2 * o);
+                        }
+                    }
+                } else {
                     float pa[2][4], pb[2][4];
                     const int zs4 = 4 * m.ld_a;
                     if (wave < m.n_tiles) {
@@ -874,7 +898,7 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
 #pragma unroll
     for (int sl = 0; sl < MAXT; sl++) {
         const int t = wave + sl * nwaves;
-        if (t < m.n_tiles) {
+        if (!TAPEDW && t < m.n_tiles) {
             const TileDesc d = tiles[t];
             const int j = lane & 15;
 #pragma unroll
@@ -891,6 +915,161 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
     }
     block_reduce_sums(sums, 6, red, out + m.n_params, tid, nth);
     if (tid >= 6 && tid < 8) out[m.n_params + tid] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// taped weight gradients: dW[i][j] = Σ_{records, columns} a[c][i] · dz[c][j], a split-K GEMM over the rows taped by
+// adjoint_kernel<..., TAPEDW>.  The contracted index (column, stage) is the row index of the tape, so both MFMA operands
+// are read from HBM/L2 already in operand layout (lane = feature, 128-byte segments): no LDS, no transposition.
+// One wavefront owns one 64x64 block (2 x 2 tiles of v_mfma_f32_32x32x2_f32) for one slice of the records; the four
+// waves of a workgroup hold consecutive blocks (same layer: shared input rows hit L1).  Workgroups that share a slice
+// are placed on the same XCD (id mod 8) so that the slice streams through that XCD's L2 once.
+// ------------------------------------------------------------------------------------------------
+typedef float dwf32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256)
+dw_gemm_kernel(const float* __restrict__ dwtape, size_t n_records, int R, const DwMacro* __restrict__ macros, int n_macros,
+               int n_groups, int n_slices, float* __restrict__ slab_rows, int stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
+    const int group = k % n_groups, slice = (k / n_groups) * 8 + xcd;
+    const int mi = group * 4 + wave;
+    if (slice >= n_slices || mi >= n_macros) return;
+    const DwMacro mc = macros[mi];
+    const size_t per = (n_records + n_slices - 1) / n_slices;
+    const size_t r0 = (size_t)slice * per, r1 = r0 + per < n_records ? r0 + per : n_records;
+    const int f = lane & 31, kk = lane >> 5;
+    const bool a_hi = mc.ni_rem > 32, d_hi = mc.no_rem > 32;
+    const int fa0 = min(mc.a_feat + f, R - 1), fa1 = min(mc.a_feat + 32 + f, R - 1);
+    const int fd0 = min(mc.d_feat + f, R - 1), fd1 = min(mc.d_feat + 32 + f, R - 1);
+    dwf32x16 acc00 = (dwf32x16)(0.0f), acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    for (size_t r = r0; r < r1; r++) {
+        const float* rec = dwtape + r * ((size_t)CT * R) + (size_t)kk * R;
+        float a0[8], a1[8], d0[8], d1[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const float* row = rec + (size_t)(2 * s) * R;
+            a0[s] = row[fa0];
+            d0[s] = row[fd0];
+            a1[s] = a_hi ? row[fa1] : 0.0f;
+            d1[s] = d_hi ? row[fd1] : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], d0[s], acc00, 0, 0, 0);
+            if (d_hi) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], d1[s], acc01, 0, 0, 0);
+            if (a_hi) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], d0[s], acc10, 0, 0, 0);
+            if (a_hi && d_hi) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], d1[s], acc11, 0, 0, 0);
+        }
+    }
+    // D layout: lane (j = lane & 31, h = lane >> 5), register r -> row i = 8 (r / 4) + 4 h + (r % 4)
+    float* out = slab_rows + (size_t)slice * stride + mc.g_off;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i = 8 * (r >> 2) + 4 * kk + (r & 3);
+        if (i < mc.ni_rem && f < mc.no_rem) out[(size_t)i * mc.no + f] = acc00[r];
+        if (i < mc.ni_rem && f + 32 < mc.no_rem) out[(size_t)i * mc.no + f + 32] = acc01[r];
+        if (i + 32 < mc.ni_rem && f < mc.no_rem) out[(size_t)(i + 32) * mc.no + f] = acc10[r];
+        if (i + 32 < mc.ni_rem && f + 32 < mc.no_rem) out[(size_t)(i + 32) * mc.no + f + 32] = acc11[r];
+    }
+}
+
+// LDS-staged variant: one workgroup streams its slice of records through two LDS buffers (global_load_lds, 16 bytes per lane: no
+// register staging) and its four waves contract up to DW_MAXM blocks each from LDS, so the tape is read from HBM exactly once.
+// Chosen when two records fit in LDS and the network has at most 4 * DW_MAXM blocks (64-256-256-63: 24 blocks, 77.7 KB records).
+#define DW_MAXM 6
+
+template <int MAXM>
+__global__ void __launch_bounds__(256)
+dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, const DwMacro* __restrict__ macros, int n_macros,
+                   int n_slices, float* __restrict__ slab_rows, int stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slice = blockIdx.x;
+    const int rec_floats = CT * R;                       // multiple of 4 (checked by the host)
+    const size_t per = (n_records + n_slices - 1) / n_slices;
+    const size_t r0 = (size_t)slice * per, r1 = r0 + per < n_records ? r0 + per : n_records;
+    const int f = lane & 31, kk = lane >> 5;
+    DwMacro mc[MAXM];
+    int fa0[MAXM], fa1[MAXM], fd0[MAXM], fd1[MAXM];
+    dwf32x16 acc[MAXM][4];
+#pragma unroll
+    for (int q = 0; q < MAXM; q++) {
+        const int mi = wave + 4 * q;
+        if (mi < n_macros) mc[q] = macros[mi];
+        else { mc[q].a_feat = 0; mc[q].d_feat = 0; mc[q].ni_rem = 0; mc[q].no_rem = 0; mc[q].g_off = 0; mc[q].no = 1; }
+        fa0[q] = min(mc[q].a_feat + f, R - 1) + kk * R;
+        fa1[q] = min(mc[q].a_feat + 32 + f, R - 1) + kk * R;
+        fd0[q] = min(mc[q].d_feat + f, R - 1) + kk * R;
+        fd1[q] = min(mc[q].d_feat + 32 + f, R - 1) + kk * R;
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[q][t] = (dwf32x16)(0.0f);
+    }
+    // asynchronous copy of one record into an LDS buffer: 1 KB per wave instruction, lanes contiguous
+    auto fetch = [&](size_t r, int dst /* float offset of the buffer inside smem */) {
+        const float* src = dwtape + r * (size_t)rec_floats;
+        for (int o = wave * 256; o < rec_floats; o += 4 * 256) {
+            if (o + lane * 4 < rec_floats)
+                __builtin_amdgcn_global_load_lds(src + o + lane * 4, smem + dst + o, 16, 0, 0);
+        }
+    };
+    if (r0 < r1) fetch(r0, 0);
+    __syncthreads();
+    int cur = 0;                                         // float offset of the buffer being contracted
+    for (size_t r = r0; r < r1; r++) {
+        if (r + 1 < r1) fetch(r + 1, rec_floats - cur);
+        const float* rec = smem + cur;
+        // straight-line: all four 32x32 tiles of every block are issued (blocks narrower than 64 read clamped, in-range
+        // features whose products are never stored) so that the operand reads of later k-steps pipeline under the MFMAs
+#pragma unroll
+        for (int q = 0; q < MAXM; q++) {
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const float* row = rec + 2 * s * R;
+                const float a0 = row[fa0[q]], d0 = row[fd0[q]], a1 = row[fa1[q]], d1 = row[fd1[q]];
+                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d0, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d1, acc[q][1], 0, 0, 0);
+                acc[q][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d0, acc[q][2], 0, 0, 0);
+                acc[q][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d1, acc[q][3], 0, 0, 0);
+            }
+        }
+        __syncthreads();          // every wave is done with this buffer, and (vmcnt drain) the next record has landed
+        cur = rec_floats - cur;
+    }
+#pragma unroll
+    for (int q = 0; q < MAXM; q++) {
+        if (mc[q].ni_rem == 0) continue;
+        float* out = slab_rows + (size_t)slice * stride + mc[q].g_off;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = 8 * (r >> 2) + 4 * kk + (r & 3);
+            if (i < mc[q].ni_rem && f < mc[q].no_rem) out[(size_t)i * mc[q].no + f] = acc[q][0][r];
+            if (i < mc[q].ni_rem && f + 32 < mc[q].no_rem) out[(size_t)i * mc[q].no + f + 32] = acc[q][1][r];
+            if (i + 32 < mc[q].ni_rem && f < mc[q].no_rem) out[(size_t)(i + 32) * mc[q].no + f] = acc[q][2][r];
+            if (i + 32 < mc[q].ni_rem && f + 32 < mc[q].no_rem) out[(size_t)(i + 32) * mc[q].no + f + 32] = acc[q][3][r];
+        }
+    }
+}
+
+bool dw_gemm_lds_fits(int row_floats, int n_macros) {
+    const char* e = getenv("COLNDE_T16_DWLDS");           // 0: always the L2-streaming kernel (testing aid)
+    if (e && atoi(e) == 0) return false;
+    return n_macros <= 4 * DW_MAXM && ((CT * row_floats) & 3) == 0 && (size_t)2 * CT * row_floats * sizeof(float) <= 160 * 1024;
+}
+
+hipError_t launch_dw_gemm(const float* dwtape, size_t n_records, int row_floats, const DwMacro* macros, int n_macros, int n_slices,
+                          float* slab_rows, int slab_stride, hipStream_t stream) {
+    if (dw_gemm_lds_fits(row_floats, n_macros)) {
+        if (n_records == 0 || n_slices < 1) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(dw_gemm_lds_kernel<DW_MAXM>, dim3(n_slices), dim3(256), (size_t)2 * CT * row_floats * sizeof(float), stream, dwtape,
+                           n_records, row_floats, macros, n_macros, n_slices, slab_rows, slab_stride);
+        return hipGetLastError();
+    }
+    if (n_records == 0 || n_macros < 1 || n_slices < 8 || (n_slices & 7)) return hipErrorInvalidValue;
+    const int n_groups = (n_macros + 3) / 4;
+    const int grid = n_groups * n_slices;          // = 8 * n_groups * (n_slices / 8): every (group, slice) pair once
+    hipLaunchKernelGGL(dw_gemm_kernel, dim3(grid), dim3(256), 0, stream, dwtape, n_records, row_floats, macros, n_macros, n_groups,
+                       n_slices, slab_rows, slab_stride);
+    return hipGetLastError();
 }
 
 // grad[p] = Σ_tiles slab[tile][p] in a fixed order (deterministic); the 6 raw sums become scaled mean terms
@@ -1018,8 +1197,25 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
                           const TileDesc* tiles, const int* bias_zoff, const int* bias_goff, const float* bcs,
                           const float* save_times, int n_save, int substeps, const float* sol, const float* truth,
                           const float* tape, const LossWeights& lw, float* slab, int n_col, const AdjointGeom& geo,
-                          size_t lds_bytes, hipStream_t stream) {
+                          size_t lds_bytes, hipStream_t stream, float* dwtape) {
     const int n_tiles = (n_col + CT - 1) / CT;
+    if (dwtape) {
+        // 1,024 threads (four waves per SIMD, 101 VGPRs) hide the L2 latency of the streamed weights better than 512:
+        // 328 vs 377 ms on 64-256-256-63 (COLNDE_T16_TAPE_THREADS=512 selects the smaller workgroup)
+        const char* et = getenv("COLNDE_T16_TAPE_THREADS");
+        const int nth_env = et ? atoi(et) : 1024;
+        if (nth_env == 1024 && CT * m.ns <= 2 * 1024)
+            hipLaunchKernelGGL((adjoint_kernel<1, 1024, 2, false, true>), dim3(n_tiles), dim3(1024), lds_bytes, stream, m, pk, w, wf, wb,
+                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape);
+        else if (CT * m.ns <= 3 * 512)
+            hipLaunchKernelGGL((adjoint_kernel<1, 512, 3, false, true>), dim3(n_tiles), dim3(512), lds_bytes, stream, m, pk, w, wf, wb,
+                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape);
+        else if (CT * m.ns <= 6 * 512)
+            hipLaunchKernelGGL((adjoint_kernel<1, 512, 6, false, true>), dim3(n_tiles), dim3(512), lds_bytes, stream, m, pk, w, wf, wb,
+                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (geo.nthreads == 512 && geo.maxt == 16 && geo.maxr == 3 && geo.wlds) LAUNCH_ADJ(16, 512, 3, true);
     else if (geo.nthreads == 256 && geo.maxt == 32 && geo.maxr == 6 && geo.wlds) LAUNCH_ADJ(32, 256, 6, true);
     else if (geo.nthreads == 256 && geo.maxt == 32 && geo.maxr == 6) LAUNCH_ADJ(32, 256, 6, false);
@@ -1073,6 +1269,10 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     SETATTR((adjoint_kernel<32, 256, 12, false>));
     SETATTR((adjoint_kernel<32, 512, 6, false>));
     SETATTR((adjoint_kernel<48, 512, 3, false>));
+    SETATTR((adjoint_kernel<1, 512, 3, false, true>));
+    SETATTR((adjoint_kernel<1, 512, 6, false, true>));
+    SETATTR((adjoint_kernel<1, 1024, 2, false, true>));
+    SETATTR((dw_gemm_lds_kernel<DW_MAXM>));
 #undef SETATTR
     return hipSuccess;
 }

@@ -66,6 +66,37 @@ def test_free_convection(Nz, ca):
     assert _rel(grad_g, g) < GRAD_REL
 
 
+@pytest.mark.parametrize("case", ["fc32", "fc64", "fc32_ca", "wind_mixing", "fc64_l2stream", "wind_mixing_l2stream", "fc64_512threads"])
+def test_tile16_taped_weight_gradients(case, monkeypatch):
+    """tile16 with the layer deltas taped and every dW contracted by the split-K GEMM kernel (the default for 64-256-256-63,
+    whose 384 gradient tiles overflow the register file; forced here on the smaller networks too)."""
+    from colnde.nde import ENGINE_TILE16
+    monkeypatch.setenv("COLNDE_T16_DWTAPE", "1")
+    if case.endswith("_l2stream"):                   # the split-K kernel that reads its operands straight from L2 (no LDS staging)
+        monkeypatch.setenv("COLNDE_T16_DWLDS", "0")
+        case = case[:-len("_l2stream")]
+    if case.endswith("_512threads"):
+        monkeypatch.setenv("COLNDE_T16_TAPE_THREADS", "512")
+        case = case[:-len("_512threads")]
+    if case == "wind_mixing":
+        p = synthetic.wind_mixing_problem(21, n_frames=5, weight_divisor=1e2)
+        sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    else:
+        ca = case.endswith("_ca")
+        p = synthetic.free_convection_problem(37, Nz=64 if "64" in case else 32, n_save=5, substeps=16 if ca else 2,
+                                              convective_adjustment=ca, t_end=0.01)
+        sc = O.default_loss_scalings(p.cfg)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_TILE16) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+        tot_2, _, grad_2 = nde.loss_grad(p.weights, sc)
+    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
+    assert _rel(grad_g, g) < GRAD_REL
+    assert tot_2 == tot_g and np.array_equal(grad_2, grad_g)        # fixed-order reductions: bit-reproducible
+
+
 def test_infer_forcing():
     cfg, T, top, w = synthetic.inference_problem(16, 9)
     ref = O.infer_forcing(cfg, T, top, w, 1000.0)

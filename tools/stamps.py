@@ -11,14 +11,16 @@ if FWD: sys.argv.remove("--fwd")
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcolnde_stamps_fwd.so" if FWD else "libcolnde_stamps.so")
 L = _lib.lib()
 L.colnde_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
+FC64 = "--fc64" in sys.argv     # free convection 64-256-256-63 (tile16, taped weight gradients)
+if FC64: sys.argv.remove("--fc64")
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 33
-p = synthetic.wind_mixing_problem(ncol, n_frames=frames)
+p = synthetic.free_convection_problem(ncol, Nz=64, n_save=frames) if FC64 else synthetic.wind_mixing_problem(ncol, n_frames=frames)
 nde = colnde.ColumnNDE(p.cfg, ncol)
 nde.set_problem(p.x0, p.bcs)
 truth = nde.forward(p.weights_truth)
 nde.set_problem(p.x0, p.bcs, truth)
-nde.loss_grad(p.weights, [1, 1, 1, 5e-3, 5e-3, 5e-3])
+nde.loss_grad(p.weights, [0, 0, 1, 0, 0, 0] if FC64 else [1, 1, 1, 5e-3, 5e-3, 5e-3])
 buf = (ctypes.c_ulonglong * 16)()
 _lib.check(L.colnde_debug_stamps(nde._h, buf))
 if nde.engine == 2 and FWD:
