@@ -498,7 +498,11 @@ static int rt_plan_tapes(colnde_handle* h) {
         h->d_rt_tapez = nullptr;
         h->rt_ztape = false;
     }
-    if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tapes failed: %s", (n1 + n2) * sizeof(float), hipGetErrorString(e));
+    if (e != hipSuccess) {
+        for (float** q : {&h->d_rt_tape, &h->d_rt_tape2, &h->d_rt_xscr, &h->d_rt_tapez})      // leave no half-built state behind
+            if (*q) { (void)hipFree(*q); *q = nullptr; }
+        return fail("hipMalloc of the %zu-byte stage tapes failed: %s", (n1 + n2) * sizeof(float), hipGetErrorString(e));
+    }
     h->rt_block = block;
     h->rt_nblocks = (n32 + block - 1) / block;
     return 0;
