@@ -858,6 +858,38 @@ extern "C" int colnde_adam_step_dev(colnde_handle* h, float* d_weights, const fl
     return 0;
 }
 
+extern "C" int colnde_coarse_grain_dev(colnde_handle* h, const float* d_in, int n_rows, int N, int n, int location, float* d_out) {
+    if (!h) return fail("null handle");
+    if (!d_in || !d_out) return fail("null pointer argument");
+    if (n_rows < 1 || N < 2 || n < 2 || n > N) return fail("need n_rows >= 1 and 2 <= n <= N (n_rows = %d, N = %d, n = %d)", n_rows, N, n);
+    if (location != 0 && location != 1) return fail("location must be 0 (Center) or 1 (Face)");
+    if (location == 0 && N % n != 0) return fail("coarse_grain(Center): n = %d must divide N = %d", n, N);
+    HIPCHK(hipSetDevice(h->device));
+    hipError_t e = launch_coarse_grain(d_in, n_rows, N, n, location, d_out, h->stream);
+    if (e != hipSuccess) return fail("coarse_grain launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_zscore_stats_dev(colnde_handle* h, const float* d_x, int64_t count, float* d_mu_sigma) {
+    if (!h) return fail("null handle");
+    if (!d_x || !d_mu_sigma) return fail("null pointer argument");
+    if (count < 2) return fail("need at least two values for a standard deviation");
+    HIPCHK(hipSetDevice(h->device));
+    hipError_t e = launch_zscore_stats(d_x, (long)count, d_mu_sigma, h->stream);
+    if (e != hipSuccess) return fail("zscore_stats launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_scale_dev(colnde_handle* h, const float* d_x, int64_t count, const float* d_mu_sigma, float* d_out) {
+    if (!h) return fail("null handle");
+    if (!d_x || !d_mu_sigma || !d_out) return fail("null pointer argument");
+    if (count < 1) return fail("count must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    hipError_t e = launch_zscore_scale(d_x, (long)count, d_mu_sigma, d_out, h->stream);
+    if (e != hipSuccess) return fail("scale launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // Diagnostic builds (-DCOLNDE_STAMPS) only; not part of include/colnde.h.  Returns zeros in the shipped library.
 extern "C" int colnde_debug_stamps(colnde_handle* h, unsigned long long* out16) {
     if (!h || !out16) return fail("null argument");

@@ -8,3 +8,7 @@ hipError_t launch_convective_adjustment(const float* T, const float* halo_bottom
                                         float* out, int Nz, int n_col, hipStream_t stream);
 hipError_t launch_adam_step(float* w, const float* grad, float* m, float* v, float eta, float beta1, float beta2, float eps,
                             float beta1_t, float beta2_t, int n, hipStream_t stream);
+// data preparation: rows are profiles ([n_rows][N] -> [n_rows][n]); face = 0: block means, 1: linear interpolation keeping the end points
+hipError_t launch_coarse_grain(const float* in, int n_rows, int N, int n, int face, float* out, hipStream_t stream);
+hipError_t launch_zscore_stats(const float* x, long count, float* out2 /* mu, sigma */, hipStream_t stream);
+hipError_t launch_zscore_scale(const float* x, long count, const float* mu_sigma, float* out, hipStream_t stream);

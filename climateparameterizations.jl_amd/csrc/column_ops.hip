@@ -133,3 +133,79 @@ hipError_t launch_adam_step(float* w, const float* grad, float* m, float* v, flo
                        1.0f / (1.0f - beta1_t), 1.0f / (1.0f - beta2_t), n);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// data preparation: wind_mixing/src/data_containers.jl:343-427 coarse-grains every LES profile
+// 128 -> 32 cells / 129 -> 33 faces and z-scores each variable before training.
+// ------------------------------------------------------------------------------------------------
+// coarse_grain(Φ, n, Center), src/DataWrangling/coarse_graining.jl:8-16: block means, Δ = N / n.
+// coarse_grain_linear_interpolation(Φ, n, Face), :47-62: end points kept, interior point i (1-based) at position
+// p = 1 + (i-1)(N-1)/(n-1): (⌊p⌋ + 1 - p) Φ[⌊p⌋] + (p - ⌊p⌋) Φ[⌊p⌋ + 1].  One thread per output value; rows are profiles.
+__global__ void __launch_bounds__(256) coarse_grain_kernel(const float* __restrict__ in, int n_rows, int N, int n, int face,
+                                                           float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)n_rows * n) return;
+    const int row = (int)(idx / n), i = (int)(idx - (long)row * n);
+    const float* src = in + (size_t)row * N;
+    float v;
+    if (!face) {
+        const int d = N / n;
+        float acc = 0.0f;
+        for (int k = 0; k < d; k++) acc += src[i * d + k];
+        v = acc / (float)d;
+    } else if (i == 0) v = src[0];
+    else if (i == n - 1) v = src[N - 1];
+    else {
+        const double p = 1.0 + (double)i * ((double)(N - 1) / (double)(n - 1));     // 1-based position, as the reference computes it
+        const double fl = floor(p);
+        const int k = (int)fl - 1;                                                    // 0-based index of Φ[⌊p⌋]
+        v = (float)((fl + 1.0 - p) * (double)src[k] + (p - fl) * (double)src[k + 1 < N ? k + 1 : N - 1]);
+    }
+    out[idx] = v;
+}
+
+// ZeroMeanUnitVarianceScaling(data) (src/DataWrangling/feature_scaling.jl:17-20): μ = mean, σ = std (n - 1 in the denominator),
+// accumulated in float64 by one workgroup in a fixed order (deterministic); out[0] = μ, out[1] = σ.
+__global__ void __launch_bounds__(1024) zscore_stats_kernel(const float* __restrict__ x, long count, float* __restrict__ out2) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < count; i += 1024) s += (double)x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+    const double mu = red[0] / (double)count;
+    __syncthreads();
+    double q = 0.0;
+    for (long i = threadIdx.x; i < count; i += 1024) { const double d = (double)x[i] - mu; q += d * d; }
+    red[threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) { out2[0] = (float)mu; out2[1] = (float)sqrt(red[0] / (double)(count > 1 ? count - 1 : 1)); }
+}
+
+// scale(x, s) = (x - μ) / σ (feature_scaling.jl:22); μ, σ read from device memory (the output of zscore_stats_kernel)
+__global__ void __launch_bounds__(256) zscore_scale_kernel(const float* __restrict__ x, long count, const float* __restrict__ mu_sigma,
+                                                           float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = (x[i] - mu_sigma[0]) / mu_sigma[1];
+}
+
+hipError_t launch_coarse_grain(const float* in, int n_rows, int N, int n, int face, float* out, hipStream_t stream) {
+    if (n_rows < 1 || N < 2 || n < 2 || n > N) return hipErrorInvalidValue;
+    if (!face && N % n != 0) return hipErrorInvalidValue;
+    const long total = (long)n_rows * n;
+    hipLaunchKernelGGL(coarse_grain_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, n_rows, N, n, face, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_zscore_stats(const float* x, long count, float* out2, hipStream_t stream) {
+    if (count < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(zscore_stats_kernel, dim3(1), dim3(1024), 0, stream, x, count, out2);
+    return hipGetLastError();
+}
+
+hipError_t launch_zscore_scale(const float* x, long count, const float* mu_sigma, float* out, hipStream_t stream) {
+    if (count < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(zscore_scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, x, count, mu_sigma, out);
+    return hipGetLastError();
+}

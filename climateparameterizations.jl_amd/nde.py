@@ -257,3 +257,27 @@ class ColumnNDE:
         _lib.check(self._L.colnde_adam_step_dev(self._h, weights.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), float(eta),
                                                 float(beta[0]), float(beta[1]), float(eps), float(bt[0]), float(bt[1]), n))
         return weights
+
+    # ---- data preparation on device (wind_mixing/src/data_containers.jl:343-427) -------------------------
+    def coarse_grain(self, x, n: int, location: str = "center"):
+        """`coarse_grain(Φ, n, Center)` / `coarse_grain_linear_interpolation(Φ, n, Face)` on the rows of a device tensor [rows, N]."""
+        import torch
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2):
+            raise ValueError("expected a contiguous float32 device tensor [rows, N]")
+        out = torch.empty(x.shape[0], int(n), dtype=torch.float32, device=x.device)
+        self.use_torch_stream()
+        _lib.check(self._L.colnde_coarse_grain_dev(self._h, x.data_ptr(), x.shape[0], x.shape[1], int(n),
+                                                   {"center": 0, "face": 1}[location], out.data_ptr()))
+        return out
+
+    def zscore(self, x):
+        """`ZeroMeanUnitVarianceScaling(data)` and its application: returns (scaled, mu_sigma) — both stay on the device."""
+        import torch
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+            raise ValueError("expected a contiguous float32 device tensor")
+        ms = torch.empty(2, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        self.use_torch_stream()
+        _lib.check(self._L.colnde_zscore_stats_dev(self._h, x.data_ptr(), x.numel(), ms.data_ptr()))
+        _lib.check(self._L.colnde_scale_dev(self._h, x.data_ptr(), x.numel(), ms.data_ptr(), out.data_ptr()))
+        return out, ms

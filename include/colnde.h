@@ -140,6 +140,15 @@ int colnde_convective_adjustment_dev(colnde_handle* h, const float* d_T, const f
 int colnde_adam_step_dev(colnde_handle* h, float* d_weights, const float* d_grad, float* d_m, float* d_v, float eta, float beta1,
                          float beta2, float eps, float beta1_t, float beta2_t, int n);
 
+/* Data preparation on device (wind_mixing/src/data_containers.jl:343-427).  d_in [n_rows][N] -> d_out [n_rows][n], one row per
+ * profile.  location 0 = Center: coarse_grain(Φ, n, Center) (src/DataWrangling/coarse_graining.jl:8-16), block means, n divides N;
+ * location 1 = Face: coarse_grain_linear_interpolation(Φ, n, Face) (:47-62), end points kept (the form data_containers.jl:357 uses). */
+int colnde_coarse_grain_dev(colnde_handle* h, const float* d_in, int n_rows, int N, int n, int location, float* d_out);
+/* ZeroMeanUnitVarianceScaling(data) (src/DataWrangling/feature_scaling.jl:17-20): d_mu_sigma[0] = mean, [1] = std (n-1 denominator)
+ * of `count` device floats; colnde_scale_dev applies scale(x, s) = (x - μ)/σ (:22) with μ, σ read from device memory. */
+int colnde_zscore_stats_dev(colnde_handle* h, const float* d_x, int64_t count, float* d_mu_sigma);
+int colnde_scale_dev(colnde_handle* h, const float* d_x, int64_t count, const float* d_mu_sigma, float* d_out);
+
 /* ---- measurement: HIP-event timing of the handle's kernels on its stream.
  * which: 0 = forward solve kernel, 1 = adjoint kernel, 2 = gradient reduce, 3 = rhs, 4 = inference,
  * 5 = streaming dW1 GEMM (regtile engine only), 6 = convective adjustment, 7 = ADAM step.

@@ -575,3 +575,33 @@ def adam_step(theta, grad, m, v, eta, beta, eps, beta_t):
     v = beta[1] * v + (1 - beta[1]) * grad * grad
     delta = m / (1 - beta_t[0]) / (np.sqrt(v / (1 - beta_t[1])) + eps) * eta
     return theta - delta, m, v, (beta_t[0] * beta[0], beta_t[1] * beta[1])
+
+
+def coarse_grain_center(phi, n):
+    """`coarse_grain(Φ, n, Center)` — src/DataWrangling/coarse_graining.jl:8-16 (block means, Δ = N/n)."""
+    phi = np.asarray(phi, np.float64)
+    d = phi.shape[-1] // n
+    assert d * n == phi.shape[-1]
+    return phi.reshape(phi.shape[:-1] + (n, d)).mean(axis=-1)
+
+
+def coarse_grain_linear_interpolation_face(phi, n):
+    """`coarse_grain_linear_interpolation(Φ, n, Face)` — src/DataWrangling/coarse_graining.jl:47-62, the form
+    wind_mixing/src/data_containers.jl:357 uses: end points kept, interior point i (1-based) at p = 1 + (i-1)(N-1)/(n-1)."""
+    phi = np.asarray(phi, np.float64)
+    N = phi.shape[-1]
+    out = np.empty(phi.shape[:-1] + (n,), np.float64)
+    out[..., 0], out[..., -1] = phi[..., 0], phi[..., -1]
+    gap = (N - 1) / (n - 1)
+    for i in range(2, n):                          # 1-based interior indices, as in the reference loop
+        p = 1 + (i - 1) * gap
+        f = int(np.floor(p))
+        out[..., i - 1] = (f + 1 - p) * phi[..., f - 1] + (p - f) * phi[..., min(f, N - 1)]
+    return out
+
+
+def zero_mean_unit_variance(data):
+    """`ZeroMeanUnitVarianceScaling(data)` — src/DataWrangling/feature_scaling.jl:17-23: (μ, σ = std with n-1), scaled."""
+    data = np.asarray(data, np.float64)
+    mu, sigma = data.mean(), data.std(ddof=1)
+    return (data - mu) / sigma, mu, sigma
