@@ -49,6 +49,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 // acc += sum_{s<n} mfma(ap[s*a_step], bp[s*b_step]): operands are read U steps at a time ahead of their MFMAs.
 // (The engine is instruction-issue-bound, so the loop carries no clamps or selects: full chunks, then a remainder.)
+#ifndef GU
+#define GU 32     // prefetch depth (k-steps) of the chains whose A operand streams from L2 (packed weight image); measured on the
+                  // 64-256-256-63 taped adjoint: depth 4: 296 ms, 8: 413 ms, 16: 247 ms, 32: 233 ms (remainders halve the depth)
+#endif
 template <int U>
 __device__ __forceinline__ f32x4 gemm_chain(const float* ap, int a_step, const float* bp, int b_step, int n, f32x4 acc) {
     int s = 0;
@@ -62,6 +66,7 @@ __device__ __forceinline__ f32x4 gemm_chain(const float* ap, int a_step, const f
 #pragma unroll
         for (int u = 0; u < U; u++) acc = mfma16(a[u], b[u], acc);
     }
+    if (U > 1) return s < n ? gemm_chain<(U > 1 ? U / 2 : 1)>(ap + s * a_step, a_step, bp + s * b_step, b_step, n - s, acc) : acc;
     for (; s < n; s++) acc = mfma16(ap[s * a_step], bp[s * b_step], acc);
     return acc;
 }
@@ -139,7 +144,7 @@ __device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& p
                 acc = gemm_chain<4>(ap, 4 * no, in + kq, 4, nk4, acc);
             } else {
                 const float* ap = wf + (size_t)net * pk.pf_net + pk.pf_off[l] + (size_t)mt * nk4 * 64 + lane;
-                acc = gemm_chain<4>(ap, 64, in + kq, 4, nk4, acc);
+                acc = gemm_chain<GU>(ap, 64, in + kq, 4, nk4, acc);
             }
             FINE(2);
             const int ro = (net * CT + c) * m.ld_a + m.act_off[l];
@@ -178,7 +183,7 @@ __device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& 
                     acc = gemm_chain<4>(ap, 4, dz + jq, 4, nj4, acc);
                 } else {
                     const float* ap = wb + (size_t)net * pk.pb_net + pk.pb_off[l] + (size_t)it * nj4 * 64 + lane;
-                    acc = gemm_chain<4>(ap, 64, dz + jq, 4, nj4, acc);
+                    acc = gemm_chain<GU>(ap, 64, dz + jq, 4, nj4, acc);
                 }
                 const int ro = (net * CT + c) * m.ld_a + m.act_off[l - 1];
 #pragma unroll
@@ -197,7 +202,7 @@ __device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& 
                         acc = gemm_chain<4>(ap, 4, dz + jq, 4, nj4, acc);
                     } else {
                         const float* ap = wb + (size_t)net * pk.pb_net + pk.pb_off[0] + (size_t)it * nj4 * 64 + lane;
-                        acc = gemm_chain<4>(ap, 64, dz + jq, 4, nj4, acc);
+                        acc = gemm_chain<GU>(ap, 64, dz + jq, 4, nj4, acc);
                     }
                 }
 #pragma unroll

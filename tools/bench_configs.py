@@ -5,7 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import colnde
-from colnde import synthetic
+from colnde import synthetic, _lib
+if os.environ.get("COLNDE_LIB"):      # A/B aid: another build of the library
+    _lib.LIB_PATH = os.path.join(ROOT, "climateparameterizations.jl_amd", os.environ["COLNDE_LIB"])
 
 dev = torch.device("cuda", 0)
 which = sys.argv[1:] or ["2", "4s", "5"]
