@@ -980,12 +980,13 @@ dw_gemm_kernel(const float* __restrict__ dwtape, size_t n_records, int R, const 
 }
 
 // LDS-staged variant: one workgroup streams its slice of records through two LDS buffers (global_load_lds, 16 bytes per lane: no
-// register staging) and its four waves contract up to DW_MAXM blocks each from LDS, so the tape is read from HBM exactly once.
-// Chosen when two records fit in LDS and the network has at most 4 * DW_MAXM blocks (64-256-256-63: 24 blocks, 77.7 KB records).
-#define DW_MAXM 6
+// register staging) and its DW_NW waves contract up to DW_MAXM blocks each from LDS, so the tape is read from HBM exactly once.
+// Chosen when two records fit in LDS and the network has at most DW_NW * DW_MAXM blocks (64-256-256-63: 24 blocks, 77.7 KB records).
+#define DW_MAXM 3          // blocks per wave: 3 x 64 accumulator registers leave room for two waves per SIMD
+#define DW_NW 8            // waves per workgroup
 
-template <int MAXM>
-__global__ void __launch_bounds__(256)
+template <int MAXM, int NW>
+__global__ void __launch_bounds__(64 * NW)
 dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, const DwMacro* __restrict__ macros, int n_macros,
                    int n_slices, float* __restrict__ slab_rows, int stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -999,7 +1000,7 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
     dwf32x16 acc[MAXM][4];
 #pragma unroll
     for (int q = 0; q < MAXM; q++) {
-        const int mi = wave + 4 * q;
+        const int mi = wave + NW * q;
         if (mi < n_macros) mc[q] = macros[mi];
         else { mc[q].a_feat = 0; mc[q].d_feat = 0; mc[q].ni_rem = 0; mc[q].no_rem = 0; mc[q].g_off = 0; mc[q].no = 1; }
         fa0[q] = min(mc[q].a_feat + f, R - 1) + kk * R;
@@ -1012,7 +1013,7 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
     // asynchronous copy of one record into an LDS buffer: 1 KB per wave instruction, lanes contiguous
     auto fetch = [&](size_t r, int dst /* float offset of the buffer inside smem */) {
         const float* src = dwtape + r * (size_t)rec_floats;
-        for (int o = wave * 256; o < rec_floats; o += 4 * 256) {
+        for (int o = wave * 256; o < rec_floats; o += NW * 256) {
             if (o + lane * 4 < rec_floats)
                 __builtin_amdgcn_global_load_lds(src + o + lane * 4, smem + dst + o, 16, 0, 0);
         }
@@ -1058,14 +1059,14 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
 bool dw_gemm_lds_fits(int row_floats, int n_macros) {
     const char* e = getenv("COLNDE_T16_DWLDS");           // 0: always the L2-streaming kernel (testing aid)
     if (e && atoi(e) == 0) return false;
-    return n_macros <= 4 * DW_MAXM && ((CT * row_floats) & 3) == 0 && (size_t)2 * CT * row_floats * sizeof(float) <= 160 * 1024;
+    return n_macros <= DW_NW * DW_MAXM && ((CT * row_floats) & 3) == 0 && (size_t)2 * CT * row_floats * sizeof(float) <= 160 * 1024;
 }
 
 hipError_t launch_dw_gemm(const float* dwtape, size_t n_records, int row_floats, const DwMacro* macros, int n_macros, int n_slices,
                           float* slab_rows, int slab_stride, hipStream_t stream) {
     if (dw_gemm_lds_fits(row_floats, n_macros)) {
         if (n_records == 0 || n_slices < 1) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(dw_gemm_lds_kernel<DW_MAXM>, dim3(n_slices), dim3(256), (size_t)2 * CT * row_floats * sizeof(float), stream, dwtape,
+        hipLaunchKernelGGL((dw_gemm_lds_kernel<DW_MAXM, DW_NW>), dim3(n_slices), dim3(64 * DW_NW), (size_t)2 * CT * row_floats * sizeof(float), stream, dwtape,
                            n_records, row_floats, macros, n_macros, n_slices, slab_rows, slab_stride);
         return hipGetLastError();
     }
@@ -1277,7 +1278,7 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     SETATTR((adjoint_kernel<1, 512, 3, false, true>));
     SETATTR((adjoint_kernel<1, 512, 6, false, true>));
     SETATTR((adjoint_kernel<1, 1024, 2, false, true>));
-    SETATTR((dw_gemm_lds_kernel<DW_MAXM>));
+    SETATTR((dw_gemm_lds_kernel<DW_MAXM, DW_NW>));
 #undef SETATTR
     return hipSuccess;
 }
