@@ -253,7 +253,11 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         if (e == hipSuccess) e = rt_set_attributes();
         if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); }
     }
-    h->use_rt = rt_supported(h->m) && cfg->engine != COLNDE_ENGINE_GENERIC;
+    // AUTO: regtile where it applies, except for small problems (< 4,096 columns), which are latency points — one wavefront per
+    // SIMD at most — where tile16's eight cooperating waves per 16-column tile finish a gradient sooner (8 columns x 576 steps:
+    // 66 vs 83 ms per iteration)
+    h->use_rt = rt_supported(h->m) && cfg->engine != COLNDE_ENGINE_GENERIC &&
+                (cfg->engine == COLNDE_ENGINE_MFMA || cfg->n_columns >= 4096 || !h->geo_ok);
     h->rt_fwd32 = h->use_rt && rt_forward_is32();
     if (cfg->engine == COLNDE_ENGINE_MFMA && !h->use_rt) {
         delete h;

@@ -128,7 +128,8 @@ def test_engine_selection_and_cross_check():
     res = {}
     for eng in (ENGINE_TILE16, ENGINE_REGTILE, ENGINE_AUTO):
         with colnde.ColumnNDE(p.cfg, p.n_columns, engine=eng) as nde:
-            assert nde.engine == (ENGINE_TILE16 if eng == ENGINE_TILE16 else ENGINE_REGTILE)
+            # AUTO sends small problems (< 4,096 columns: latency points) to tile16 and everything else regtile covers to regtile
+            assert nde.engine == (ENGINE_REGTILE if eng == ENGINE_REGTILE else ENGINE_TILE16)
             nde.set_problem(p.x0, p.bcs)
             truth = nde.forward(p.weights_truth)
             nde.set_problem(p.x0, p.bcs, truth)
@@ -138,6 +139,8 @@ def test_engine_selection_and_cross_check():
     a, b = res[ENGINE_TILE16][1], res[ENGINE_REGTILE][1]
     assert np.isclose(a[0], b[0], rtol=1e-4)
     assert _rel(a[2], b[2].astype(np.float64)) < 1e-4
+    with colnde.ColumnNDE(p.cfg, 4096) as nde:
+        assert nde.engine == ENGINE_REGTILE
     # smoothing is outside the regtile engine's coverage: AUTO falls back, an explicit request fails loudly
     ps = synthetic.wind_mixing_problem(8, n_frames=3, smooth_NN=True)
     with colnde.ColumnNDE(ps.cfg, 8) as nde:

@@ -85,3 +85,18 @@ for c in which:
             kt = ms / nl * 1e-3
             print("ADAM step: %d parameters: kernel %.4f ms -> %.0f GB/s (28 B/parameter); wall %.4f ms" % (n, kt * 1e3, n * 28 / kt / 1e9, dt * 1e3), flush=True)
         nde.close()
+    if c == "3":      # latency point: 8 simulations x 32 levels x 289 frames, fwd+adjoint (BASELINE configs[2] as written), both engines
+        for eng in (2, 1):
+            p = synthetic.wind_mixing_problem(8)
+            nde = colnde.ColumnNDE(p.cfg, 8, engine=eng)
+            x0, bcs, w, wt = (torch.from_numpy(a).to(dev) for a in (p.x0, p.bcs, p.weights, p.weights_truth))
+            nde.set_problem(x0, bcs)
+            truth = nde.forward(wt)
+            nde.set_problem(x0, bcs, truth)
+            out = torch.empty(p.cfg.n_params + 8, device=dev)
+            nde.set_profiling(True)
+            dt = timed(lambda: nde.loss_grad(w, [1, 1, 1, 5e-3, 5e-3, 5e-3], out=out), n=3)
+            kt = {k: round(nde.kernel_time(k)[0] / max(nde.kernel_time(k)[1], 1), 2) for k in ("forward", "adjoint", "dw1", "reduce")}
+            print("config 3: 8 columns x 576 RK4 steps fwd+adjoint, engine %d: %.1f ms per iteration -> %.1f k column-timesteps/s %s"
+                  % (nde.engine, dt * 1e3, 8 * p.cfg.n_steps / dt / 1e3, kt), flush=True)
+            nde.close()
