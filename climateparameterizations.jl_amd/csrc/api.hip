@@ -52,7 +52,7 @@ struct colnde_handle {
     bool fwd_wlds = false;
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
     float* d_wimg = nullptr;
-    float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_xscr = nullptr, *d_rt_tapez = nullptr;
+    float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_tapez = nullptr;
     bool rt_fwd32 = false;         // COLNDE_RT_FWD=32 at creation: the 32-column forward kernel (no Z1 tape)
     bool rt_ztape = false;         // layer-1 pre-activations taped by the forward kernel instead of recomputed by the adjoint
     int rt_rows = 0;
@@ -312,7 +312,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     drain_events(h);
-    void* ptrs[] = {h->d_rt_tapez, h->d_rt_xscr, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
+    void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
                     h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -479,7 +479,7 @@ static int rt_plan_tapes(colnde_handle* h) {
     const int n32 = ((h->n_col + 31) / 32) * 32;
     int block = 0;
     for (int pass = 0; pass < 2 && block == 0; pass++) {
-        const size_t per_col = per_col_x + per_col_2 * (want_z ? 2 : 1) + 5 * 96 * sizeof(float);
+        const size_t per_col = per_col_x + per_col_2 * (want_z ? 2 : 1);
         const size_t fit = budget / per_col;
         if (fit >= (size_t)n32) block = n32;
         else if (fit >= 1024) {
@@ -495,7 +495,6 @@ static int rt_plan_tapes(colnde_handle* h) {
     const size_t n1 = rt_tape_floats(block, n_steps), n2 = rt_tape2_floats(block, n_steps);
     hipError_t e = hipMalloc((void**)&h->d_rt_tape, n1 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_tape2, n2 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_xscr, (size_t)rt_n_wtiles(block) * 5 * 3072 * sizeof(float));
     h->rt_ztape = want_z;
     if (e == hipSuccess && h->rt_ztape && hipMalloc((void**)&h->d_rt_tapez, n2 * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
@@ -503,7 +502,7 @@ static int rt_plan_tapes(colnde_handle* h) {
         h->rt_ztape = false;
     }
     if (e != hipSuccess) {
-        for (float** q : {&h->d_rt_tape, &h->d_rt_tape2, &h->d_rt_xscr, &h->d_rt_tapez})      // leave no half-built state behind
+        for (float** q : {&h->d_rt_tape, &h->d_rt_tape2, &h->d_rt_tapez})      // leave no half-built state behind
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         return fail("hipMalloc of the %zu-byte stage tapes failed: %s", (n1 + n2) * sizeof(float), hipGetErrorString(e));
     }
@@ -687,7 +686,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                 Timed tm(h, K_ADJOINT);
                 e = rt_launch_adjoint(h->m, h->d_wimg, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                       h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_rt_tape,
-                                      h->d_rt_tape2, h->d_rt_xscr, h->rt_ztape ? h->d_rt_tapez : nullptr, lw,
+                                      h->d_rt_tape2, h->rt_ztape ? h->d_rt_tapez : nullptr, lw,
                                       h->d_rt_slab + (size_t)(c0 / 32) * stride, nc, h->stream);
                 if (e != hipSuccess) return fail("rt adjoint launch failed: %s", hipGetErrorString(e));
             }

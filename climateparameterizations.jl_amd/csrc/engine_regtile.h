@@ -35,7 +35,7 @@ int rt_n_wtiles(int n_col);
 int rt_dw1_waves(int n_col, int n_steps);
 hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,
                              int substeps, const float* sol, const float* truth, const float* tape, float* tape2,
-                             float* xscr, const float* tapez, const LossWeights& lw, float* slab, int n_col, hipStream_t stream);
+                             const float* tapez, const LossWeights& lw, float* slab, int n_col, hipStream_t stream);
 hipError_t rt_launch_dw1(const DevModel& m, const float* tape, const float* tape2, int n_col, int n_steps, float* slab_rows,
                          hipStream_t stream);
 hipError_t rt_debug_read_stamps(unsigned long long* out8);

@@ -37,29 +37,10 @@ __device__ unsigned long long g_rt_stamps[16];
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define RHO0(r) (((r) & 3) + 8 * ((r) >> 2))
-// Optional "parking" of the flux cotangents / stage cotangents in an L2-resident scratch buffer to free registers.
-// Measured (tools/ab_bench.py, 32,768 columns): park both 126.1 ms, park x̄ only 132.3 ms, park nothing 121.6 ms per adjoint
-// launch, and parking adds 115 GB of scratch traffic: off.
-#ifndef RT_X_AT_TOP
-#define RT_X_AT_TOP 1    // 1: load the stage input at the top of its stage instead of one stage ahead
-#endif
-#ifndef RT_Z_EARLY
-#define RT_Z_EARLY 1
-#endif
-#ifndef RT_Z0_AT_TOP
-#define RT_Z0_AT_TOP 0
-#endif
-#ifndef RT_TOP_FENCE
-#define RT_TOP_FENCE 0
-#endif
+// (Tried and removed, see DESIGN.md §6: "parking" cotangents in an L2-resident scratch buffer to free registers — slower and
+// 115 GB of extra traffic; prefetching the stage input one stage ahead — spilled under exposed waits.)
 #ifndef RT16_WAVES
 #define RT16_WAVES 8      // wavefronts per workgroup of the 16-column forward kernel (two per SIMD)
-#endif
-#ifndef RT_PARK_DO
-#define RT_PARK_DO 0
-#endif
-#ifndef RT_PARK_XB
-#define RT_PARK_XB 0
 #endif
 #ifndef RT_ADJ_CH
 #define RT_ADJ_CH 8       // A-operand prefetch depth (k-steps) of the adjoint kernel's layer-1 chains
@@ -586,7 +567,6 @@ __global__ void __launch_bounds__(256)
 rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ bcs,
                   const float* __restrict__ save_times, int n_save, int substeps, const float* __restrict__ sol,
                   const float* __restrict__ truth, const float* __restrict__ tape, float* __restrict__ tape2,
-                  float* xscr /* [tile][5][3072]: the four stage cotangents of the step in flight + the flux cotangents */,
                   const float* __restrict__ tapez /* layer-1 pre-activations taped by the forward kernel (ZT) */,
                   LossWeights lw, float* __restrict__ slab, int n_col) {
     float* wl = rt_smem;
@@ -624,17 +604,14 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     f32x16 xb[3], X[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) xb[q] = (f32x16)(0.0f);
-#if !RT_PARK_XB
     f32x16 xbs[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) xbs[q] = (f32x16)(0.0f);
-#endif
 #pragma unroll
     for (int e = 0; e < 48; e++) lam[e * 64 + lane] = 0.0f;
 
     const int n_steps = (n_save - 1) * substeps;
     const float* tp = tape + (size_t)tile * n_steps * 4 * 3072 + lane * 4;
-    [[maybe_unused]] float* xs4 = xscr + (size_t)tile * 5 * 3072 + lane * 4;    // RT_PARK_* variants only
     float* tp2 = tape2 + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4;
     const float* tpz = ZT ? tapez + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4 : nullptr;
 
@@ -692,9 +669,6 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 X[q][4 * g] = v[0]; X[q][4 * g + 1] = v[1]; X[q][4 * g + 2] = v[2]; X[q][4 * g + 3] = v[3];
             }
     };
-#if !RT_X_AT_TOP
-    load_x(n_steps - 1, 3);
-#endif
 
     for (int iv = n_save - 2; iv >= 0; iv--) {
         const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
@@ -710,20 +684,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 f32x16 A1n[2], D1n[2];      // net n + 1, in flight under net n's W1^T products (ZT)
 #pragma unroll
                 for (int r = 9; r < 16; r++) { A1[1][r] = 0.0f; D1[1][r] = 0.0f; A1n[1][r] = 0.0f; D1n[1][r] = 0.0f; }
-#if RT_X_AT_TOP
                 load_x(step, st);
-#endif
-#if RT_Z0_AT_TOP
-                if (ZT) load_z1(step, st, 0, A1);
-#endif
-#if RT_TOP_FENCE
-                __builtin_amdgcn_sched_barrier(0);
-#endif
                 // (1) stage cotangent and the physics pullback: dO = cotangent of the NN fluxes, xb = physics part of x̄
-                // (RT_PARK_DO: dO is parked in an L2-resident scratch slot and re-read one net at a time: 32 fewer live registers)
-#if !RT_PARK_DO
                 f32x16 dOk[3];
-#endif
                 {
                     f32x16 kb[3];
 #pragma unroll
@@ -731,42 +694,21 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                         for (int r = 0; r < 16; r++) kb[q][r] = cwl * lam[(q * 16 + r) * 64 + lane] + cwx * xb[q][r];
                     rt_physics_vjp(m, X, kb, h, xb);       // kb now holds dO
-#if RT_PARK_DO
-#pragma unroll
-                    for (int q = 0; q < 3; q++)
-#pragma unroll
-                        for (int g = 0; g < 4; g++) {
-                            const f32x4v v = {kb[q][4 * g], kb[q][4 * g + 1], kb[q][4 * g + 2], kb[q][4 * g + 3]};
-                            *reinterpret_cast<f32x4v*>(xs4 + 4 * 3072 + (q * 4 + g) * 256) = v;
-                        }
-#else
 #pragma unroll
                     for (int q = 0; q < 3; q++) dOk[q] = kb[q];
-#endif
                 }
                 RT_STAMP(0);
                 float* dst = tp2 + ((size_t)step * 4 + st) * RT_TAPE2;
                 // the nets are handled one after the other so that only one net's hidden state is live at a time
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
-#if RT_PARK_DO
-                    f32x16 dOn;
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const f32x4v v = *reinterpret_cast<const f32x4v*>(xs4 + 4 * 3072 + (n * 4 + g) * 256);
-                        dOn[4 * g] = v[0]; dOn[4 * g + 1] = v[1]; dOn[4 * g + 2] = v[2]; dOn[4 * g + 3] = v[3];
-                    }
-#else
                     const f32x16 dOn = dOk[n];
-#endif
                     // (2) hidden layer 1 of net n: activation A1 (feeds layer 2 and the dW2 products) and derivative D1 (feeds dZ1),
                     //     evaluated once, together.  With the Z1 tape (ZT) nets 1 and 2 arrive already activated: their taped
                     //     pre-activations were fetched and activated in the shadow of the previous net's W1^T products (6).
                     if (ZT) {
                         if (n == 0) {
-#if !RT_Z0_AT_TOP
                             load_z1(step, st, 0, A1);
-#endif
 #pragma unroll
                             for (int G = 0; G < 25; G++) rt_act_pair_at<ACT>(A1, D1, G);
                         }
@@ -824,9 +766,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     }
                     RT_STAMP(3);
                     // fetch net n + 1's taped pre-activations now: dW2, W2^T and the first W1^T chunk cover the HBM latency
-#if RT_Z_EARLY
                     if (ZT && n < 2) load_z1(step, st, n + 1, A1n);
-#endif
                     // (4) layer 2: weight/bias gradient
                     {
                         const f32x16 TA = rt_transpose(tb, Z2, wbase, rbase);
@@ -854,17 +794,6 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         *reinterpret_cast<f32x4v*>(dst + (n * 7 + grp) * 256) = v;
                     }
                     RT_STAMP(5);
-#if !RT_X_AT_TOP
-                    if (n == 2 && step * 4 + st > 0) {
-                        // fetch the next stage's input under the last W1^T products; X has been dead since the physics
-                        // pullback (ZT) / net 2's layer-1 chains
-                        const int qn = step * 4 + st - 1;
-                        load_x(qn >> 2, qn & 3);
-                    }
-#endif
-#if !RT_Z_EARLY
-                    if (ZT && n < 2) load_z1(step, st, n + 1, A1n);
-#endif
                     // (6) x̄ += W1_n^T dZ1_n
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
@@ -887,42 +816,16 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     }
                 }
                 RT_STAMP(6);
-#if RT_PARK_XB
-                // park this stage's x̄ in an L2-resident scratch slot (keeps 48 registers free); the four slots of the step
-                // are summed into λ below
-                {
-                    float* slot = xs4 + (size_t)st * 3072;
-#pragma unroll
-                    for (int q = 0; q < 3; q++)
-#pragma unroll
-                        for (int g = 0; g < 4; g++) {
-                            const f32x4v v = {xb[q][4 * g], xb[q][4 * g + 1], xb[q][4 * g + 2], xb[q][4 * g + 3]};
-                            *reinterpret_cast<f32x4v*>(slot + (q * 4 + g) * 256) = v;
-                        }
-                }
-#else
 #pragma unroll
                 for (int q = 0; q < 3; q++) xbs[q] += xb[q];
-#endif
             }
             // λ_n = λ_{n+1} + x̄_1 + x̄_2 + x̄_3 + x̄_4
-#if RT_PARK_XB
-#pragma unroll
-            for (int grp = 0; grp < 12; grp++) {
-                f32x4v acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int st = 0; st < 4; st++) acc4 += *reinterpret_cast<const f32x4v*>(xs4 + (size_t)st * 3072 + grp * 256);
-#pragma unroll
-                for (int e = 0; e < 4; e++) lam[(grp * 4 + e) * 64 + lane] += acc4[e];
-            }
-#else
 #pragma unroll
             for (int q = 0; q < 3; q++) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) lam[(q * 16 + r) * 64 + lane] += xbs[q][r];
                 xbs[q] = (f32x16)(0.0f);
             }
-#endif
         }
     }
 
@@ -1449,16 +1352,16 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
 
 hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,
                              int substeps, const float* sol, const float* truth, const float* tape, float* tape2,
-                             float* xscr, const float* tapez, const LossWeights& lw, float* slab, int n_col, hipStream_t stream) {
+                             const float* tapez, const LossWeights& lw, float* slab, int n_col, hipStream_t stream) {
     const int n_wtiles = rt_n_wtiles(n_col);
     const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
     const size_t lds = rt_adjoint_lds_bytes();
 #define RT_ADJ(A)                                                                                                             \
     do {                                                                                                                      \
         if (tapez) hipLaunchKernelGGL((rt_adjoint_kernel<A, true>), grid, block, lds, stream, m, wimg, bcs, save_times, n_save, \
-                                      substeps, sol, truth, tape, tape2, xscr, tapez, lw, slab, n_col);                      \
+                                      substeps, sol, truth, tape, tape2, tapez, lw, slab, n_col);                      \
         else hipLaunchKernelGGL((rt_adjoint_kernel<A, false>), grid, block, lds, stream, m, wimg, bcs, save_times, n_save,    \
-                                substeps, sol, truth, tape, tape2, xscr, tapez, lw, slab, n_col);                            \
+                                substeps, sol, truth, tape, tape2, tapez, lw, slab, n_col);                            \
     } while (0)
     switch (m.acts[0]) {
         case COLNDE_ACT_IDENTITY: RT_ADJ(COLNDE_ACT_IDENTITY); break;
