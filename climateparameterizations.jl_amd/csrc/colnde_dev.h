@@ -52,13 +52,19 @@ struct DevModel {
 __device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 // ---- activations (NNlib 0.7: relu, mish, swish, tanh, leakyrelu) ------------------------------------
-__device__ __forceinline__ float dev_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dev_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // mish(x) = x tanh(softplus(x));  tanh(log(1+e^x)) = ((1+e^x)^2 - 1)/((1+e^x)^2 + 1) = n/(n+2), n = e^x (e^x + 2)
 __device__ __forceinline__ float dev_mish_t(float x) {
     float e = __expf(fminf(x, 20.0f));
     float n = e * (e + 2.0f);
-    return n / (n + 2.0f);
+    return fast_div(n, n + 2.0f);
+}
+
+// tanh(z) = 1 - 2 / (1 + e^{2z}) on the exponential and reciprocal units
+__device__ __forceinline__ float dev_tanh(float z) {
+    const float e = __expf(2.0f * fminf(fmaxf(z, -15.0f), 15.0f));
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 __device__ __forceinline__ float dev_act(int a, float z) {
@@ -66,7 +72,7 @@ __device__ __forceinline__ float dev_act(int a, float z) {
         case COLNDE_ACT_RELU: return fmaxf(z, 0.0f);
         case COLNDE_ACT_MISH: return z * dev_mish_t(z);
         case COLNDE_ACT_SWISH: return z * dev_sigmoid(z);
-        case COLNDE_ACT_TANH: return tanhf(z);
+        case COLNDE_ACT_TANH: return dev_tanh(z);
         case COLNDE_ACT_LEAKYRELU: return z > 0.0f ? z : 0.01f * z;
         default: return z;
     }
@@ -75,9 +81,12 @@ __device__ __forceinline__ float dev_act(int a, float z) {
 __device__ __forceinline__ float dev_act_grad(int a, float z) {
     switch (a) {
         case COLNDE_ACT_RELU: return z > 0.0f ? 1.0f : 0.0f;
-        case COLNDE_ACT_MISH: { float t = dev_mish_t(z); return t + z * (1.0f - t * t) * dev_sigmoid(z); }
+        case COLNDE_ACT_MISH: {      // e w / (n + 2)^2, w = 4 (z + 1) + 4 e^2 + e^3 + e (4 z + 6): one exponential, one reciprocal
+            const float e = __expf(fminf(z, 20.0f)), n = e * (e + 2.0f), r = __builtin_amdgcn_rcpf(n + 2.0f), p = 4.0f * z + 4.0f;
+            return (e * r) * (fmaf(e, (n + 2.0f * e) + (p + 2.0f), p) * r);
+        }
         case COLNDE_ACT_SWISH: { float s = dev_sigmoid(z); return s + z * s * (1.0f - s); }
-        case COLNDE_ACT_TANH: { float t = tanhf(z); return 1.0f - t * t; }
+        case COLNDE_ACT_TANH: { float t = dev_tanh(z); return 1.0f - t * t; }
         case COLNDE_ACT_LEAKYRELU: return z > 0.0f ? 1.0f : 0.01f;
         default: return 1.0f;
     }

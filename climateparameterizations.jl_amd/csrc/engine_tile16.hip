@@ -132,11 +132,13 @@ __device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& p
             const int net = job / nmt, mt = job - net * nmt;
             const float* bl = w + (size_t)net * m.net_size + m.b_off[l];
             const float* in = (l == 0) ? xs + c * m.ld_x : A + (net * CT + c) * m.ld_a + m.act_off[l - 1];
-            f32x4 acc;
+            // the bias is fetched now and added after the chain, so that its load latency hides under the MFMAs
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            float bq[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = mt * 16 + 4 * kq + r;
-                acc[r] = row < no ? bl[row] : 0.0f;
+                bq[r] = bl[min(row, no - 1)];
             }
             FINE(1);
             if (WLDS) {
@@ -152,8 +154,9 @@ __device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& p
             for (int r = 0; r < 4; r++) {
                 const int row = mt * 16 + 4 * kq + r;
                 if (row < no) {
-                    if (STORE_Z) Z[ro + row] = acc[r];
-                    A[ro + row] = dev_act(act, acc[r]);
+                    const float z = acc[r] + bq[r];
+                    if (STORE_Z) Z[ro + row] = z;
+                    A[ro + row] = dev_act(act, z);
                 }
             }
             FINE(3);
