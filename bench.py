@@ -177,7 +177,8 @@ def main():
             except Exception:
                 traffic = None
         regtile = nde.engine == 2
-        ztape = regtile and os.environ.get("COLNDE_RT_ZTAPE", "1") != "0" and os.environ.get("COLNDE_RT_FWD", "16") != "32"
+        plan = nde.plan()
+        ztape = regtile and plan["z1_taped"]
         adj_flop = (ADJ_FLOP_REGTILE if ztape else ADJ_FLOP_REGTILE_NOZ) if regtile else ADJ_FLOP_TILE16
         dw1_s = ms_dw1 / max(n_dw1, 1) * 1e-3
         achieved_tf = adj_flop * units_per_launch / adj_s / 1e12
@@ -216,6 +217,7 @@ def main():
                                "achieved": (DW1_FLOP_PER_COLSTEP * units_per_launch / dw1_s / 1e12) if dw1_s > 0 else None,
                                "unit": "TFLOP/s"},
                 "engine": {1: "tile16", 2: "regtile"}.get(nde.engine, str(nde.engine)),
+                "plan": plan,
             },
             "loss_total": float(res[nde.n_params + 6]),
             "grad_l2": float(np.linalg.norm(res[:nde.n_params])),

@@ -40,6 +40,7 @@ SYMBOLS = [
     ("colnde_coarse_grain_dev", ctypes.c_int, [_V, _V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _V]),
     ("colnde_zscore_stats_dev", ctypes.c_int, [_V, _V, ctypes.c_int64, _V]),
     ("colnde_scale_dev", ctypes.c_int, [_V, _V, ctypes.c_int64, _V, _V]),
+    ("colnde_plan", ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int)]),
     ("colnde_set_profiling", ctypes.c_int, [_V, ctypes.c_int]),
     ("colnde_kernel_time", ctypes.c_int, [_V, ctypes.c_int, _F, ctypes.POINTER(ctypes.c_int)]),
     ("colnde_reset_kernel_times", ctypes.c_int, [_V]),

@@ -893,6 +893,21 @@ extern "C" int colnde_scale_dev(colnde_handle* h, const float* d_x, int64_t coun
     return 0;
 }
 
+extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
+    if (!h || !info) return fail("null argument");
+    for (int i = 0; i < 8; i++) info[i] = 0;
+    info[0] = h->use_rt ? COLNDE_ENGINE_MFMA : COLNDE_ENGINE_GENERIC;
+    if (h->use_rt) {
+        info[1] = h->rt_block;
+        info[2] = h->rt_nblocks;
+        info[3] = h->rt_ztape ? 1 : 0;
+    } else {
+        info[4] = h->t16_dwtape == 1 ? 1 : 0;
+        info[5] = h->t16_dwtape == 1 ? h->dw_slices : 0;
+    }
+    return 0;
+}
+
 // Diagnostic builds (-DCOLNDE_STAMPS) only; not part of include/colnde.h.  Returns zeros in the shipped library.
 extern "C" int colnde_debug_stamps(colnde_handle* h, unsigned long long* out16) {
     if (!h || !out16) return fail("null argument");

@@ -89,6 +89,13 @@ class ColumnNDE:
         _lib.check(self._L.colnde_kernel_time(self._h, KERNEL_IDS[which], ctypes.byref(ms), ctypes.byref(n)))
         return float(ms.value), int(n.value)
 
+    def plan(self):
+        """How the gradient path runs (valid after the first loss_grad): engine, column blocks, which tapes are in use."""
+        info = (ctypes.c_int * 8)()
+        _lib.check(self._L.colnde_plan(self._h, info))
+        return dict(engine=info[0], block_columns=info[1], n_blocks=info[2], z1_taped=bool(info[3]),
+                    dw_taped=bool(info[4]), dw_slices=info[5])
+
     def reset_kernel_times(self):
         _lib.check(self._L.colnde_reset_kernel_times(self._h))
 

@@ -201,3 +201,21 @@ def test_config4_free_convection_64_levels_properties():
             parts.append(sh.loss_grad(p.weights, sc))
     assert np.isclose(parts[0][0] + parts[1][0], tot, rtol=1e-4)
     assert _rel(parts[0][2] + parts[1][2], grad.astype(np.float64)) < 1e-4
+
+
+def test_plan_reports_engine_and_tapes():
+    from colnde.nde import ENGINE_REGTILE, ENGINE_TILE16
+    p = synthetic.wind_mixing_problem(40, n_frames=3)
+    for eng, key in ((ENGINE_REGTILE, "z1_taped"), (ENGINE_TILE16, None)):
+        with colnde.ColumnNDE(p.cfg, 40, engine=eng) as nde:
+            nde.set_problem(p.x0, p.bcs)
+            truth = nde.forward(p.weights_truth)
+            nde.set_problem(p.x0, p.bcs, truth)
+            assert nde.plan()["n_blocks"] == 0                      # nothing planned before the first gradient
+            nde.loss_grad(p.weights, [1, 1, 1, 5e-3, 5e-3, 5e-3])
+            pl = nde.plan()
+            assert pl["engine"] == eng
+            if eng == ENGINE_REGTILE:
+                assert pl["n_blocks"] == 1 and pl["block_columns"] == 64 and pl["z1_taped"]
+            else:
+                assert not pl["dw_taped"]                              # 108 gradient tiles: accumulated in registers
