@@ -1081,15 +1081,25 @@ hipError_t launch_dw_gemm(const float* dwtape, size_t n_records, int row_floats,
     return hipGetLastError();
 }
 
-// grad[p] = Σ_tiles slab[tile][p] in a fixed order (deterministic); the 6 raw sums become scaled mean terms
-__global__ void reduce_kernel(const float* __restrict__ slab, int n_tiles, int n_params, int stride, LossWeights lw,
-                              float* __restrict__ out /* [n_params + 8] */) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_params + 6) return;
+// grad[p] = Σ_rows slab[row][p] in a fixed order (deterministic): 64 parameters x 16 row lanes per workgroup, lane ry sums
+// rows ry, ry + 16, ..., then the 16 partial sums are added in order; the 6 raw sums become scaled mean terms
+__global__ void __launch_bounds__(1024) reduce_kernel(const float* __restrict__ slab, int n_tiles, int n_params, int stride, LossWeights lw,
+                                                      float* __restrict__ out /* [n_params + 8] */) {
+    __shared__ float part[16][65];
+    const int px = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + px;
     float s = 0.0f;
-    for (int t = 0; t < n_tiles; t++) s += slab[(size_t)t * stride + p];
-    if (p >= n_params) s *= lw.w[p - n_params];
-    out[p] = s;
+    if (p < n_params + 6)
+        for (int t = ry; t < n_tiles; t += 16) s += slab[(size_t)t * stride + p];
+    part[ry][px] = s;
+    __syncthreads();
+    if (ry == 0 && p < n_params + 6) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) tot += part[q][px];
+        if (p >= n_params) tot *= lw.w[p - n_params];
+        out[p] = tot;
+    }
 }
 
 __global__ void finish_loss_kernel(float* __restrict__ out8) {
@@ -1237,7 +1247,7 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
 
 hipError_t launch_reduce(const float* slab, int n_tiles, int n_params, int stride, const LossWeights& lw, float* out,
                          hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_kernel, dim3((n_params + 6 + 255) / 256), dim3(256), 0, stream, slab, n_tiles, n_params, stride, lw, out);
+    hipLaunchKernelGGL(reduce_kernel, dim3((n_params + 6 + 63) / 64), dim3(1024), 0, stream, slab, n_tiles, n_params, stride, lw, out);
     hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(64), 0, stream, out + n_params);
     return hipGetLastError();
 }
