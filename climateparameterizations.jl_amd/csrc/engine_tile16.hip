@@ -1031,6 +1031,7 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
         // features whose products are never stored) so that the operand reads of later k-steps pipeline under the MFMAs
 #pragma unroll
         for (int q = 0; q < MAXM; q++) {
+            if (mc[q].ni_rem == 0) continue;          // empty slot of this wave (wave-uniform)
 #pragma unroll
             for (int s = 0; s < 8; s++) {
                 const float* row = rec + 2 * s * R;

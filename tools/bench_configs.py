@@ -32,9 +32,10 @@ for c in which:
         cs = 4096 * p.cfg.n_steps
         print("config 2: forward 4096 columns: %.2f ms -> %.1f M column-timesteps/s, %.1f TFLOP/s (engine %d)" % (dt * 1e3, cs / dt / 1e6, cs * 154080 / dt / 1e12, nde.engine), flush=True)
         nde.close()
-    if c in ("4", "4ca", "4s"):   # free convection, 64 levels, 64-256-256-63 relu, 129 save points; 16,384 columns = one GPU's shard of 65,536
+    if c in ("4", "4ca", "4s", "4n32"):   # free convection, 64 levels (4n32: the 32-level 32-128-128-31 network), 64-256-256-63 relu, 129 save points; 16,384 columns = one GPU's shard of 65,536
         ncol = 4096 if c == "4s" else 16384
-        p = synthetic.free_convection_problem(ncol, Nz=64, convective_adjustment=(c == "4ca"))
+        Nzc = 32 if c == "4n32" else 64
+        p = synthetic.free_convection_problem(ncol, Nz=Nzc, convective_adjustment=(c == "4ca"))
         nde = colnde.ColumnNDE(p.cfg, ncol)
         x0, bcs, w, wt = (torch.from_numpy(a).to(dev) for a in (p.x0, p.bcs, p.weights, p.weights_truth))
         nde.set_problem(x0, bcs)
@@ -45,10 +46,10 @@ for c in which:
         nde.set_profiling(True)
         dt = timed(lambda: nde.loss_grad(w, sc, out=out), n=2)
         cs = ncol * p.cfg.n_steps
-        mlp = 2 * (64 * 256 + 256 * 256 + 256 * 63)
-        kt = {k: round(nde.kernel_time(k)[0] / max(nde.kernel_time(k)[1], 1), 2) for k in ("forward", "adjoint", "reduce")}
-        print("config %s: fwd+adjoint %d columns x 64 levels x %d RK4 steps: %.1f ms -> %.2f M column-timesteps/s, %.1f TFLOP/s at 3x forward flops (engine %d) %s"
-              % (c, ncol, p.cfg.n_steps, dt * 1e3, cs / dt / 1e6, cs * 4 * 3 * mlp / dt / 1e12, nde.engine, kt), flush=True)
+        mlp = 2 * (Nzc * 4 * Nzc + 16 * Nzc * Nzc + 4 * Nzc * (Nzc - 1))
+        kt = {k: round(nde.kernel_time(k)[0] / max(nde.kernel_time(k)[1], 1), 2) for k in ("forward", "adjoint", "dw1", "reduce")}
+        print("config %s: fwd+adjoint %d columns x %d levels x %d RK4 steps: %.1f ms -> %.2f M column-timesteps/s, %.1f TFLOP/s at 3x forward flops (engine %d) %s"
+              % (c, ncol, Nzc, p.cfg.n_steps, dt * 1e3, cs / dt / 1e6, cs * 4 * 3 * mlp / dt / 1e12, nde.engine, kt), flush=True)
         nde.close()
     if c == "5":      # inference forcing, 256 x 256 columns x 32 levels, 32-128-128-31
         cfg, T, tf, w = synthetic.inference_problem(256, 256)
