@@ -66,6 +66,7 @@ struct colnde_handle {
     // tile16 taped-dW mode (networks whose weight-gradient tiles overflow the register file)
     int t16_dwtape = -1;            // -1 undecided, 0 off, 1 on
     float* d_dwtape = nullptr;
+    float* d_t16_ztape = nullptr;   // taped mode: hidden pre-activations written by the forward kernel (the adjoint skips its forward GEMMs)
     DwMacro* d_macros = nullptr;
     int n_macros = 0, dw_slices = 0, t16_rows = 0;
     int *d_bias_zoff = nullptr, *d_bias_goff = nullptr;
@@ -313,7 +314,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     (void)hipSetDevice(h->device);
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
-                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros};
+                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -541,7 +542,7 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
     Timed tm(h, K_FORWARD);
     hipError_t e = launch_forward(h->m, h->pk, d_weights, h->d_wf, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save,
                                   h->cfg.substeps, d_sol, with_tape ? h->d_tape : nullptr, h->n_col, h->fwd_threads,
-                                  h->fwd_wlds, h->lds_fwd_solve, h->stream);
+                                  h->fwd_wlds, h->lds_fwd_solve, h->stream, with_tape ? h->d_t16_ztape : nullptr);
     if (e != hipSuccess) return fail("forward launch failed: %s", hipGetErrorString(e));
     return 0;
 }
@@ -652,6 +653,18 @@ static int t16_plan_dwtape(colnde_handle* h) {
         return 0;
     }
     h->t16_dwtape = 1;
+    // optional: tape the hidden pre-activations too (COLNDE_T16_ZTAPE=0 disables; dropped when it does not fit)
+    const char* ezt = getenv("COLNDE_T16_ZTAPE");
+    if (!(ezt && atoi(ezt) == 0)) {
+        const size_t zbytes = n_rec * CT * t16_ztape_col_floats(m) * sizeof(float);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+            zbytes + (size_t)h->n_tiles * n_steps * 4 * CT * m.ns * sizeof(float) + ((size_t)2 << 30) <= free_b &&
+            hipMalloc((void**)&h->d_t16_ztape, zbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_t16_ztape = nullptr;
+        }
+    }
     return 0;
 }
 
@@ -717,7 +730,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
             hipError_t e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
                                           h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol, h->d_truth, h->d_tape,
                                           lw, h->d_slab, h->n_col, g, (MODEL_FLOATS + lds_floats_adjoint(h->m)) * sizeof(float), h->stream,
-                                          h->d_dwtape);
+                                          h->d_dwtape, h->d_t16_ztape);
             if (e != hipSuccess) return fail("adjoint (taped dW) launch failed: %s", hipGetErrorString(e));
         }
         {

@@ -30,14 +30,16 @@ hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, con
                       const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x0,
                           const float* bcs, const float* save_times, int n_save, int substeps, float* sol, float* tape,
-                          int n_col, int nthreads, bool wlds, size_t lds_bytes, hipStream_t stream);
+                          int n_col, int nthreads, bool wlds, size_t lds_bytes, hipStream_t stream, float* ztape = nullptr);
 hipError_t launch_loss(const DevModel& m, const float* sol, const float* truth, int n_save, int n_col, float* partial,
                        int n_blocks, hipStream_t stream);
 hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* wb,
                           const TileDesc* tiles, const int* bias_zoff, const int* bias_goff, const float* bcs,
                           const float* save_times, int n_save, int substeps, const float* sol, const float* truth,
                           const float* tape, const LossWeights& lw, float* slab, int n_col, const AdjointGeom& geo,
-                          size_t lds_bytes, hipStream_t stream, float* dwtape = nullptr);
+                          size_t lds_bytes, hipStream_t stream, float* dwtape = nullptr, const float* ztape = nullptr);
+// hidden pre-activation tape of the taped-dW mode: floats per column
+static inline size_t t16_ztape_col_floats(const DevModel& m) { return (size_t)((m.n_nets * m.act_off[m.n_layers - 1] + 3) & ~3); }
 // taped-dW mode (dwtape != nullptr above): floats per 16-column tile and stage, and the contraction kernel
 static inline int dwtape_ns4(const DevModel& m) { return (m.ns + 3) & ~3; }
 static inline int dwtape_act4(const DevModel& m) { return (m.act_total + 3) & ~3; }

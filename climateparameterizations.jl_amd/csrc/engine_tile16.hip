@@ -120,7 +120,7 @@ __global__ void pack_weights_kernel(DevModel m, PackInfo pk, const float* __rest
 template <bool STORE_Z, bool WLDS>
 __device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& pk, const float* w,
                                             const float* __restrict__ wf, const float* xs, float* Z, float* A,
-                                            int wave, int nwaves, int lane) {
+                                            int wave, int nwaves, int lane, float* __restrict__ zrec = nullptr, int zld = 0) {
     const int c = lane & 15, kq = lane >> 4;
     FINE_BEGIN();
     for (int l = 0; l < m.n_layers; l++) {
@@ -157,6 +157,8 @@ __device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& p
                     const float z = acc[r] + bq[r];
                     if (STORE_Z) Z[ro + row] = z;
                     A[ro + row] = dev_act(act, z);
+                    // hidden-layer pre-activations taped for the adjoint (row [c][net][hidden features], stride zld)
+                    if (zrec && l + 1 < m.n_layers) zrec[c * zld + net * m.act_off[m.n_layers - 1] + m.act_off[l] + row] = z;
                 }
             }
             FINE(3);
@@ -531,12 +533,13 @@ template <bool WLDS, int NTH>
 __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                                const float* __restrict__ x0, const float* __restrict__ bcs,
                                const float* __restrict__ save_times, int n_save, int substeps,
-                               float* __restrict__ sol, float* __restrict__ tape, int n_col) {
+                               float* __restrict__ sol, float* __restrict__ tape, int n_col, float* __restrict__ ztape) {
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
     float* wl = smem;                                   // raw weights (WLDS) + 128 floats of zero padding
     float* xs = smem + (WLDS ? ((m.n_params + 3) & ~3) + 128 : 0);
     float* kk = xs + CT * m.ld_x;
+    const int zld = (m.n_nets * m.act_off[m.n_layers - 1] + 3) & ~3;      // floats per column of the hidden pre-activation tape
     float* A = kk + CT * m.ld_x;
     float* F = A + m.n_nets * CT * m.ld_a;
     float* Ri_l = F + 3 * CT * m.ld_f;
@@ -591,7 +594,8 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
                     }
                 }
                 __syncthreads();
-                mlp_forward<false, WLDS>(m, pk, wsrc, wf, xs, nullptr, A, wave, nwaves, lane);
+                mlp_forward<false, WLDS>(m, pk, wsrc, wf, xs, nullptr, A, wave, nwaves, lane,
+                                         ztape ? ztape + ((size_t)blockIdx.x * n_steps * 4 + (size_t)step * 4 + st) * ((size_t)CT * zld) : nullptr, zld);
                 physics_forward(m, xs, A, F, Ri_l, bcl, ts + ca * dt, kk, tid, nth);
             }
             const bool save = (s == substeps - 1);
@@ -682,7 +686,7 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                const int* __restrict__ bias_goff, const float* __restrict__ bcs, const float* __restrict__ save_times,
                int n_save, int substeps, const float* __restrict__ sol, const float* __restrict__ truth,
                const float* __restrict__ tape, LossWeights lw, float* __restrict__ slab /* [grid][n_params+8] */,
-               int n_col, float* __restrict__ dwtape = nullptr) {
+               int n_col, float* __restrict__ dwtape = nullptr, const float* __restrict__ ztape = nullptr) {
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
     // the model description lives in LDS: per-layer fields indexed with a runtime layer number would otherwise be
@@ -820,7 +824,23 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                 }
                 __syncthreads();
                 STAMP(0);
-                mlp_forward<true, WLDS>(m, pk, wsrc, wf, xs, Z, A, wave, nwaves, lane);
+                if (TAPEDW && ztape) {
+                    // hidden-layer pre-activations taped by the forward kernel: Z and A = act(Z) without the forward GEMMs (the output
+                    // layer enters the pullback linearly: its values are not needed)
+                    const int hid = m.act_off[m.n_layers - 1], zld = (m.n_nets * hid + 3) & ~3;
+                    const float* zr = ztape + ((size_t)blockIdx.x * n_steps * 4 + (size_t)step * 4 + st) * ((size_t)CT * zld);
+                    for (int c = wave; c < CT; c += nwaves)
+                        for (int net = 0; net < m.n_nets; net++)
+                            for (int o = lane; o < hid; o += 64) {
+                                const float z = zr[c * zld + net * hid + o];
+                                int l = 0;
+                                while (o >= m.act_off[l + 1]) l++;
+                                Z[(net * CT + c) * m.ld_a + o] = z;
+                                A[(net * CT + c) * m.ld_a + o] = dev_act(m.acts[l], z);
+                            }
+                    __syncthreads();
+                } else
+                    mlp_forward<true, WLDS>(m, pk, wsrc, wf, xs, Z, A, wave, nwaves, lane);
                 STAMP(1);
                 physics_vjp(m, xs, dbar, Z, xb, gb, Ri_l, Rib_l, tid, nth);
                 STAMP(2);
@@ -1194,11 +1214,11 @@ hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, con
 
 hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x0,
                           const float* bcs, const float* save_times, int n_save, int substeps, float* sol, float* tape,
-                          int n_col, int nthreads, bool wlds, size_t lds_bytes, hipStream_t stream) {
+                          int n_col, int nthreads, bool wlds, size_t lds_bytes, hipStream_t stream, float* ztape) {
     const dim3 grid((n_col + CT - 1) / CT);
 #define LAUNCH_FWD(WL, NT)                                                                                           \
     hipLaunchKernelGGL((forward_kernel<WL, NT>), grid, dim3(NT), lds_bytes, stream, m, pk, w, wf, x0, bcs, save_times, \
-                       n_save, substeps, sol, tape, n_col)
+                       n_save, substeps, sol, tape, n_col, ztape)
     if (wlds && nthreads == 512) LAUNCH_FWD(true, 512);
     else if (wlds && nthreads == 256) LAUNCH_FWD(true, 256);
     else if (!wlds && nthreads == 512) LAUNCH_FWD(false, 512);
@@ -1217,7 +1237,7 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
                           const TileDesc* tiles, const int* bias_zoff, const int* bias_goff, const float* bcs,
                           const float* save_times, int n_save, int substeps, const float* sol, const float* truth,
                           const float* tape, const LossWeights& lw, float* slab, int n_col, const AdjointGeom& geo,
-                          size_t lds_bytes, hipStream_t stream, float* dwtape) {
+                          size_t lds_bytes, hipStream_t stream, float* dwtape, const float* ztape) {
     const int n_tiles = (n_col + CT - 1) / CT;
     if (dwtape) {
         // 1,024 threads (four waves per SIMD, 101 VGPRs) hide the L2 latency of the streamed weights better than 512:
@@ -1226,13 +1246,13 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
         const int nth_env = et ? atoi(et) : 1024;
         if (nth_env == 1024 && CT * m.ns <= 2 * 1024)
             hipLaunchKernelGGL((adjoint_kernel<1, 1024, 2, false, true>), dim3(n_tiles), dim3(1024), lds_bytes, stream, m, pk, w, wf, wb,
-                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape);
+                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape, ztape);
         else if (CT * m.ns <= 3 * 512)
             hipLaunchKernelGGL((adjoint_kernel<1, 512, 3, false, true>), dim3(n_tiles), dim3(512), lds_bytes, stream, m, pk, w, wf, wb,
-                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape);
+                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape, ztape);
         else if (CT * m.ns <= 6 * 512)
             hipLaunchKernelGGL((adjoint_kernel<1, 512, 6, false, true>), dim3(n_tiles), dim3(512), lds_bytes, stream, m, pk, w, wf, wb,
-                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape);
+                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape, ztape);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
