@@ -66,7 +66,7 @@ def test_free_convection(Nz, ca):
     assert _rel(grad_g, g) < GRAD_REL
 
 
-@pytest.mark.parametrize("case", ["fc32", "fc64", "fc32_ca", "wind_mixing", "fc64_l2stream", "wind_mixing_l2stream", "fc64_512threads"])
+@pytest.mark.parametrize("case", ["fc32", "fc64", "fc32_ca", "wind_mixing", "fc64_l2stream", "wind_mixing_l2stream", "fc64_512threads", "fc64_noztape"])
 def test_tile16_taped_weight_gradients(case, monkeypatch):
     """tile16 with the layer deltas taped and every dW contracted by the split-K GEMM kernel (the default for 64-256-256-63,
     whose 384 gradient tiles overflow the register file; forced here on the smaller networks too)."""
@@ -75,6 +75,9 @@ def test_tile16_taped_weight_gradients(case, monkeypatch):
     if case.endswith("_l2stream"):                   # the split-K kernel that reads its operands straight from L2 (no LDS staging)
         monkeypatch.setenv("COLNDE_T16_DWLDS", "0")
         case = case[:-len("_l2stream")]
+    if case.endswith("_noztape"):                    # the adjoint recomputes the forward GEMMs instead of reading taped pre-activations
+        monkeypatch.setenv("COLNDE_T16_ZTAPE", "0")
+        case = case[:-len("_noztape")]
     if case.endswith("_512threads"):
         monkeypatch.setenv("COLNDE_T16_TAPE_THREADS", "512")
         case = case[:-len("_512threads")]
