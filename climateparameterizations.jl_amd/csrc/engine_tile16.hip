@@ -829,15 +829,30 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                     // layer enters the pullback linearly: its values are not needed)
                     const int hid = m.act_off[m.n_layers - 1], zld = (m.n_nets * hid + 3) & ~3;
                     const float* zr = ztape + ((size_t)blockIdx.x * n_steps * 4 + (size_t)step * 4 + st) * ((size_t)CT * zld);
+                    // (segments start at multiples of 4 floats: one float4 never straddles two layers; up to four float4 per lane
+                    //  are fetched back to back so that one HBM latency covers them)
+                    const int nq = (m.n_nets * hid) >> 2;                      // float4 items per column
                     for (int c = wave; c < CT; c += nwaves)
-                        for (int net = 0; net < m.n_nets; net++)
-                            for (int o = lane; o < hid; o += 64) {
-                                const float z = zr[c * zld + net * hid + o];
-                                int l = 0;
-                                while (o >= m.act_off[l + 1]) l++;
-                                Z[(net * CT + c) * m.ld_a + o] = z;
-                                A[(net * CT + c) * m.ld_a + o] = dev_act(m.acts[l], z);
+                        for (int q0 = lane; q0 < nq; q0 += 4 * 64) {
+                            float4 v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                                if (q0 + 64 * u < nq) v[u] = *reinterpret_cast<const float4*>(zr + c * zld + 4 * (q0 + 64 * u));
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int q = q0 + 64 * u;
+                                if (q < nq) {
+                                    const int f = 4 * q, net = f / hid, o = f - net * hid;
+                                    int l = 0;
+                                    while (o >= m.act_off[l + 1]) l++;
+                                    const int a = m.acts[l];
+                                    float* zd = Z + (net * CT + c) * m.ld_a + o;
+                                    float* ad = A + (net * CT + c) * m.ld_a + o;
+                                    zd[0] = v[u].x; zd[1] = v[u].y; zd[2] = v[u].z; zd[3] = v[u].w;
+                                    ad[0] = dev_act(a, v[u].x); ad[1] = dev_act(a, v[u].y); ad[2] = dev_act(a, v[u].z); ad[3] = dev_act(a, v[u].w);
+                                }
                             }
+                        }
                     __syncthreads();
                 } else
                     mlp_forward<true, WLDS>(m, pk, wsrc, wf, xs, Z, A, wave, nwaves, lane);
