@@ -150,16 +150,25 @@ __device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& p
             }
             FINE(2);
             const int ro = (net * CT + c) * m.ld_a + m.act_off[l];
+            float zv[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = mt * 16 + 4 * kq + r;
+                zv[r] = acc[r] + bq[r];
                 if (row < no) {
-                    const float z = acc[r] + bq[r];
-                    if (STORE_Z) Z[ro + row] = z;
-                    A[ro + row] = dev_act(act, z);
-                    // hidden-layer pre-activations taped for the adjoint (row [c][net][hidden features], stride zld)
-                    if (zrec && l + 1 < m.n_layers) zrec[c * zld + net * m.act_off[m.n_layers - 1] + m.act_off[l] + row] = z;
+                    if (STORE_Z) Z[ro + row] = zv[r];
+                    A[ro + row] = dev_act(act, zv[r]);
                 }
+            }
+            // hidden-layer pre-activations taped for the adjoint: row [c][net][hidden features] of stride zld; the lane's four
+            // rows are consecutive and 16-byte aligned (every segment starts at a multiple of 4 floats)
+            if (zrec && l + 1 < m.n_layers) {
+                float* zo = zrec + c * zld + net * m.act_off[m.n_layers - 1] + m.act_off[l] + mt * 16 + 4 * kq;
+                if (mt * 16 + 4 * kq + 3 < no) *reinterpret_cast<float4*>(zo) = make_float4(zv[0], zv[1], zv[2], zv[3]);
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (mt * 16 + 4 * kq + r < no) zo[r] = zv[r];
             }
             FINE(3);
         }
