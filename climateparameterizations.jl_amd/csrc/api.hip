@@ -596,14 +596,16 @@ extern "C" int colnde_loss(colnde_handle* h, const float* weights, const float s
     return 0;
 }
 
-// tile16, taped weight gradients: decide once per handle.  On for networks whose 16x16 weight-gradient tiles would spill in
-// adjoint_kernel (more than 256 of them: 64-256-256-63 has 384) when the delta tape fits in the free HBM;
+// tile16, taped weight gradients: decide once per handle.  On when the tapes fit in the free HBM (the in-register adjoint_kernel
+// geometries remain the fallback; 64-256-256-63's 384 gradient tiles spill there);
 // COLNDE_T16_DWTAPE=1 / 0 forces it on / off.
 static int t16_plan_dwtape(colnde_handle* h) {
     if (h->t16_dwtape >= 0) return 0;
     const DevModel& m = h->m;
     const char* ev = getenv("COLNDE_T16_DWTAPE");
-    bool want = ev ? atoi(ev) != 0 : (m.n_tiles > 256 || !h->geo_ok);
+    // default: on whenever the tapes fit — with the hidden pre-activations taped too, the 1,024-thread accumulator-free adjoint beats
+    // the in-register kernels at every size measured (8 columns: 53 vs 64 ms per iteration; 32-128-128-31: 162 vs 198 ms)
+    bool want = ev ? atoi(ev) != 0 : true;
     const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
     const size_t n_rec = (size_t)h->n_tiles * n_steps * 4, R = dwtape_row_floats(m);
     const size_t need = n_rec * CT * R * sizeof(float);

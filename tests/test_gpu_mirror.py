@@ -218,7 +218,7 @@ def test_plan_reports_engine_and_tapes():
             if eng == ENGINE_REGTILE:
                 assert pl["n_blocks"] == 1 and pl["block_columns"] == 64 and pl["z1_taped"]
             else:
-                assert not pl["dw_taped"]                              # 108 gradient tiles: accumulated in registers
+                assert pl["dw_taped"] and pl["dw_slices"] >= 1           # tile16 default: taped deltas + split-K dW GEMM
 
 
 def test_two_engines_agree_at_the_bench_horizon_4096_columns():

@@ -66,12 +66,16 @@ def test_free_convection(Nz, ca):
     assert _rel(grad_g, g) < GRAD_REL
 
 
-@pytest.mark.parametrize("case", ["fc32", "fc64", "fc32_ca", "wind_mixing", "fc64_l2stream", "wind_mixing_l2stream", "fc64_512threads", "fc64_noztape"])
+@pytest.mark.parametrize("case", ["fc32", "fc64", "fc32_ca", "wind_mixing", "fc64_l2stream", "wind_mixing_l2stream", "fc64_512threads", "fc64_noztape",
+                                  "fc32_inregister", "fc64_inregister", "wind_mixing_inregister"])
 def test_tile16_taped_weight_gradients(case, monkeypatch):
-    """tile16 with the layer deltas taped and every dW contracted by the split-K GEMM kernel (the default for 64-256-256-63,
-    whose 384 gradient tiles overflow the register file; forced here on the smaller networks too)."""
+    """tile16's gradient modes: layer deltas and hidden pre-activations taped with every dW contracted by the split-K GEMM kernel
+    (the default), its variants, and the in-register fallback."""
     from colnde.nde import ENGINE_TILE16
     monkeypatch.setenv("COLNDE_T16_DWTAPE", "1")
+    if case.endswith("_inregister"):                 # the fallback when the tapes do not fit: accumulators resident in registers
+        monkeypatch.setenv("COLNDE_T16_DWTAPE", "0")
+        case = case[:-len("_inregister")]
     if case.endswith("_l2stream"):                   # the split-K kernel that reads its operands straight from L2 (no LDS staging)
         monkeypatch.setenv("COLNDE_T16_DWLDS", "0")
         case = case[:-len("_l2stream")]
