@@ -69,6 +69,7 @@ struct colnde_handle {
     float* d_t16_ztape = nullptr;   // taped mode: hidden pre-activations written by the forward kernel (the adjoint skips its forward GEMMs)
     DwMacro* d_macros = nullptr;
     int n_macros = 0, dw_slices = 0, t16_rows = 0;
+    int t16_block = 0, t16_nblocks = 0;   // taped mode: columns per pass (multiple of 16) — the tapes hold one block
     int *d_bias_zoff = nullptr, *d_bias_goff = nullptr;
     bool have_problem = false, have_truth = false;
     bool prof = false;
@@ -524,6 +525,23 @@ static int rt_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int 
     return 0;
 }
 
+// tile16 forward solve of columns [c0, c0 + nc) (c0 a multiple of the 16-column tile); with_tape: into the handle's (block) tapes
+static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape, int c0, int nc) {
+    const size_t ns = h->m.ns;
+    if (with_tape && !h->d_tape) {     // in-register gradient mode: the whole problem's stage tape
+        const size_t n = (size_t)h->n_tiles * (h->cfg.n_save - 1) * h->cfg.substeps * 4 * CT * ns;
+        hipError_t e = hipMalloc((void**)&h->d_tape, n * sizeof(float));
+        if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tape failed: %s", n * sizeof(float), hipGetErrorString(e));
+    }
+    Timed tm(h, K_FORWARD);
+    hipError_t e = launch_forward(h->m, h->pk, d_weights, h->d_wf, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times,
+                                  h->cfg.n_save, h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
+                                  with_tape ? h->d_tape : nullptr, nc, h->fwd_threads, h->fwd_wlds, h->lds_fwd_solve, h->stream,
+                                  with_tape ? h->d_t16_ztape : nullptr);
+    if (e != hipSuccess) return fail("forward launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // ---- forward solve -------------------------------------------------------------------------------------
 static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape) {
     if (!h->have_problem) return fail("colnde_set_problem has not been called");
@@ -534,18 +552,9 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
         return rt_forward_range(h, d_sol, false, 0, h->n_col);
     }
     if (pack(h, d_weights)) return 1;
-    if (with_tape && !h->d_tape) {
-        const size_t n = (size_t)h->n_tiles * (h->cfg.n_save - 1) * h->cfg.substeps * 4 * CT * h->m.ns;
-        hipError_t e = hipMalloc((void**)&h->d_tape, n * sizeof(float));
-        if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tape failed: %s", n * sizeof(float), hipGetErrorString(e));
-    }
-    Timed tm(h, K_FORWARD);
-    hipError_t e = launch_forward(h->m, h->pk, d_weights, h->d_wf, h->d_x0, h->d_bcs, h->d_times, h->cfg.n_save,
-                                  h->cfg.substeps, d_sol, with_tape ? h->d_tape : nullptr, h->n_col, h->fwd_threads,
-                                  h->fwd_wlds, h->lds_fwd_solve, h->stream, with_tape ? h->d_t16_ztape : nullptr);
-    if (e != hipSuccess) return fail("forward launch failed: %s", hipGetErrorString(e));
-    return 0;
+    return t16_forward_range(h, d_weights, d_sol, with_tape, 0, h->n_col);
 }
+
 
 extern "C" int colnde_forward_dev(colnde_handle* h, const float* d_weights, float* d_sol) {
     if (!h) return fail("null handle");
@@ -607,17 +616,36 @@ static int t16_plan_dwtape(colnde_handle* h) {
     // the in-register kernels at every size measured (8 columns: 53 vs 64 ms per iteration; 32-128-128-31: 162 vs 198 ms)
     bool want = ev ? atoi(ev) != 0 : true;
     const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
-    const size_t n_rec = (size_t)h->n_tiles * n_steps * 4, R = dwtape_row_floats(m);
-    const size_t need = n_rec * CT * R * sizeof(float);
+    const size_t R = dwtape_row_floats(m);
     if (want && (size_t)CT * m.ns > 6 * 512) want = false;
     if (want && (MODEL_FLOATS + lds_floats_adjoint(m)) * sizeof(float) > 160 * 1024) want = false;
+    // The tapes hold ONE block of columns (a multiple of the 16-column tile; whole rounds of 4,096 columns = one workgroup per CU when
+    // possible); larger problems run forward -> adjoint -> dW GEMM block after block.  COLNDE_T16_BLOCK=<columns> forces a size.
+    const size_t per_col = (size_t)n_steps * 4 * (R + t16_ztape_col_floats(m) + m.ns) * sizeof(float);
+    const int n16 = h->n_tiles * CT;
+    int block = 0;
     if (want) {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const size_t other = (size_t)h->n_tiles * n_steps * 4 * CT * m.ns * sizeof(float) + ((size_t)2 << 30);   // stage tape + margin
-        if (need + other > free_b) want = false;
+        const size_t margin = ((size_t)3 << 30) + (size_t)h->n_tiles * (m.n_params + 8) * sizeof(float);
+        const size_t fit = free_b > margin ? (free_b - margin) / per_col : 0;
+        if (fit >= (size_t)n16) block = n16;
+        else if (fit >= CT) {
+            const int nb = (int)(((size_t)n16 + fit - 1) / fit);
+            block = ((n16 + nb - 1) / nb + CT - 1) / CT * CT;
+            if (block >= 4096) block = (block + 4095) / 4096 * 4096;
+            while ((size_t)block > fit) block -= block > 4096 ? 4096 : CT;
+        }
+        const char* eb = getenv("COLNDE_T16_BLOCK");
+        if (eb && atoi(eb) >= CT) block = std::min(n16, (atoi(eb) / CT) * CT);
+        if (block <= 0) want = false;
     }
     if (!want) { h->t16_dwtape = 0; return 0; }
+    const int tiles_b = block / CT;
+    const size_t n_rec = (size_t)tiles_b * n_steps * 4;
+    const size_t need = n_rec * CT * R * sizeof(float);
+    h->t16_block = block;
+    h->t16_nblocks = (n16 + block - 1) / block;
     // 64x64 blocks of every layer's weight matrix
     std::vector<DwMacro> mac;
     for (int net = 0; net < m.n_nets; net++)
@@ -642,7 +670,7 @@ static int t16_plan_dwtape(colnde_handle* h) {
     if (dw_gemm_lds_fits((int)R, h->n_macros))       // one workgroup per CU (two records in LDS): two rounds of slices
         slices = std::min<size_t>(512, std::max<size_t>(1, n_rec));
     h->dw_slices = (int)slices;
-    h->t16_rows = h->n_tiles + h->dw_slices;
+    h->t16_rows = h->n_tiles + h->t16_nblocks * h->dw_slices;
     const int stride = m.n_params + 8;
     hipError_t e = hipMalloc((void**)&h->d_dwtape, need);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_macros, mac.size() * sizeof(DwMacro));
@@ -655,17 +683,20 @@ static int t16_plan_dwtape(colnde_handle* h) {
         return 0;
     }
     h->t16_dwtape = 1;
-    // optional: tape the hidden pre-activations too (COLNDE_T16_ZTAPE=0 disables; dropped when it does not fit)
-    const char* ezt = getenv("COLNDE_T16_ZTAPE");
-    if (!(ezt && atoi(ezt) == 0)) {
-        const size_t zbytes = n_rec * CT * t16_ztape_col_floats(m) * sizeof(float);
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-            zbytes + (size_t)h->n_tiles * n_steps * 4 * CT * m.ns * sizeof(float) + ((size_t)2 << 30) <= free_b &&
-            hipMalloc((void**)&h->d_t16_ztape, zbytes) != hipSuccess) {
+    // the block's stage tape, and (COLNDE_T16_ZTAPE=0 disables) the hidden pre-activations the forward kernel tapes for the adjoint
+    if (!h->d_tape) {
+        e = hipMalloc((void**)&h->d_tape, n_rec * CT * m.ns * sizeof(float));
+        if (e != hipSuccess) {
             (void)hipGetLastError();
-            h->d_t16_ztape = nullptr;
+            (void)hipFree(h->d_dwtape); h->d_dwtape = nullptr;
+            h->t16_dwtape = 0;
+            return 0;
         }
+    }
+    const char* ezt = getenv("COLNDE_T16_ZTAPE");
+    if (!(ezt && atoi(ezt) == 0) && hipMalloc((void**)&h->d_t16_ztape, n_rec * CT * t16_ztape_col_floats(m) * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        h->d_t16_ztape = nullptr;
     }
     return 0;
 }
@@ -720,26 +751,35 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         return 0;
     }
     if (t16_plan_dwtape(h)) return 1;
-    if (forward_impl(h, d_weights, h->d_sol, true)) return 1;
     if (h->t16_dwtape == 1) {
+        if (!h->have_problem) return fail("colnde_set_problem has not been called");
         LossWeights lw;
         loss_weights(h, scalings, &lw);
         const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+        const size_t ns = h->m.ns;
+        if (pack(h, d_weights)) return 1;
         HIPCHK(hipMemsetAsync(h->d_slab, 0, (size_t)h->t16_rows * stride * sizeof(float), h->stream));
-        {
-            Timed tm(h, K_ADJOINT);
-            AdjointGeom g = {512, 1, 3, 0};
-            hipError_t e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
-                                          h->d_bcs, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol, h->d_truth, h->d_tape,
-                                          lw, h->d_slab, h->n_col, g, (MODEL_FLOATS + lds_floats_adjoint(h->m)) * sizeof(float), h->stream,
-                                          h->d_dwtape, h->d_t16_ztape);
-            if (e != hipSuccess) return fail("adjoint (taped dW) launch failed: %s", hipGetErrorString(e));
-        }
-        {
-            Timed tm(h, K_DW1);
-            hipError_t e = launch_dw_gemm(h->d_dwtape, (size_t)h->n_tiles * n_steps * 4, (int)dwtape_row_floats(h->m), h->d_macros,
-                                          h->n_macros, h->dw_slices, h->d_slab + (size_t)h->n_tiles * stride, stride, h->stream);
-            if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
+        for (int b = 0; b < h->t16_nblocks; b++) {
+            const int c0 = b * h->t16_block, nc = std::min(h->t16_block, h->n_col - c0);
+            if (nc <= 0) break;
+            const int tiles_b = (nc + CT - 1) / CT;
+            if (t16_forward_range(h, d_weights, h->d_sol, true, c0, nc)) return 1;
+            {
+                Timed tm(h, K_ADJOINT);
+                AdjointGeom g = {512, 1, 3, 0};
+                hipError_t e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
+                                              h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
+                                              h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
+                                              lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, g,
+                                              (MODEL_FLOATS + lds_floats_adjoint(h->m)) * sizeof(float), h->stream, h->d_dwtape, h->d_t16_ztape);
+                if (e != hipSuccess) return fail("adjoint (taped dW) launch failed: %s", hipGetErrorString(e));
+            }
+            {
+                Timed tm(h, K_DW1);
+                hipError_t e = launch_dw_gemm(h->d_dwtape, (size_t)tiles_b * n_steps * 4, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros,
+                                              h->dw_slices, h->d_slab + ((size_t)h->n_tiles + (size_t)b * h->dw_slices) * stride, stride, h->stream);
+                if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
+            }
         }
         {
             Timed tm(h, K_REDUCE);
@@ -748,6 +788,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         }
         return 0;
     }
+    if (forward_impl(h, d_weights, h->d_sol, true)) return 1;
     if (!h->geo_ok)
         return fail("network too large for the tile engine's in-register adjoint (%d weight-gradient tiles, %zu B of LDS) and its "
                     "delta tape does not fit in HBM", h->m.n_tiles, h->lds_adj);
@@ -917,6 +958,8 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
         info[2] = h->rt_nblocks;
         info[3] = h->rt_ztape ? 1 : 0;
     } else {
+        info[1] = h->t16_dwtape == 1 ? h->t16_block : 0;
+        info[2] = h->t16_dwtape == 1 ? h->t16_nblocks : 0;
         info[4] = h->t16_dwtape == 1 ? 1 : 0;
         info[5] = h->t16_dwtape == 1 ? h->dw_slices : 0;
     }

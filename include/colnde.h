@@ -150,7 +150,7 @@ int colnde_zscore_stats_dev(colnde_handle* h, const float* d_x, int64_t count, f
 int colnde_scale_dev(colnde_handle* h, const float* d_x, int64_t count, const float* d_mu_sigma, float* d_out);
 
 /* How the handle runs its gradient path (filled in by the first colnde_loss_grad[_dev]; zeros before that):
- * info[0] engine (COLNDE_ENGINE_*), [1] columns per block of the regtile gradient path, [2] number of blocks, [3] regtile: layer-1
+ * info[0] engine (COLNDE_ENGINE_*), [1] columns per block of the gradient path (the tapes hold one block), [2] number of blocks, [3] regtile: layer-1
  * pre-activations taped (1) or recomputed (0), [4] tile16: weight gradients taped (1) or accumulated in registers (0),
  * [5] tile16 taped mode: K-slices of the dW GEMM, [6..7] reserved (0). */
 int colnde_plan(const colnde_handle* h, int info[8]);

@@ -67,12 +67,15 @@ def test_free_convection(Nz, ca):
 
 
 @pytest.mark.parametrize("case", ["fc32", "fc64", "fc32_ca", "wind_mixing", "fc64_l2stream", "wind_mixing_l2stream", "fc64_512threads", "fc64_noztape",
-                                  "fc32_inregister", "fc64_inregister", "wind_mixing_inregister"])
+                                  "fc32_inregister", "fc64_inregister", "wind_mixing_inregister", "fc64_blocked", "wind_mixing_blocked"])
 def test_tile16_taped_weight_gradients(case, monkeypatch):
     """tile16's gradient modes: layer deltas and hidden pre-activations taped with every dW contracted by the split-K GEMM kernel
     (the default), its variants, and the in-register fallback."""
     from colnde.nde import ENGINE_TILE16
     monkeypatch.setenv("COLNDE_T16_DWTAPE", "1")
+    if case.endswith("_blocked"):                    # tapes sized for one 16-column block: 21 / 37 columns run as 2 / 3 passes
+        monkeypatch.setenv("COLNDE_T16_BLOCK", "16")
+        case = case[:-len("_blocked")]
     if case.endswith("_inregister"):                 # the fallback when the tapes do not fit: accumulators resident in registers
         monkeypatch.setenv("COLNDE_T16_DWTAPE", "0")
         case = case[:-len("_inregister")]
