@@ -239,9 +239,11 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         h->fwd_wlds = h->lds_fwd + wl <= lds_cap;
         const char* ew = getenv("COLNDE_FWD_WLDS");
         if (ew) h->fwd_wlds = h->fwd_wlds && atoi(ew) != 0;
-        h->fwd_threads = h->fwd_wlds ? 512 : 256;
+        // weights in LDS: 1,024 threads (four waves per SIMD; 8 simulations 19.7 vs 21.3 ms at 512, 32-128-128-31 54.7 vs 55.7 ms);
+        // weights streamed from L2 (64-256-256-63): two independent 256-thread workgroups per CU do better (113 vs 121 ms)
+        h->fwd_threads = h->fwd_wlds ? 1024 : 256;
         const char* et = getenv("COLNDE_FWD_THREADS");
-        if (et && (atoi(et) == 256 || atoi(et) == 512)) h->fwd_threads = atoi(et);
+        if (et && (atoi(et) == 256 || atoi(et) == 512 || atoi(et) == 1024)) h->fwd_threads = atoi(et);
         h->lds_fwd_solve = h->lds_fwd + (h->fwd_wlds ? wl : 0);
     }
     if (h->lds_fwd > lds_cap) {

@@ -543,6 +543,7 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
                                const float* __restrict__ x0, const float* __restrict__ bcs,
                                const float* __restrict__ save_times, int n_save, int substeps,
                                float* __restrict__ sol, float* __restrict__ tape, int n_col, float* __restrict__ ztape) {
+    constexpr int FMAXR = 3072 / NTH;      // owner-thread register items per state array: CT * ns <= 3072 (ns <= 192)
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
     float* wl = smem;                                   // raw weights (WLDS) + 128 floats of zero padding
@@ -562,9 +563,9 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
     const int n_items = CT * m.ns;
     load_bcs(m, bcs, bcl, col0, n_col, tid);
 
-    float xn[FWD_MAXR], acc[FWD_MAXR];
+    float xn[FMAXR], acc[FMAXR];
 #pragma unroll
-    for (int r = 0; r < FWD_MAXR; r++) {
+    for (int r = 0; r < FMAXR; r++) {
         const int it = tid + r * nth;
         xn[r] = 0.0f;
         acc[r] = 0.0f;
@@ -587,7 +588,7 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
                 const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);            // stage abscissa
                 const float cbp = (st == 1) ? 1.0f / 6.0f : 1.0f / 3.0f;               // weight of k_{st-1}
 #pragma unroll
-                for (int r = 0; r < FWD_MAXR; r++) {
+                for (int r = 0; r < FMAXR; r++) {
                     const int it = tid + r * nth;
                     if (it < n_items) {
                         const int c = it / m.ns, i = it - c * m.ns;
@@ -609,7 +610,7 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
             }
             const bool save = (s == substeps - 1);
 #pragma unroll
-            for (int r = 0; r < FWD_MAXR; r++) {
+            for (int r = 0; r < FMAXR; r++) {
                 const int it = tid + r * nth;
                 if (it < n_items) {
                     const int c = it / m.ns, i = it - c * m.ns;
@@ -1247,6 +1248,8 @@ hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w,
     else if (wlds && nthreads == 256) LAUNCH_FWD(true, 256);
     else if (!wlds && nthreads == 512) LAUNCH_FWD(false, 512);
     else if (!wlds && nthreads == 256) LAUNCH_FWD(false, 256);
+    else if (wlds && nthreads == 1024) LAUNCH_FWD(true, 1024);
+    else if (!wlds && nthreads == 1024) LAUNCH_FWD(false, 1024);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1327,6 +1330,8 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     SETATTR((forward_kernel<true, 256>));
     SETATTR((forward_kernel<false, 512>));
     SETATTR((forward_kernel<false, 256>));
+    SETATTR((forward_kernel<true, 1024>));
+    SETATTR((forward_kernel<false, 1024>));
     SETATTR((adjoint_kernel<16, 512, 3, true>));
     SETATTR((adjoint_kernel<32, 256, 6, true>));
     SETATTR((adjoint_kernel<32, 256, 6, false>));
