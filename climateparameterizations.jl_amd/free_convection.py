@@ -97,3 +97,32 @@ def convective_adjustment(engine: ColumnNDE, T_interior, dt: float, K: float, dz
     hb = None if halo_bottom is None else np.asarray(halo_bottom, np.float32).reshape(-1)
     ht = None if halo_top is None else np.asarray(halo_top, np.float32).reshape(-1)
     return engine.convective_adjustment(T2, dt, dz, K, hb, ht).reshape(shape)
+
+
+def train_neural_differential_equation_device(nde: FreeConvectionNDE, weights, opt: ADAM, epochs: int, process_group=None):
+    """`Flux.train!` (training.jl:71) with θ and the ADAM state resident on the GPU: per epoch one `colnde_loss_grad_dev`,
+    [one SUM all-reduce when the simulations are sharded over `process_group`], one fused `colnde_adam_step_dev`.
+    Returns (θ, loss history) like `train_neural_differential_equation`; the per-epoch callback is not available here."""
+    import torch
+    eng = nde.engine
+    dev = torch.device("cuda", eng.device)
+    n = eng.n_params
+    theta = torch.as_tensor(np.asarray(weights, dtype=np.float32)).to(dev).contiguous()
+    out = torch.empty(n + 8, dtype=torch.float32, device=dev)
+    m = torch.zeros(n, dtype=torch.float32, device=dev)
+    v = torch.zeros(n, dtype=torch.float32, device=dev)
+    if opt.m is not None:
+        m.copy_(torch.as_tensor(opt.m, dtype=torch.float32)); v.copy_(torch.as_tensor(opt.v, dtype=torch.float32))
+    hist = []
+    for _ in range(epochs):
+        eng.loss_grad(theta, [0, 0, 1, 0, 0, 0], out=out)
+        if process_group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
+        hist.append(out[n + 6].clone())
+        eng.adam_step(theta, out, m, v, opt.eta, opt.beta, opt.eps, beta_t=tuple(opt.beta_t))
+        opt.beta_t[0] *= opt.beta[0]
+        opt.beta_t[1] *= opt.beta[1]
+    opt.m, opt.v = m.double().cpu().numpy(), v.double().cpu().numpy()
+    history = [float(x) for x in torch.stack(hist).cpu().numpy()] if hist else []
+    return theta.cpu().numpy(), history

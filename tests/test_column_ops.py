@@ -156,3 +156,18 @@ def test_gpu_device_resident_training_follows_the_host_loop():
     np.testing.assert_allclose(lb, la, rtol=2e-3)
     assert lb[-1] < lb[0]
     np.testing.assert_allclose(rb.weights, ra.weights, rtol=1e-3, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_free_convection_device_training_follows_the_host_loop():
+    from colnde import free_convection as fc
+    p = synthetic.free_convection_problem(6, Nz=32, n_save=5, substeps=2, t_end=0.02)
+    truth = orc.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    a = fc.FreeConvectionNDE(p.cfg, p.x0, p.bcs, truth)
+    b = fc.FreeConvectionNDE(p.cfg, p.x0, p.bcs, truth)
+    tha, ha = fc.train_neural_differential_equation(a, p.weights, flux_compat.ADAM(1e-3), epochs=6)
+    thb, hb = fc.train_neural_differential_equation_device(b, p.weights, flux_compat.ADAM(1e-3), epochs=6)
+    a.close(); b.close()
+    np.testing.assert_allclose(hb, ha, rtol=2e-3)
+    assert hb[-1] < hb[0]
+    np.testing.assert_allclose(thb, tha, rtol=1e-3, atol=2e-6)
