@@ -97,7 +97,7 @@ template <int ACT>
 __device__ __forceinline__ float rt_act(float z) {
     if (ACT == COLNDE_ACT_RELU) return fmaxf(z, 0.0f);
     if (ACT == COLNDE_ACT_MISH) {
-        const float e = __expf(fminf(z, 20.0f));
+        const float e = __expf(__builtin_amdgcn_fmed3f(z, -3.0e38f, 20.0f));
         const float n = e * (e + 2.0f);
         return z * fast_div(n, n + 2.0f);
     }
@@ -422,7 +422,7 @@ template <int ACT>
 __device__ __forceinline__ float rt_act_grad(float z) {
     if (ACT == COLNDE_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
     if (ACT == COLNDE_ACT_MISH) {
-        const float e = __expf(fminf(z, 20.0f));
+        const float e = __expf(__builtin_amdgcn_fmed3f(z, -3.0e38f, 20.0f));
         const float n = e * (e + 2.0f);
         const float t = fast_div(n, n + 2.0f);
         const float sg = fast_div(e, 1.0f + e);
@@ -440,7 +440,7 @@ __device__ __forceinline__ float rt_act_grad(float z) {
 template <int ACT>
 __device__ __forceinline__ void rt_act_pair(float z, float& a, float& d) {
     if (ACT == COLNDE_ACT_MISH) {
-        const float e = __expf(fminf(z, 20.0f));
+        const float e = __expf(__builtin_amdgcn_fmed3f(z, -3.0e38f, 20.0f));
         const float n = e * (e + 2.0f);
         const float r = __builtin_amdgcn_rcpf(n + 2.0f);
         const float p = 4.0f * z + 4.0f;
