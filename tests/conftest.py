@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once, as __graft_entry__.build() does
+    lib = os.path.join(ROOT, "climateparameterizations.jl_amd", "libcolnde.so")
+    ref = os.path.join(ROOT, "oracle", "_build", "libcolnde_ref.so")
+    if not (os.path.exists(lib) and os.path.exists(ref)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
