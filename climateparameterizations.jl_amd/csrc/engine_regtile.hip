@@ -488,24 +488,36 @@ __device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (
     f32x16 gb[3];
     if (m.mpp) {
         const f32x16 Ud = shift_down(X[0], h, 0.0f), Vd = shift_down(X[1], h, 0.0f), Td = shift_down(X[2], h, 0.0f);
+        // Same arithmetic as rt_physics_forward's diffusivity and its derivative, with every uniform factor folded into a handful
+        // of wave-uniform constants (this phase has no MFMA beside it: each vector instruction is fully exposed).
+        // level differences d = X[r] - X[r-1];  gu = Nz d_u etc.;  a1 = σ_u (gu + ε);  S2 = a1² + a2²;  Ri = B (gT + ε) / S2
+        const float cU = m.sig_u * Nz, sU = m.sig_u * m.eps, cV = m.sig_v * Nz, sV = m.sig_v * m.eps, cB = m.B * Nz, sB = m.B * m.eps;
+        // tanh((Ri - Riᶜ)/ΔRi) = 1 - 2 / (1 + exp2(kE Ri + oE)), argument clamped to ±30 log2(e)
+        const float L2E = 1.4426950408889634f;
+        const float kE = 2.0f * m.inv_dRi * L2E, oE = -2.0f * m.Ric * m.inv_dRi * L2E, cE = 30.0f * L2E;
+        const float nA = -0.5f * m.nu_minus, nB = m.nu0 + 0.5f * m.nu_minus;                    // ν = nB + nA tanh
+        const float m0 = -m.cs[0], m1 = -m.cs[1], m2 = -m.cs[2] * m.inv_Pr;                      // g_k = k̄_k ν m_k  (D = -k̄)
+        const float n0 = m0 * Nz * m.c_rib, n1 = m1 * Nz * m.c_rib, n2 = m2 * Nz * m.c_rib;      // c_rib Σ D_k c_k g_k = Σ k̄_k d_k n_k
+        const float q0 = -2.0f * m.sig_u, q1 = -2.0f * m.sig_v;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const bool in = !(r == 0 && h == 0);
-            const float gu = (X[0][r] - Ud[r]) * Nz, gv = (X[1][r] - Vd[r]) * Nz, gT = (X[2][r] - Td[r]) * Nz;
-            const float a1 = m.sig_u * (gu + m.eps), a2 = m.sig_v * (gv + m.eps);
-            const float S2 = a1 * a1 + a2 * a2;
-            const float Ri = fast_div(m.B * (gT + m.eps), S2);
-            const float e = __expf(2.0f * fminf(fmaxf((Ri - m.Ric) * m.inv_dRi, -15.0f), 15.0f));
-            const float th = 1.0f - fast_div(2.0f, 1.0f + e);
-            const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
-            const float D0 = -kd[0][r], D1 = -kd[1][r], D2 = -kd[2][r];
-            float g0 = D0 * m.cs[0] * nu, g1 = D1 * m.cs[1] * nu, g2 = D2 * m.cs[2] * nu * m.inv_Pr;
-            const float nub = D0 * m.cs[0] * gu + D1 * m.cs[1] * gv + D2 * m.cs[2] * gT * m.inv_Pr;
-            const float ribs = nub * m.c_rib * (1.0f - th * th);
-            g2 += fast_div(ribs * m.B, S2);
-            const float q = fast_div(ribs * -Ri, S2) * 2.0f;
-            g0 += q * m.sig_u * m.sig_u * (gu + m.eps);
-            g1 += q * m.sig_v * m.sig_v * (gv + m.eps);
+            const float dU = X[0][r] - Ud[r], dV = X[1][r] - Vd[r], dT = X[2][r] - Td[r];
+            const float a1 = fmaf(dU, cU, sU), a2 = fmaf(dV, cV, sV);
+            const float rS = __builtin_amdgcn_rcpf(fmaf(a2, a2, a1 * a1));
+            const float Ri = fmaf(dT, cB, sB) * rS;
+            const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(fmaf(Ri, kE, oE), -cE, cE));
+            const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+            const float nu = fmaf(th, nA, nB);
+            const float t0 = kd[0][r] * nu, t1 = kd[1][r] * nu, t2 = kd[2][r] * nu;
+            float nub = (kd[0][r] * dU) * n0;
+            nub = fmaf(kd[1][r] * dV, n1, nub);
+            nub = fmaf(kd[2][r] * dT, n2, nub);
+            const float w = nub * (fmaf(-th, th, 1.0f) * rS);                                  // c_rib (1 - tanh²) Σ… / S2
+            const float qq = w * Ri;
+            const float g2 = fmaf(w, m.B, t2 * m2);
+            const float g0 = fmaf(qq, a1 * q0, t0 * m0);
+            const float g1 = fmaf(qq, a2 * q1, t1 * m1);
             gb[0][r] = in ? g0 : 0.0f;
             gb[1][r] = in ? g1 : 0.0f;
             gb[2][r] = in ? g2 : 0.0f;
@@ -1091,6 +1103,14 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
     // f = 4 qq + g of net n is element (2qq & 3) + (g >> 1) of group qq >> 1, lane32 = j + 16 half + 32 (g & 1)
     float* tz = tapez ? tapez + (size_t)tile32 * n_steps * 4 * RT_TAPE2 + (j + 16 * half + 32 * (g & 1)) * 4 + (g >> 1) : nullptr;
     const float Nz = 32.0f;
+    struct { float cU, sU, cV, sV, cB, sB, kE, oE, cE, nA, nB, f0, f1, f2; } pc;
+    {
+        const float L2E = 1.4426950408889634f;
+        pc.cU = m.sig_u * Nz; pc.sU = m.sig_u * m.eps; pc.cV = m.sig_v * Nz; pc.sV = m.sig_v * m.eps; pc.cB = m.B * Nz; pc.sB = m.B * m.eps;
+        pc.kE = 2.0f * m.inv_dRi * L2E; pc.oE = -2.0f * m.Ric * m.inv_dRi * L2E; pc.cE = 30.0f * L2E;
+        pc.nA = -0.5f * m.nu_minus; pc.nB = m.nu0 + 0.5f * m.nu_minus;
+        pc.f0 = -m.cs[0] * Nz; pc.f1 = -m.cs[1] * Nz; pc.f2 = -m.cs[2] * m.inv_Pr * Nz;
+    }
     int step = 0;
     for (int iv = 0; iv < n_save - 1; iv++) {
         const float t0 = save_times[iv];
@@ -1181,16 +1201,17 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                             if (!m.zero_w && !in) { f0 = bc.b[0]; f1 = bc.b[1]; f2 = bc.b[2]; }
                             if (m.mpp) {
                                 if (in) {
-                                    const float gu = (Xs[0].t[tau][r] - Ud.t[tau][r]) * Nz, gv = (Xs[1].t[tau][r] - Vd.t[tau][r]) * Nz,
-                                                gT = (Xs[2].t[tau][r] - Td.t[tau][r]) * Nz;
-                                    const float a1 = m.sig_u * (gu + m.eps), a2 = m.sig_v * (gv + m.eps);
-                                    const float Ri = fast_div(m.B * (gT + m.eps), a1 * a1 + a2 * a2);
-                                    const float e = __expf(2.0f * fminf(fmaxf((Ri - m.Ric) * m.inv_dRi, -15.0f), 15.0f));
-                                    const float th = 1.0f - fast_div(2.0f, 1.0f + e);
-                                    const float nu = m.nu0 + m.nu_minus * (1.0f - th) * 0.5f;
-                                    f0 -= m.cs[0] * nu * gu;
-                                    f1 -= m.cs[1] * nu * gv;
-                                    f2 -= m.cs[2] * (nu * m.inv_Pr) * gT;
+                                    // uniform factors folded (see rt_physics_vjp): d = level difference, a = σ (Nz d + ε), Ri = B (Nz d_T + ε) / S2,
+                                    // tanh via exp2, ν = nB + nA tanh, diffusive flux = -(c Nz) ν d
+                                    const float dU = Xs[0].t[tau][r] - Ud.t[tau][r], dV = Xs[1].t[tau][r] - Vd.t[tau][r], dT = Xs[2].t[tau][r] - Td.t[tau][r];
+                                    const float a1 = fmaf(dU, pc.cU, pc.sU), a2 = fmaf(dV, pc.cV, pc.sV);
+                                    const float Ri = fmaf(dT, pc.cB, pc.sB) * __builtin_amdgcn_rcpf(fmaf(a2, a2, a1 * a1));
+                                    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(fmaf(Ri, pc.kE, pc.oE), -pc.cE, pc.cE));
+                                    const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+                                    const float nu = fmaf(th, pc.nA, pc.nB);
+                                    f0 = fmaf(nu * dU, pc.f0, f0);
+                                    f1 = fmaf(nu * dV, pc.f1, f1);
+                                    f2 = fmaf(nu * dT, pc.f2, f2);
                                 } else if (m.zero_w) {
                                     f0 += bc.b[0] - m.s0[0]; f1 += bc.b[1] - m.s0[1]; f2 += bc.b[2] - m.s0[2];
                                 }
