@@ -442,9 +442,10 @@ __device__ __forceinline__ void rt_act_pair(float z, float& a, float& d) {
     if (ACT == COLNDE_ACT_MISH) {
         const float e = __expf(__builtin_amdgcn_fmed3f(z, -3.0e38f, 20.0f));
         const float n = e * (e + 2.0f);
-        const float r = __builtin_amdgcn_rcpf(n + 2.0f);
+        const float q = n + 2.0f;
+        const float r = __builtin_amdgcn_rcpf(q);
         const float p = 4.0f * z + 4.0f;
-        const float w = fmaf(e, (n + 2.0f * e) + (p + 2.0f), p);
+        const float w = fmaf(e, fmaf(2.0f, e, q) + p, p);          // n + 2 e + p + 2 = (q + 2 e) + p
         a = z * (n * r);
         d = (e * r) * (w * r);
     } else if (ACT == COLNDE_ACT_SWISH) {
