@@ -241,3 +241,50 @@ def test_zero_weights_give_zero_weight_gradient_blocks(engine):
         assert np.all(W1 == 0) and np.all(b1 == 0) and np.all(W2 == 0) and np.all(b2 == 0) and np.all(W3 == 0)
         assert np.abs(b3).max() > 0
     assert _rel(g, g_ref) < GRAD_REL
+
+
+# ---- the generic engine on shapes nobody tuned for ----------------------------------------------------------------
+_RANDOM_SHAPES = [
+    # (model, Nz, hidden sizes, hidden activations, columns)
+    ("wm", 8, (7,), ("tanh",), 5),
+    ("wm", 16, (33, 9), ("swish", "relu"), 19),
+    ("wm", 24, (17, 40, 5), ("mish", "leakyrelu", "tanh"), 33),
+    ("wm", 48, (64,), ("relu",), 17),
+    ("fc", 12, (20, 20), ("relu", "relu"), 16),
+    ("fc", 40, (70, 11, 30), ("tanh", "mish", "swish"), 23),
+    ("fc", 96, (48,), ("leakyrelu",), 9),
+    ("ca", 20, (16, 16), ("relu", "tanh"), 31),
+]
+
+
+@pytest.mark.parametrize("mode", ["taped", "inregister", "l2stream"])
+@pytest.mark.parametrize("model,Nz,hidden,acts,ncol", _RANDOM_SHAPES)
+def test_tile16_untuned_shapes(model, Nz, hidden, acts, ncol, mode, monkeypatch):
+    """Layer counts 2..4, widths that are not multiples of the 16-row MFMA tile, mixed activations, Nz from 8 to 96, ragged column
+    counts: solution, loss terms and gradient of the generic engine (taped gradient path) against the float64 oracle."""
+    if mode == "inregister":
+        monkeypatch.setenv("COLNDE_T16_DWTAPE", "0")
+    if mode == "l2stream":
+        monkeypatch.setenv("COLNDE_T16_DWLDS", "0")
+    if model == "wm":
+        sizes = (3 * Nz,) + tuple(hidden) + (Nz - 1,)
+        p = synthetic.wind_mixing_problem(ncol, Nz=Nz, n_frames=5, weight_divisor=1e2, layer_sizes=sizes,
+                                          activations=tuple(acts) + ("identity",))
+        sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    else:
+        sizes = (Nz,) + tuple(hidden) + (Nz - 1,)
+        p = synthetic.free_convection_problem(ncol, Nz=Nz, n_save=5, substeps=32 if model == "ca" else 2, t_end=0.01,
+                                              convective_adjustment=(model == "ca"), layer_sizes=sizes,
+                                              activations=tuple(acts) + ("identity",))
+        sc = O.default_loss_scalings(p.cfg)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+        dx_g = nde.rhs(p.x0, p.weights, p.bcs, 0.01)
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
+    assert _rel(grad_g, g) < GRAD_REL
+    assert _rel(dx_g, O.rhs(p.cfg, p.x0, p.bcs, p.weights, 0.01)) < 2e-5
