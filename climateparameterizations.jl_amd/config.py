@@ -142,8 +142,10 @@ class NDEConfig:
             if a not in ACT_IDS:
                 raise ValueError("unknown activation %r" % (a,))
         if self.model == WIND_MIXING:
-            if self.modified_pacanowski_philander and self.convective_adjustment:
-                # `@assert !modified_pacanowski_philander || !convective_adjustment` NDE_training.jl:171
+            if self.modified_pacanowski_philander and self.convective_adjustment and not self.inplace_variant:
+                # `@assert !modified_pacanowski_philander || !convective_adjustment` NDE_training.jl:171; the in-place `NDE!`
+                # hard-wires MPP and reads `conditions.convective_adjustment` for its ν_T switch
+                # (training_postprocessing.jl:118-121), so the pair is legal there
                 raise ValueError("modified_pacanowski_philander and convective_adjustment are exclusive")
             if self.zero_weights and not self.modified_pacanowski_philander:
                 # NDE_training.jl:192-194

@@ -105,6 +105,57 @@ def wm_rhs(cfg, x, p_bcs, theta, t=0.0):
     return torch.cat([dudt, dvdt, dTdt])
 
 
+def wm_rhs_inplace(cfg, x, p_bcs, theta, t=0.0):
+    """The in-place evaluation RHS `NDE!` with its `predict_flux!`, written as training_postprocessing.jl:55-153 is: face
+    vectors whose end entries are preset ONCE to `BC - scaling(0)` (:82-93), interiors overwritten by the nets (:105-107) and
+    decremented by the diffusive flux (:126-128), `Ri` WITHOUT the ϵ of the training RHS (:114), the `ν_T` switch that tests
+    ∂u∂z (:118-121), and a diurnal top flux refreshed every call WITHOUT the `- scaling(0)` offset (:142-144)."""
+    Nz, H, tau, f = cfg.Nz, cfg.H, cfg.tau, cfg.f
+    mu_u, mu_v, mu_T, mu_uw, mu_vw, mu_wT = cfg.mu
+    s_u, s_v, s_T, s_uw, s_vw, s_wT = cfg.sigma
+    D_cell = torch.tensor(O.Dc(Nz, 1 / Nz), dtype=DT)
+    D_face = torch.tensor(O.Df(Nz, 1 / Nz), dtype=DT)
+    nets = chains(theta, cfg)
+    uw_b, uw_t, vw_b, vw_t, wT_b, wT_t = [float(p_bcs[i]) for i in range(6)]
+    scal0 = lambda mu, sg: (0.0 - mu) / sg                                   # scalings.φ(0f0)
+    if cfg.diurnal:
+        Q = float(p_bcs[5])
+        top_fn = lambda tt: (Q * np.sin(2 * np.pi / (24 * 60 ** 2) * tt) / (cfg.alpha * cfg.g) - mu_wT) / s_wT
+    uw, vw, wT = (torch.zeros(Nz + 1, dtype=DT) for _ in range(3))
+    uw[0] = uw_b - scal0(mu_uw, s_uw)
+    vw[0] = vw_b - scal0(mu_vw, s_vw)
+    wT[0] = wT_b - scal0(mu_wT, s_wT)
+    uw[-1] = uw_t - scal0(mu_uw, s_uw)
+    vw[-1] = vw_t - scal0(mu_vw, s_vw)
+    wT[-1] = (top_fn(0.0) if cfg.diurnal else wT_t) - scal0(mu_wT, s_wT)
+    u, v, T = x[:Nz], x[Nz:2 * Nz], x[2 * Nz:]
+    # predict_flux!
+    uw[1:-1] = chain_call(nets[0], cfg.activations, x)
+    vw[1:-1] = chain_call(nets[1], cfg.activations, x)
+    wT[1:-1] = chain_call(nets[2], cfg.activations, x)
+    dudz, dvdz, dTdz = D_face @ u, D_face @ v, D_face @ T
+    Bz = H * cfg.g * cfg.alpha * s_T * dTdz
+    S2 = (s_u * dudz) ** 2 + (s_v * dvdz) ** 2
+    Ri = Bz / S2                                                              # end faces 0/0: never read
+    nu = cfg.nu0 + cfg.nu_minus * (1 - torch.tanh((Ri - cfg.Ric) / cfg.dRi)) / 2
+    nu_T = torch.zeros(Nz + 1, dtype=DT)
+    if cfg.convective_adjustment:
+        for i in range(1, Nz):
+            nu_T[i] = nu[i] / cfg.Pr if dudz[i] > 0 else cfg.kappa
+    else:
+        nu_T = nu / cfg.Pr
+    uw[1:-1] = uw[1:-1] - s_u / s_uw / H * nu[1:-1] * dudz[1:-1]
+    vw[1:-1] = vw[1:-1] - s_v / s_vw / H * nu[1:-1] * dvdz[1:-1]
+    wT[1:-1] = wT[1:-1] - s_T / s_wT / H * nu_T[1:-1] * dTdz[1:-1]
+    # NDE!
+    if cfg.diurnal:
+        wT[-1] = top_fn(t * tau)
+    dudt = -tau / H * s_uw / s_u * (D_cell @ uw) + f * tau / s_u * (s_v * v + mu_v)
+    dvdt = -tau / H * s_vw / s_v * (D_cell @ vw) - f * tau / s_v * (s_u * u + mu_u)
+    dTdt = -tau / H * s_wT / s_T * (D_cell @ wT)
+    return torch.cat([dudt, dvdt, dTdt])
+
+
 def fc_rhs(cfg, T, p_bcs, theta, t=0.0):
     Nz = cfg.Nz
     s_T, s_wT = cfg.sigma[2], cfg.sigma[5]
@@ -122,7 +173,9 @@ def fc_rhs(cfg, T, p_bcs, theta, t=0.0):
 
 
 def rhs(cfg, x, bcs, theta, t=0.0):
-    return wm_rhs(cfg, x, bcs, theta, t) if cfg.model == O.WIND_MIXING else fc_rhs(cfg, x, bcs, theta, t)
+    if cfg.model == O.WIND_MIXING:
+        return wm_rhs_inplace(cfg, x, bcs, theta, t) if cfg.inplace_variant else wm_rhs(cfg, x, bcs, theta, t)
+    return fc_rhs(cfg, x, bcs, theta, t)
 
 
 def solve_rk4(cfg, x0, bcs, theta):

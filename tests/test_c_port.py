@@ -6,24 +6,30 @@ import colnde
 from colnde import synthetic
 from oracle import nde_oracle as O
 from oracle import cref
-from tests.test_oracle import VARIANTS
+from tests.test_oracle import VARIANTS, INPLACE_VARIANTS
 
 
 def _rel(a, b):
     return np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-300)
 
 
-@pytest.mark.parametrize("name", sorted(VARIANTS) + ["inplace", "inplace_ca"])
+@pytest.mark.parametrize("name", sorted(VARIANTS) + sorted(INPLACE_VARIANTS))
 def test_c_rhs_matches_numpy(name):
-    kw = dict(VARIANTS.get(name, {}))
-    if name == "inplace":
-        kw = dict(inplace_variant=True)
-    if name == "inplace_ca":
-        kw = dict(inplace_variant=True, convective_adjustment=False)
+    kw = dict(VARIANTS[name] if name in VARIANTS else INPLACE_VARIANTS[name])
     p = synthetic.wind_mixing_problem(5, n_frames=3, weight_divisor=10.0, **kw)
     ref = O.rhs(p.cfg, p.x0, p.bcs, p.weights, 0.02)
     got = cref.rhs(p.cfg, p.x0, p.bcs, p.weights, 0.02)
     assert _rel(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("name", sorted(INPLACE_VARIANTS))
+def test_c_forward_inplace_matches_numpy(name):
+    """`solve_NDE_mutating` (training_postprocessing.jl:55-159): a forward solve under the in-place arithmetic; κ = 0.1 keeps
+    the ν_T = κ faces inside RK4's stability region at two sub-steps per frame."""
+    p = synthetic.wind_mixing_problem(4, n_frames=9, weight_divisor=1e2, kappa=0.1, **INPLACE_VARIANTS[name])
+    sol = O.solve(p.cfg, p.x0, p.bcs, p.weights)
+    got = cref.forward(p.cfg, p.x0, p.bcs, p.weights)
+    assert np.abs(got - sol).max() < 5e-5
 
 
 @pytest.mark.parametrize("ca", [False, True])

@@ -138,6 +138,36 @@ def test_inplace_variant_differs_only_at_eps():
     assert np.abs(a - b).max() < 1e-4 * np.abs(a).max()
 
 
+# the in-place `NDE!` arithmetic (training_postprocessing.jl:55-153): cases shared by the oracle, C-port and GPU tests
+INPLACE_VARIANTS = {
+    "inplace": dict(inplace_variant=True),
+    "inplace_ca": dict(inplace_variant=True, convective_adjustment=True),                    # ν_T = κ where ∂u∂z <= 0 (:118-121)
+    "inplace_diurnal": dict(inplace_variant=True, diurnal=True),                             # un-offset top flux (:142-144)
+    "inplace_ca_diurnal": dict(inplace_variant=True, convective_adjustment=True, diurnal=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(INPLACE_VARIANTS))
+def test_inplace_rhs_matches_literal(name):
+    p = _wm(3, **INPLACE_VARIANTS[name])
+    t = 0.013
+    dx = O.rhs(p.cfg, p.x0, p.bcs, p.weights, t)
+    th = torch.tensor(p.weights.astype(np.float64))
+    for c in range(3):
+        ref = LT.wm_rhs_inplace(p.cfg, torch.tensor(p.x0[c].astype(np.float64)),
+                                torch.tensor(p.bcs[c].astype(np.float64)), th, t).numpy()
+        np.testing.assert_allclose(dx[c], ref, rtol=1e-9, atol=1e-9)
+    if "ca" in name:                       # the switch is live: both branches occur on these profiles, and it matters
+        gu = O._face_grad(p.x0[:, :32].astype(np.float64), 32)[:, 1:32]
+        assert (gu > 0).any() and (gu <= 0).any()
+        plain = O.rhs(p.cfg.with_(convective_adjustment=False), p.x0, p.bcs, p.weights, t)
+        assert np.abs(dx - plain).max() > 1e-2 * np.abs(plain).max()
+    if "diurnal" in name:                  # the missing `- scaling(0)` offset is visible in the surface cell only
+        off = O.rhs(p.cfg.with_(inplace_variant=False, convective_adjustment=False), p.x0, p.bcs, p.weights, t)
+        base = O.rhs(p.cfg.with_(convective_adjustment=False), p.x0, p.bcs, p.weights, t)
+        assert np.abs((base - off)[:, 95]).min() > 1e-3 and np.abs((base - off)[:, 64:95]).max() < 1e-3 * np.abs(off).max()
+
+
 # ---------------------------------------------------------------- adjoint vs torch autograd
 def _autograd_case(p, scal):
     cfg = p.cfg
