@@ -10,13 +10,24 @@ from tests.test_oracle import VARIANTS, INPLACE_VARIANTS
 
 pytestmark = pytest.mark.gpu
 
-SOL_ATOL = 1e-4          # scaled units, O(1) profiles
-LOSS_RTOL = 2e-3
-GRAD_REL = 5e-3          # relative L2 error of the float32 gradient vs the float64 oracle
-# the 576-step bench horizon (float32 round-off accumulates over the steps); loss/gradient tolerances keyed by weight divisor
-LONG_SOL_ATOL = 5e-4
-LONG_LOSS_RTOL = {1e2: 5e-3, 1e5: 5e-3}
-LONG_GRAD_REL = {1e2: 2e-2, 1e5: 2e-2}
+# Tolerances of the float32 HIP path against the float64 oracle: about 10x the largest error MEASURED on an MI355X for the
+# family of cases (profiles/r02_parity_errors.json keeps the run they were set from; COLNDE_RECORD_ERRORS=1 re-measures).
+# Wind mixing, 3..9 frames (smooth profiles, loss O(1e-3)): measured sol 2.1e-6, loss 8e-6, gradient 1.8e-5.
+SOL_ATOL = 2e-5          # scaled units, O(1) profiles
+LOSS_RTOL = 8e-5
+GRAD_REL = 2e-4          # relative L2 error of the float32 gradient vs the float64 oracle
+# Free convection (relu nets; the loss is a small difference of O(1) profiles, so float32 cancellation shows in it and relu
+# kinks flip between float32 and float64): measured sol 7.4e-6 (stiff CA variant), loss 3.2e-4, gradient 3.9e-4.
+FC_SOL_ATOL = 8e-5
+FC_LOSS_RTOL = 3e-3
+FC_GRAD_REL = 4e-3
+# The 576-step bench horizon (round-off accumulates over the steps).  Loss and gradient tolerances are keyed by the weight
+# divisor: with the bench's own weights/1e5 the net is near zero and the loss (3e-9) IS float32 round-off of the trajectories
+# (measured: total 1.6e-3, the T term 1.8e-2, gradient 2.1e-3); with weights/1e2: sol 7.6e-6, loss 1.2e-6, terms 2e-6, gradient 3.2e-6.
+LONG_SOL_ATOL = 8e-5
+LONG_LOSS_RTOL = {1e2: 2e-5, 1e5: 1.5e-2}
+LONG_TERMS_RTOL = {1e2: 2e-5, 1e5: 1.5e-1}
+LONG_GRAD_REL = {1e2: 4e-5, 1e5: 2e-2}
 
 
 def _rel(a, b):
@@ -42,7 +53,7 @@ def test_rhs_wind_mixing(name):
     with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
         got = nde.rhs(p.x0, p.weights, p.bcs, 0.02)
     _record("rhs_wm/" + name, rhs_rel=_rel(got, ref))
-    assert _rel(got, ref) < 2e-5
+    assert _rel(got, ref) < 1e-6                                            # measured 1.0e-7
 
 
 @pytest.mark.parametrize("name", sorted(INPLACE_VARIANTS))
@@ -96,9 +107,9 @@ def test_free_convection(Nz, ca):
         sol_g = nde.forward(p.weights)
         tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
     _record("test_free_convection" + "/" + str(Nz) + "/" + str(ca), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g))
-    assert np.abs(sol_g - sol).max() < SOL_ATOL
-    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
-    assert _rel(grad_g, g) < GRAD_REL
+    assert np.abs(sol_g - sol).max() < FC_SOL_ATOL
+    assert np.isclose(tot_g, tot, rtol=FC_LOSS_RTOL)
+    assert _rel(grad_g, g) < FC_GRAD_REL
 
 
 @pytest.mark.parametrize("case", ["fc32", "fc64", "fc32_ca", "wind_mixing", "fc64_l2stream", "wind_mixing_l2stream", "fc64_512threads", "fc64_noztape",
@@ -138,8 +149,9 @@ def test_tile16_taped_weight_gradients(case, monkeypatch):
         tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
         tot_2, _, grad_2 = nde.loss_grad(p.weights, sc)
     _record("test_tile16_taped_weight_gradients" + "/" + str(case), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g))
-    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
-    assert _rel(grad_g, g) < GRAD_REL
+    wm = case == "wind_mixing"
+    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL if wm else FC_LOSS_RTOL)
+    assert _rel(grad_g, g) < (GRAD_REL if wm else FC_GRAD_REL)
     assert tot_2 == tot_g and np.array_equal(grad_2, grad_g)        # fixed-order reductions: bit-reproducible
 
 
@@ -148,7 +160,8 @@ def test_infer_forcing():
     ref = O.infer_forcing(cfg, T, top, w, 1000.0)
     with colnde.ColumnNDE(cfg, T.shape[0]) as nde:
         got = nde.infer_forcing(w, T, top, 1000.0)
-    assert _rel(got, ref) < 1e-4
+    _record("infer_forcing", rel=_rel(got, ref))
+    assert _rel(got, ref) < 2e-6                                            # measured 2e-7
 
 
 def test_long_horizon_2day_suite_shape():
@@ -162,9 +175,9 @@ def test_long_horizon_2day_suite_shape():
         sol_g = nde.forward(p.weights)
         tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
     _record("test_long_horizon_2day_suite_shape", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g))
-    assert np.abs(sol_g - sol).max() < 5e-4
-    assert np.isclose(tot_g, tot, rtol=5e-3)
-    assert _rel(grad_g, g) < 2e-2
+    assert np.abs(sol_g - sol).max() < LONG_SOL_ATOL
+    assert np.isclose(tot_g, tot, rtol=LONG_LOSS_RTOL[1e5])               # synthetic default = the bench's weights/1e5
+    assert _rel(grad_g, g) < LONG_GRAD_REL[1e5]
 
 
 @pytest.mark.parametrize("n_col,divisor", [(8, 1e2), (64, 1e2), (64, 1e5)])
@@ -185,7 +198,7 @@ def test_regtile_long_horizon_against_oracle(n_col, divisor):
     _record("regtile_576/%d/%g" % (n_col, divisor), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot,
             terms_rel=np.abs(terms_g / terms - 1).max(), grad_rel=_rel(grad_g, g))
     assert np.abs(sol_g - sol).max() < LONG_SOL_ATOL
-    np.testing.assert_allclose(terms_g, terms, rtol=LONG_LOSS_RTOL[divisor], atol=0)
+    np.testing.assert_allclose(terms_g, terms, rtol=LONG_TERMS_RTOL[divisor], atol=0)
     assert np.isclose(tot_g, tot, rtol=LONG_LOSS_RTOL[divisor], atol=0)
     assert _rel(grad_g, g) < LONG_GRAD_REL[divisor]
 
@@ -209,6 +222,9 @@ def test_config1_shape_one_column_ten_frames():
         assert _rel(grad_g, g) < GRAD_REL
 
 
+CA64_F32 = (2e-6, 5e-6, 6e-5)          # HIP vs the float32 oracle on the kinked case: measured 1.8e-7, 4.2e-7, 5.6e-6
+
+
 def test_conv_adj_nde_64_levels():
     """`ConvectiveAdjustmentNDE` (convective_adjustment_nde.jl:33-48, K = 10) at the 64 levels of BASELINE config 4, on profiles
     with unstable faces so that the min(0, K dT/dz) term is live; RK4 needs dt <= 2.785 / (4 K C Nz^2) = 3.4e-5 here."""
@@ -223,10 +239,19 @@ def test_conv_adj_nde_64_levels():
         nde.set_problem(x0, p.bcs, truth)
         sol_g = nde.forward(p.weights)
         tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
-    _record("ca_nde_64", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g))
-    assert np.abs(sol_g - sol).max() < SOL_ATOL
-    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
-    assert _rel(grad_g, g) < GRAD_REL
+    # Once a layer is adjusted its dT/dz hovers at 0-, i.e. AT the kink of min(0, K dT/dz): which side a face sits on is
+    # decided by round-off, so the float32 gradient differs from the float64 one by what those faces carry (179 of 1,197 faces
+    # end with |K dT/dz| < 1e-3 here).  The float32 NumPy oracle shows the same 4.8e-2 gap to float64 as the HIP path does, and
+    # the HIP path agrees with THAT oracle tightly: the gap is float32's, not the kernel's.
+    tot32, _, g32, sol32 = O.loss_and_grad(p.cfg, x0, p.bcs, p.weights, truth, sc, dtype=np.float32)
+    _record("ca_nde_64", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g),
+            sol_abs_f32=np.abs(sol_g - sol32).max(), loss_rel_f32=abs(tot_g - tot32) / tot32, grad_rel_f32=_rel(grad_g, g32.astype(np.float64)),
+            grad_rel_oracle32_vs_64=_rel(g32, g))
+    assert np.abs(sol_g - sol).max() < 2 * FC_SOL_ATOL                      # measured 1.4e-5
+    assert np.isclose(tot_g, tot, rtol=FC_LOSS_RTOL)                        # measured 2.5e-4
+    assert _rel(grad_g, g) < 3 * _rel(g32, g) + FC_GRAD_REL                 # measured 4.79e-2, the float32 oracle's own gap
+    assert np.abs(sol_g - sol32).max() < CA64_F32[0] and abs(tot_g - tot32) <= CA64_F32[1] * tot32
+    assert _rel(grad_g, g32.astype(np.float64)) < CA64_F32[2]
 
 
 def test_config4_time_axis_129_save_points():
@@ -245,9 +270,9 @@ def test_config4_time_axis_129_save_points():
         sol_g = nde.forward(p.weights)
         tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
     _record("config4_axis/ca%d" % ca, sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g))
-    assert np.abs(sol_g - sol).max() < LONG_SOL_ATOL
-    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
-    assert _rel(grad_g, g) < LONG_GRAD_REL[1e2]
+    assert np.abs(sol_g - sol).max() < 7e-4                                 # 512 steps, profiles reaching |T| = 14: measured 6.9e-5
+    assert np.isclose(tot_g, tot, rtol=FC_LOSS_RTOL)                        # measured 5.9e-5
+    assert _rel(grad_g, g) < FC_GRAD_REL                                    # measured 1.7e-4
 
 
 # ---- engine selection: regtile (register-resident, static wind-mixing shape) vs tile16 (generic) -------------------
@@ -363,7 +388,10 @@ def test_zero_weights_give_zero_weight_gradient_blocks(engine):
         W3, b3 = blk[5870:6490], blk[6490:6521]
         assert np.all(W1 == 0) and np.all(b1 == 0) and np.all(W2 == 0) and np.all(b2 == 0) and np.all(W3 == 0)
         assert np.abs(b3).max() > 0
-    assert _rel(g, g_ref) < GRAD_REL
+    _record("zero_weights/engine%d" % engine, grad_rel=_rel(g, g_ref))
+    # truth here is the trajectory of weights/1e5: the loss (and with it the gradient) is float32 round-off of the profiles,
+    # as in the 576-step case with the bench's weights (measured 1.6e-3)
+    assert _rel(g, g_ref) < LONG_GRAD_REL[1e5]
 
 
 # ---- the generic engine on shapes nobody tuned for ----------------------------------------------------------------
@@ -408,7 +436,7 @@ def test_tile16_untuned_shapes(model, Nz, hidden, acts, ncol, mode, monkeypatch)
         tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
         dx_g = nde.rhs(p.x0, p.weights, p.bcs, 0.01)
     _record("test_tile16_untuned_shapes" + "/" + str(model) + "/" + str(Nz) + "/" + str(hidden) + "/" + str(acts) + "/" + str(ncol) + "/" + str(mode), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g))
-    assert np.abs(sol_g - sol).max() < SOL_ATOL
-    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
-    assert _rel(grad_g, g) < GRAD_REL
-    assert _rel(dx_g, O.rhs(p.cfg, p.x0, p.bcs, p.weights, 0.01)) < 2e-5
+    assert np.abs(sol_g - sol).max() < (SOL_ATOL if model == "wm" else FC_SOL_ATOL)
+    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL if model == "wm" else FC_LOSS_RTOL)
+    assert _rel(grad_g, g) < (GRAD_REL if model == "wm" else FC_GRAD_REL)
+    assert _rel(dx_g, O.rhs(p.cfg, p.x0, p.bcs, p.weights, 0.01)) < 2e-6
