@@ -70,6 +70,15 @@ class ADAM:
         self.v = None
         self.beta_t = [self.beta[0], self.beta[1]]  # Flux keeps the running powers βᵗ
 
+    def reset(self) -> None:
+        """Forget the moments and the running powers.  Flux keeps ADAM's state in an IdDict keyed by the parameter ARRAY; every
+        GalacticOptim `solve(prob, opt, …)` optimises a fresh `θ = copy(prob.u0)`, so each (optimizer, epoch) solve of
+        `train_NDE` (NDE_training.jl:340-372) starts from m = v = 0, βᵗ = β — whereas `Flux.train!` on a persistent
+        `Flux.params(NN)` (free_convection/src/training.jl:71) keeps one state across calls."""
+        self.m = None
+        self.v = None
+        self.beta_t = [self.beta[0], self.beta[1]]
+
     def update(self, theta: np.ndarray, grad: np.ndarray) -> np.ndarray:
         if self.m is None:
             self.m = np.zeros_like(theta, dtype=np.float64)

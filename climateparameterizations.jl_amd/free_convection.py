@@ -24,10 +24,14 @@ from .nde import ColumnNDE
 class FreeConvectionNDE:
     """One NDE per simulation in the reference (`ndes[id]`); here all simulations are columns of one handle."""
 
-    def __init__(self, cfg: NDEConfig, T0, nde_params, true_sols=None, device: int = 0):
+    def __init__(self, cfg: NDEConfig, T0, nde_params, true_sols=None, device: int = 0,
+                 causal_penalty: Optional[Callable] = None):
+        """`causal_penalty`: the optional term of `nde_loss` (training.jl:44,57-58: `Flux.mse(...) + causal_penalty(NN)`), a
+        function of the weights alone; here a callable θ -> (value, ∂value/∂θ) since there is no Zygote to differentiate it."""
         if cfg.model not in (FREE_CONVECTION, CONVECTIVE_ADJUSTMENT_NDE):
             raise ValueError("need a free-convection config")
         self.cfg = cfg
+        self.causal_penalty = causal_penalty
         T0 = np.ascontiguousarray(T0, dtype=np.float32)
         self.n_simulations = T0.shape[0]
         self.engine = ColumnNDE(cfg, self.n_simulations, device=device)
@@ -54,10 +58,15 @@ class FreeConvectionNDE:
     def nde_loss(self, weights) -> float:
         """`Flux.mse(cat(nde_sols…), true_sols)` (training.jl:55-62)."""
         total, _ = self.engine.loss(weights, [0, 0, 1, 0, 0, 0])
+        if self.causal_penalty is not None:
+            total += float(self.causal_penalty(np.asarray(weights, dtype=np.float32))[0])
         return total
 
     def nde_loss_and_grad(self, weights):
         total, _, grad = self.engine.loss_grad(weights, [0, 0, 1, 0, 0, 0])
+        if self.causal_penalty is not None:
+            pv, pg = self.causal_penalty(np.asarray(weights, dtype=np.float32))
+            total, grad = total + float(pv), grad + np.asarray(pg, dtype=grad.dtype)
         return total, grad
 
     def close(self):

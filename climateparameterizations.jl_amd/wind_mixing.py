@@ -136,33 +136,42 @@ class WindMixingNDE:
 
 
 def train_NDE(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epochs: int = 1, maxiters: int = 500,
-              cb: Optional[Callable] = None) -> TrainResult:
-    """The optimiser loop of `train_NDE` (NDE_training.jl:340-372): for each optimiser and epoch run `maxiters`
-    iterations of {value+gradient, callback(θ, total, scaled_losses, loss_scalings), Flux.update!} and copy back
-    the best-loss θ (`res.minimizer`, :371)."""
+              cb: Optional[Callable] = None, continue_state: bool = False) -> TrainResult:
+    """The optimiser loop of `train_NDE` (NDE_training.jl:340-372): for each optimiser and epoch one
+    `res = solve(prob_loss, opt, cb=cb, maxiters=maxiters); weights .= res.minimizer`.
+
+    That `solve` is GalacticOptim 1.2.0's Flux-optimiser `__solve` (third-party, pinned in wind_mixing/Manifest.toml, absent from
+    /root/reference; restated from its published source, `tests/test_training_loops.py` holds the literal restatement):
+      * it optimises `θ = copy(prob.u0)`, and Flux's ADAM keeps its state in an IdDict keyed by that array, so every
+        (optimizer, epoch) solve starts from zero moments and βᵗ = β (`continue_state=True` carries them over instead);
+      * per iteration: loss and gradient at θ, `cb(θ, total, losses, loss_scalings)` (true = stop), `update!(opt, θ, g)`,
+        then `save_best`: if this iteration's loss is the lowest so far, `min_θ = copy(θ)` — taken AFTER the update, i.e. the
+        point one ADAM step past the best-loss point; after `maxiters` iterations θ reverts to `min_θ`."""
     theta = np.array(weights, dtype=np.float32)
     history = []
     for opt in optimizers:
         for _ in range(epochs):
+            if not continue_state:
+                opt.reset()
             best, best_theta = np.inf, theta.copy()
             for it in range(maxiters):
                 total, losses, grad = problem.grad_loss(theta)
                 history.append(dict(total=total, **losses))
-                if total < best:
-                    best, best_theta = total, theta.copy()
                 if cb is not None and cb(theta, total, losses, problem.loss_scalings):
                     break
                 opt.update(theta, grad.astype(np.float64))
+                if total < best:
+                    best, best_theta = total, theta.copy()
             theta = best_theta
     return TrainResult(theta, history)
 
 
 def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epochs: int = 1, maxiters: int = 500,
-                     process_group=None) -> TrainResult:
+                     process_group=None, continue_state: bool = False) -> TrainResult:
     """`train_NDE`'s optimiser loop (NDE_training.jl:340-372) with θ, the ADAM state and the best-loss copy resident on the
     GPU: per iteration one `colnde_loss_grad_dev`, [one SUM all-reduce of the gradient buffer when the columns are sharded
-    over `process_group`], one fused `colnde_adam_step_dev`; nothing crosses PCIe until the end.  Same update rule and
-    best-θ selection (`res.minimizer`, :371) as `train_NDE`; the per-iteration callback is not available here."""
+    over `process_group`], one fused `colnde_adam_step_dev`; nothing crosses PCIe until the end.  Same update rule, per-solve
+    state reset and `save_best` selection as `train_NDE`; the per-iteration callback is not available here."""
     import torch
     eng = problem.engine
     dev = torch.device("cuda", eng.device)
@@ -175,9 +184,11 @@ def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM]
     hist = []
     for opt in optimizers:
         for _ in range(epochs):
+            if not continue_state:
+                opt.reset()
             m = torch.zeros(n, dtype=torch.float32, device=dev)
             v = torch.zeros(n, dtype=torch.float32, device=dev)
-            if opt.m is not None:            # continue an optimiser that has state (Flux keeps it across `solve` calls)
+            if opt.m is not None:            # continue_state: the moments of the previous solve
                 m.copy_(torch.as_tensor(opt.m, dtype=torch.float32)); v.copy_(torch.as_tensor(opt.v, dtype=torch.float32))
             best = torch.full((), float("inf"), dtype=torch.float32, device=dev)
             best_theta = theta.clone()
@@ -188,12 +199,12 @@ def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM]
                     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
                 total = out[n + 6]
                 hist.append(out[n:n + 7].clone())
-                better = total < best
-                best = torch.where(better, total, best)
-                best_theta = torch.where(better, theta, best_theta)
                 eng.adam_step(theta, out, m, v, opt.eta, opt.beta, opt.eps, beta_t=tuple(opt.beta_t))
                 opt.beta_t[0] *= opt.beta[0]
                 opt.beta_t[1] *= opt.beta[1]
+                better = total < best
+                best = torch.where(better, total, best)
+                best_theta = torch.where(better, theta, best_theta)      # min_θ = copy(θ) AFTER update! (GalacticOptim save_best)
             theta = best_theta.clone()
             opt.m, opt.v = m.double().cpu().numpy(), v.double().cpu().numpy()
     H = torch.stack(hist).cpu().numpy() if hist else np.zeros((0, 7), np.float32)

@@ -69,6 +69,12 @@ def test_free_convection_mirror_and_training():
     assert np.isclose(l0, O.loss(c, O.solve(c, p.x0, p.bcs, p.weights), truth, [0, 0, 1, 0, 0, 0])[0], rtol=2e-3)
     theta, hist = train_neural_differential_equation(nde, p.weights, ADAM(1e-3), epochs=6)
     assert hist[-1] < hist[0]
+    # `causal_penalty` (training.jl:44,57-58): an extra term of the weights alone, added to value and gradient
+    _, g0 = nde.nde_loss_and_grad(p.weights)
+    nde.causal_penalty = lambda th: (0.5 * 1e-3 * float(th @ th), 1e-3 * th)
+    assert np.isclose(nde.nde_loss(p.weights), l0 + 0.5e-3 * float(p.weights @ p.weights), rtol=1e-6)
+    l1, g1 = nde.nde_loss_and_grad(p.weights)
+    np.testing.assert_allclose(g1 - g0, 1e-3 * p.weights, rtol=1e-4, atol=1e-9)
     nde.close()
 
 
