@@ -73,6 +73,7 @@ struct colnde_handle {
     int *d_bias_zoff = nullptr, *d_bias_goff = nullptr;
     bool have_problem = false, have_truth = false;
     bool prof = false;
+    int min_substeps = 1;           // least RK4 sub-steps per save interval inside the diffusive stability bound
     std::vector<PendingEvent> pending;
     double ms[K_COUNT] = {0, 0, 0, 0, 0, 0};
     int launches[K_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -109,6 +110,40 @@ static int validate(const colnde_config* c) {
     if (c->engine != COLNDE_ENGINE_AUTO && c->engine != COLNDE_ENGINE_GENERIC && c->engine != COLNDE_ENGINE_MFMA)
         return fail("unknown engine %d", c->engine);
     return 0;
+}
+
+// ---- explicit-RK4 stability (DESIGN §2 "Stiffness") ---------------------------------------------------------
+// The reference integrates these right-hand sides with a stabilised ROCK4 (wind_mixing/train_NDE.jl:143) because their vertical
+// diffusion is stiff in proportion to Nz²: the discrete Laplacian with diffusivity D (in nondimensional time) has eigenvalues down
+// to -4 D Nz².  Classical RK4 is stable on the real axis for |lambda dt| <= 2.785.  D is the largest diffusivity the configuration
+// can switch on: tau (nu0 + nu_minus) max(1, 1/Pr) / H² for the Richardson-number closure, tau kappa / H² for the
+// convective-adjustment branches (NDE_training.jl:141-143; NDE! nu_T switch, training_postprocessing.jl:118-121), C K for
+// ConvectiveAdjustmentNDE (convective_adjustment_nde.jl:43-47).  (The MLP's own Jacobian is not bounded here.)
+static double stiff_lambda(const colnde_config* c) {
+    const double Nz2 = (double)c->Nz * c->Nz;
+    double D = 0.0;
+    if (c->model == COLNDE_MODEL_WIND_MIXING) {
+        const double k = (double)c->tau / ((double)c->H * c->H);
+        if (c->modified_pacanowski_philander) {
+            D = k * ((double)c->nu0 + c->nu_minus) * fmax(1.0, 1.0 / (double)c->Pr);
+            if (c->inplace_variant && c->convective_adjustment) D = fmax(D, k * c->kappa);
+        } else if (c->convective_adjustment) {
+            D = k * c->kappa;
+        }
+    } else if (c->model == COLNDE_MODEL_CONV_ADJ_NDE) {
+        D = (double)c->sigma[5] / c->sigma[2] * ((double)c->tau / c->H) * c->ca_K;
+    }
+    return 4.0 * D * Nz2;
+}
+
+#define COLNDE_RK4_REAL_BOUND 2.785
+
+extern "C" int colnde_min_substeps(const colnde_config* c) {
+    if (validate(c)) return -1;
+    double span = 0.0;
+    for (int i = 1; i < c->n_save; i++) span = fmax(span, (double)c->save_times[i] - (double)c->save_times[i - 1]);
+    const double need = span * stiff_lambda(c) / COLNDE_RK4_REAL_BOUND;
+    return need <= 1.0 ? 1 : (int)ceil(need);
 }
 
 static void build_model(const colnde_config* c, DevModel* m, PackInfo* pk) {
@@ -222,6 +257,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     h->n_col = cfg->n_columns;
     h->n_col_total = cfg->n_columns;
     h->n_tiles = (cfg->n_columns + CT - 1) / CT;
+    h->min_substeps = colnde_min_substeps(cfg);
     build_model(cfg, &h->m, &h->pk);
     std::vector<TileDesc> tiles;
     std::vector<int> bz, bg;
@@ -545,8 +581,20 @@ static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_
 }
 
 // ---- forward solve -------------------------------------------------------------------------------------
+// A time step outside RK4's stability region gives a blown-up or NaN trajectory, loss and gradient with rc = 0: refuse it.
+static int check_stability(const colnde_handle* h) {
+    if (h->cfg.substeps >= h->min_substeps) return 0;
+    const char* e = getenv("COLNDE_ALLOW_UNSTABLE_DT");
+    if (e && atoi(e) != 0) return 0;
+    return fail("substeps = %d puts the RK4 step outside its stability region: the stiffest diffusive mode this configuration can "
+                "switch on has lambda = -%.4g (4 D Nz^2), and lambda dt must stay within %.3f — need substeps >= %d "
+                "(colnde_min_substeps; the reference uses a stabilised ROCK4 here; COLNDE_ALLOW_UNSTABLE_DT=1 overrides)",
+                h->cfg.substeps, stiff_lambda(&h->cfg), COLNDE_RK4_REAL_BOUND, h->min_substeps);
+}
+
 static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape) {
     if (!h->have_problem) return fail("colnde_set_problem has not been called");
+    if (check_stability(h)) return 1;
     if (h->use_rt) {
         // (the gradient path tapes block by block: colnde_loss_grad_dev drives rt_forward_range itself)
         hipError_t e = rt_launch_pack(h->m, d_weights, h->d_wimg, h->stream);
@@ -604,6 +652,7 @@ extern "C" int colnde_loss(colnde_handle* h, const float* weights, const float s
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int q = 0; q < 6; q++) terms[q] = o[q];
     *total = o[6];
+    if (!std::isfinite(o[6])) return fail("the loss is not finite (%g): the solve left the stable regime (time step, weights or inputs)", o[6]);
     return 0;
 }
 
@@ -708,6 +757,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
     if (!d_weights || !scalings || !d_out) return fail("null pointer argument");
     if (!h->have_truth) return fail("no truth trajectories: pass truth to colnde_set_problem");
     if (h->m.inplace) return fail("the in-place NDE! variant is an evaluation RHS; gradients use the training RHS (inplace_variant = 0)");
+    if (check_stability(h)) return 1;
     HIPCHK(hipSetDevice(h->device));
     const int stride = h->m.n_params + 8;
     if (h->use_rt) {
@@ -829,6 +879,7 @@ extern "C" int colnde_loss_grad(colnde_handle* h, const float* weights, const fl
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int q = 0; q < 6; q++) terms[q] = o[q];
     *total = o[6];
+    if (!std::isfinite(o[6])) return fail("the loss is not finite (%g): the solve left the stable regime (time step, weights or inputs)", o[6]);
     return 0;
 }
 

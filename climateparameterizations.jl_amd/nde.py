@@ -34,6 +34,15 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def min_substeps(cfg: NDEConfig) -> int:
+    """`colnde_min_substeps`: the least RK4 sub-steps per save interval inside the diffusive stability bound (no GPU needed)."""
+    c, keep = to_c_config(cfg, 1, 0, 0)
+    n = _lib.lib().colnde_min_substeps(ctypes.byref(c))
+    if n < 0:
+        raise _lib.ColndeError(_lib.lib().colnde_last_error().decode("utf-8", "replace"))
+    return int(n)
+
+
 class ColumnNDE:
     def __init__(self, cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0):
         cfg.validate()

@@ -71,6 +71,14 @@ typedef struct colnde_handle colnde_handle;
 const char* colnde_last_error(void);
 int colnde_version(void);
 
+/* Least `substeps` for which the classical-RK4 step stays inside its stability region (|lambda dt| <= 2.785) for the stiffest
+ * diffusive mode the configuration can switch on: lambda = -4 D Nz^2 with D = tau (nu0 + nu_minus) max(1, 1/Pr) / H^2
+ * (Richardson closure), tau kappa / H^2 (convective-adjustment branches) or (sigma_wT/sigma_T)(tau/H) ca_K
+ * (ConvectiveAdjustmentNDE).  The reference sidesteps this with ROCK4 (wind_mixing/train_NDE.jl:143).  colnde_forward / _loss /
+ * _loss_grad refuse a configuration below it (instead of returning a blown-up solve with rc = 0) unless
+ * COLNDE_ALLOW_UNSTABLE_DT=1; colnde_rhs is not affected.  Returns -1 on an invalid configuration.  No GPU needed. */
+int  colnde_min_substeps(const colnde_config* cfg);
+
 int  colnde_create(const colnde_config* cfg, colnde_handle** out);
 void colnde_destroy(colnde_handle* h);
 int  colnde_n_params(const colnde_handle* h);

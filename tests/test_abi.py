@@ -85,3 +85,23 @@ def test_adam_matches_flux_update_rule():
     opt.update(th, g)
     # first step of ADAM: Δ = η · g/(|g| + ϵ') ≈ η·sign(g)
     np.testing.assert_allclose(th, [1.0 - 1e-2, -2.0 + 1e-2], rtol=1e-6)
+
+
+def test_min_substeps_is_the_rk4_diffusive_bound():
+    """colnde_min_substeps (no GPU): lambda = 4 D Nz^2, dt = widest save interval / substeps, |lambda dt| <= 2.785."""
+    import colnde
+    from colnde import synthetic
+    p = synthetic.wind_mixing_problem(1, n_frames=3)                         # bench workload: nu = 0.1001, tau = 172800, H = 256
+    lam = 4 * 172800 * 0.1001 / 256 ** 2 * 32 ** 2
+    assert colnde.min_substeps(p.cfg) == int(np.ceil(lam / 288 / 2.785)) == 2
+    assert colnde.min_substeps(p.cfg.with_(nu_minus=0.0, nu0=1e-4)) == 1
+    # kappa = 10 (the reference default) in the convective-adjustment branches: the ~130 sub-steps per frame ADVICE r1 quotes
+    ca = p.cfg.with_(modified_pacanowski_philander=False, zero_weights=False, convective_adjustment=True)
+    assert colnde.min_substeps(ca) == int(np.ceil(4 * 172800 * 10 / 256 ** 2 * 1024 / 288 / 2.785)) == 135
+    assert colnde.min_substeps(p.cfg.with_(inplace_variant=True, convective_adjustment=True)) == 135
+    # ConvectiveAdjustmentNDE, K = 10, C = 0.5, 64 levels, config 4's axis: 128 intervals over [0, 1]
+    fc = synthetic.free_convection_problem(1, Nz=64, n_save=129, convective_adjustment=True).cfg
+    assert colnde.min_substeps(fc) == int(np.ceil(4 * 0.5 * 10 * 64 ** 2 / 128 / 2.785)) == 230
+    assert colnde.min_substeps(synthetic.free_convection_problem(1, Nz=64, n_save=129).cfg) == 1
+    # a non-uniform axis is judged by its widest interval
+    assert colnde.min_substeps(p.cfg.with_(save_times=(0.0, 0.001, 0.011))) == int(np.ceil(lam * 0.01 / 2.785))

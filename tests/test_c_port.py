@@ -34,7 +34,7 @@ def test_c_forward_inplace_matches_numpy(name):
 
 @pytest.mark.parametrize("ca", [False, True])
 def test_c_free_convection_matches_numpy(ca):
-    p = synthetic.free_convection_problem(4, Nz=32, n_save=5, substeps=16 if ca else 2, convective_adjustment=ca, t_end=0.01)
+    p = synthetic.free_convection_problem(4, Nz=32, n_save=5, substeps=20 if ca else 2, convective_adjustment=ca, t_end=0.01)
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth)
     sc = O.default_loss_scalings(p.cfg)
     tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)

@@ -75,6 +75,24 @@ def test_forward_inplace_variant(name):
         assert np.abs(plain - sol).max() > 100 * SOL_ATOL
 
 
+def test_time_step_outside_rk4_stability_is_refused():
+    """kappa = 10 (the reference default) in the convective-adjustment branch needs 135 RK4 sub-steps per 10-minute frame; with 2
+    the solve would blow up and come back with rc = 0.  colnde_forward / _loss / _loss_grad refuse it and say what is needed;
+    colnde_rhs (no time stepping) still answers; COLNDE_ALLOW_UNSTABLE_DT=1 is the explicit override."""
+    p = synthetic.wind_mixing_problem(5, n_frames=3, weight_divisor=1e2, **VARIANTS["conv_adj_branch"])
+    cfg = p.cfg.with_(kappa=10.0)
+    assert colnde.min_substeps(cfg) == 135
+    with colnde.ColumnNDE(cfg, 5) as nde:
+        nde.set_problem(p.x0, p.bcs, np.zeros((5, 3, 96), np.float32))
+        assert np.isfinite(nde.rhs(p.x0, p.weights, p.bcs, 0.0)).all()
+        for call in (lambda: nde.forward(p.weights), lambda: nde.loss(p.weights, [1] * 6), lambda: nde.loss_grad(p.weights, [1] * 6)):
+            with pytest.raises(colnde.ColndeError, match="substeps >= 135"):
+                call()
+    with colnde.ColumnNDE(cfg.with_(substeps=135), 5) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        assert np.isfinite(nde.forward(p.weights)).all()
+
+
 @pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "smooth_NN", "smooth_Ri", "diurnal",
                                   "conv_adj_branch", "swish"])
 def test_forward_loss_grad_wind_mixing(name):
@@ -97,7 +115,7 @@ def test_forward_loss_grad_wind_mixing(name):
 
 @pytest.mark.parametrize("Nz,ca", [(32, False), (32, True), (64, False)])
 def test_free_convection(Nz, ca):
-    p = synthetic.free_convection_problem(19, Nz=Nz, n_save=5, substeps=16 if ca else 2,
+    p = synthetic.free_convection_problem(19, Nz=Nz, n_save=5, substeps=20 if ca else 2,
                                           convective_adjustment=ca, t_end=0.01)
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
     sc = O.default_loss_scalings(p.cfg)
@@ -139,7 +157,7 @@ def test_tile16_taped_weight_gradients(case, monkeypatch):
         sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
     else:
         ca = case.endswith("_ca")
-        p = synthetic.free_convection_problem(37, Nz=64 if "64" in case else 32, n_save=5, substeps=16 if ca else 2,
+        p = synthetic.free_convection_problem(37, Nz=64 if "64" in case else 32, n_save=5, substeps=20 if ca else 2,
                                               convective_adjustment=ca, t_end=0.01)
         sc = O.default_loss_scalings(p.cfg)
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
