@@ -44,7 +44,7 @@ def main():
          [1.0, 1.0, 1.0, 5e-3, 5e-3, 5e-3])
     # free convection, Nz = 32 (32-128-128-31 relu) and the convective-adjustment NDE
     save("free_convection_32", synthetic.free_convection_problem(3, Nz=32, n_save=5, substeps=2, t_end=0.02), [0, 0, 1.0, 0, 0, 0])
-    save("conv_adj_nde_32", synthetic.free_convection_problem(3, Nz=32, n_save=5, substeps=16, t_end=0.01,
+    save("conv_adj_nde_32", synthetic.free_convection_problem(3, Nz=32, n_save=5, substeps=20, t_end=0.01,
                                                               convective_adjustment=True), [0, 0, 1.0, 0, 0, 0])
     cfg, T, top, w = synthetic.inference_problem(6, 5)
     np.savez_compressed(os.path.join(HERE, "infer_forcing_32.npz"), T=T, top_flux=top, weights=w, Lz=np.float64(1000.0),

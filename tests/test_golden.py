@@ -16,7 +16,7 @@ CASES = {
     "wind_mixing_diurnal_smooth": lambda: synthetic.wind_mixing_problem(3, n_frames=5, weight_divisor=1e2, diurnal=True,
                                                                        smooth_NN=True, smooth_Ri=True),
     "free_convection_32": lambda: synthetic.free_convection_problem(3, Nz=32, n_save=5, substeps=2, t_end=0.02),
-    "conv_adj_nde_32": lambda: synthetic.free_convection_problem(3, Nz=32, n_save=5, substeps=16, t_end=0.01,
+    "conv_adj_nde_32": lambda: synthetic.free_convection_problem(3, Nz=32, n_save=5, substeps=20, t_end=0.01,
                                                                  convective_adjustment=True),
 }
 
