@@ -438,7 +438,7 @@ def test_tile16_untuned_shapes(model, Nz, hidden, acts, ncol, mode, monkeypatch)
     if model == "wm":
         sizes = (3 * Nz,) + tuple(hidden) + (Nz - 1,)
         p = synthetic.wind_mixing_problem(ncol, Nz=Nz, n_frames=5, weight_divisor=1e2, layer_sizes=sizes,
-                                          activations=tuple(acts) + ("identity",))
+                                          activations=tuple(acts) + ("identity",), substeps=4 if Nz > 32 else 2)  # 48 levels: min_substeps = 3
         sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
     else:
         sizes = (Nz,) + tuple(hidden) + (Nz - 1,)
