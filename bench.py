@@ -128,11 +128,18 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (colnde has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or os.environ.get("COLNDE_BENCH_FORCE_DIST"):   # the env var exercises the RCCL path with one rank
-        import torch.distributed as dist
+    # The exchange step goes through the C ABI's own RCCL communicator (colnde_comm_*, what a Julia host would call);
+    # COLNDE_BENCH_COMM=torch selects torch.distributed's backend "nccl" (= RCCL) instead.  COLNDE_BENCH_FORCE_DIST exercises the
+    # path with one rank.
+    dist = comm = None
+    if world > 1 or os.environ.get("COLNDE_BENCH_FORCE_DIST"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("COLNDE_BENCH_COMM", "colnde") == "torch":
+            import torch.distributed as dist
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            from colnde.distributed import bootstrap_comm
+            comm = bootstrap_comm(rank, world, local_rank)
 
     ncol = args.columns
     # each rank generates only its shard of the global synthetic suite (seeded per rank: independent columns)
@@ -154,15 +161,32 @@ def main():
     nde.set_problem(x0, bcs, truth)
     out = torch.empty(nde.n_params + 8, dtype=torch.float32, device=dev)
 
+    sync_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+
     def step():
         nde.loss_grad(w, scal, out=out)
-        if dist is not None:
+        if comm is not None:
+            comm.allreduce_result(nde, out)
+        elif dist is not None:
             dist.all_reduce(out, op=dist.ReduceOp.SUM)
 
     def barrier():
-        if dist is not None:
+        if comm is not None:
+            comm.allreduce(sync_buf, "sum")          # every rank arrives before any leaves
+        elif dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if comm is None and dist is None:
+            return x
+        te = torch.tensor([x], dtype=torch.float32, device=dev)
+        if comm is not None:
+            comm.allreduce(te, "max")
+        else:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        return float(te.item())
 
     for _ in range(args.warmup):
         step()
@@ -173,11 +197,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     ms_fwd, n_fwd = nde.kernel_time("forward")
     ms_adj, n_adj = nde.kernel_time("adjoint")
     ms_red, n_red = nde.kernel_time("reduce")
@@ -189,11 +209,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed_plain = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed_plain], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed_plain = float(te.item())
+    elapsed_plain = max_over_ranks(time.perf_counter() - t0)
     res = out.cpu().numpy()
 
     if rank == 0:
@@ -233,6 +249,8 @@ def main():
                             "3 x (96-50-20-31 mish), six-term loss" % (ncol, cfg.Nz, args.frames, cfg.substeps),
                 "columns_per_gpu": ncol, "levels": cfg.Nz, "frames": args.frames, "substeps": cfg.substeps,
                 "rk4_steps": cfg.n_steps, "n_params": cfg.n_params, "parallelism": "columns sharded x%d" % world,
+                "exchange": "none (one rank)" if (comm is None and dist is None) else
+                            ("colnde_comm (RCCL behind the C ABI)" if comm is not None else "torch.distributed nccl (RCCL)"),
             },
             "roofline": {
                 "kernel": "rt_adjoint_kernel" if regtile else "adjoint_kernel", "bound": "mfma",
@@ -265,6 +283,9 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     nde.close()
+    if comm is not None:
+        barrier()
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -41,6 +41,13 @@ SYMBOLS = [
     ("colnde_coarse_grain_dev", ctypes.c_int, [_V, _V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _V]),
     ("colnde_zscore_stats_dev", ctypes.c_int, [_V, _V, ctypes.c_int64, _V]),
     ("colnde_scale_dev", ctypes.c_int, [_V, _V, ctypes.c_int64, _V, _V]),
+    ("colnde_comm_unique_id", ctypes.c_int, [_V]),
+    ("colnde_comm_create", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _V, ctypes.c_int, ctypes.POINTER(_V)]),
+    ("colnde_comm_destroy", None, [_V]),
+    ("colnde_comm_rank", ctypes.c_int, [_V]),
+    ("colnde_comm_size", ctypes.c_int, [_V]),
+    ("colnde_comm_allreduce_dev", ctypes.c_int, [_V, _V, ctypes.c_int64, ctypes.c_int, _V]),
+    ("colnde_allreduce_result_dev", ctypes.c_int, [_V, _V, _V]),
     ("colnde_plan", ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int)]),
     ("colnde_set_profiling", ctypes.c_int, [_V, ctypes.c_int]),
     ("colnde_kernel_time", ctypes.c_int, [_V, ctypes.c_int, _F, ctypes.POINTER(ctypes.c_int)]),

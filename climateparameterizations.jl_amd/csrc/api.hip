@@ -26,6 +26,9 @@ static int fail(const char* fmt, ...) {
     return 1;
 }
 
+// shared with comm.hip (not part of the public header)
+extern "C" int colnde_internal_set_error(const char* msg) { g_err = msg ? msg : "error"; return 1; }
+
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -1000,6 +1003,13 @@ extern "C" int colnde_scale_dev(colnde_handle* h, const float* d_x, int64_t coun
     hipError_t e = launch_zscore_scale(d_x, (long)count, d_mu_sigma, d_out, h->stream);
     if (e != hipSuccess) return fail("scale launch failed: %s", hipGetErrorString(e));
     return 0;
+}
+
+// [grad; terms; total; 0] of this rank summed over the communicator, on the handle's stream (comm.hip)
+extern "C" int colnde_comm_allreduce_dev(colnde_comm* c, float* d_buf, int64_t n, int op, void* hip_stream);
+extern "C" int colnde_allreduce_result_dev(colnde_handle* h, colnde_comm* comm, float* d_out) {
+    if (!h || !comm || !d_out) return fail("null argument");
+    return colnde_comm_allreduce_dev(comm, d_out, (int64_t)h->m.n_params + 8, 0, (void*)h->stream);
 }
 
 extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {

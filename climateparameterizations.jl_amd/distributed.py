@@ -7,7 +7,11 @@ the CPU tests).  The reference has no distributed code; this is the MI355X-nativ
 """
 from __future__ import annotations
 
-from typing import Tuple
+import ctypes
+import os
+from typing import Optional, Tuple
+
+from . import _lib
 
 
 def shard_columns(n_total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -31,3 +35,66 @@ def allreduce_loss_grad(buf, group=None):
 def split_result(buf, n_params: int):
     """(total, terms[6], grad) from the result buffer."""
     return float(buf[n_params + 6]), buf[n_params:n_params + 6], buf[:n_params]
+
+
+class Comm:
+    """`colnde_comm`: RCCL behind the C ABI (include/colnde.h), for hosts that do not carry torch.distributed — what a Julia
+    deployment calls.  One per process (= per GPU)."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes, device: int = 0):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        self._L = _lib.lib()
+        self._c = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        _lib.check(self._L.colnde_comm_create(int(rank), int(world), buf, int(device), ctypes.byref(self._c)))
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib().colnde_comm_unique_id(buf))
+        return buf.raw
+
+    def allreduce(self, tensor, op: str = "sum", stream_ptr: Optional[int] = None):
+        """In place on a contiguous float32 device tensor, enqueued on torch's current stream (or `stream_ptr`)."""
+        import torch
+        if tensor.dtype != torch.float32 or not tensor.is_contiguous() or not tensor.is_cuda:
+            raise ValueError("need a contiguous float32 device tensor")
+        if stream_ptr is None:
+            stream_ptr = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.colnde_comm_allreduce_dev(self._c, ctypes.c_void_p(tensor.data_ptr()), tensor.numel(),
+                                                     {"sum": 0, "max": 1}[op], ctypes.c_void_p(stream_ptr)))
+        return tensor
+
+    def allreduce_result(self, nde, out):
+        """The [n_params + 8] result buffer of `nde.loss_grad(..., out=out)`, summed over the ranks on the handle's stream."""
+        _lib.check(self._L.colnde_allreduce_result_dev(nde._h, self._c, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._L.colnde_comm_destroy(self._c)
+            self._c = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bootstrap_comm(rank: int, world: int, device: int, key: str = "colnde_uid") -> Comm:
+    """Rank 0 makes the RCCL unique id and publishes it through the launcher's TCP store (MASTER_ADDR / MASTER_PORT, as
+    torch.distributed's env:// rendezvous uses it: every rank a client when torchrun hosts the store, rank 0 the server
+    otherwise); every rank then joins.  Host-side bytes only — no process group, no collective through torch."""
+    from datetime import timedelta
+    from torch.distributed import TCPStore
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
+    store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300), multi_tenant=True)
+    if rank == 0:
+        store.set(key, Comm.unique_id())
+    uid = bytes(store.get(key))
+    return Comm(rank, world, uid, device)

@@ -108,7 +108,7 @@ def convective_adjustment(engine: ColumnNDE, T_interior, dt: float, K: float, dz
     return engine.convective_adjustment(T2, dt, dz, K, hb, ht).reshape(shape)
 
 
-def train_neural_differential_equation_device(nde: FreeConvectionNDE, weights, opt: ADAM, epochs: int, process_group=None):
+def train_neural_differential_equation_device(nde: FreeConvectionNDE, weights, opt: ADAM, epochs: int, process_group=None, comm=None):
     """`Flux.train!` (training.jl:71) with θ and the ADAM state resident on the GPU: per epoch one `colnde_loss_grad_dev`,
     [one SUM all-reduce when the simulations are sharded over `process_group`], one fused `colnde_adam_step_dev`.
     Returns (θ, loss history) like `train_neural_differential_equation`; the per-epoch callback is not available here."""
@@ -125,7 +125,9 @@ def train_neural_differential_equation_device(nde: FreeConvectionNDE, weights, o
     hist = []
     for _ in range(epochs):
         eng.loss_grad(theta, [0, 0, 1, 0, 0, 0], out=out)
-        if process_group is not None:
+        if comm is not None:
+            comm.allreduce_result(eng, out)
+        elif process_group is not None:
             import torch.distributed as dist
             dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
         hist.append(out[n + 6].clone())

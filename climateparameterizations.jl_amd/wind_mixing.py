@@ -167,7 +167,7 @@ def train_NDE(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epoch
 
 
 def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epochs: int = 1, maxiters: int = 500,
-                     process_group=None, continue_state: bool = False) -> TrainResult:
+                     process_group=None, continue_state: bool = False, comm=None) -> TrainResult:
     """`train_NDE`'s optimiser loop (NDE_training.jl:340-372) with θ, the ADAM state and the best-loss copy resident on the
     GPU: per iteration one `colnde_loss_grad_dev`, [one SUM all-reduce of the gradient buffer when the columns are sharded
     over `process_group`], one fused `colnde_adam_step_dev`; nothing crosses PCIe until the end.  Same update rule, per-solve
@@ -194,7 +194,9 @@ def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM]
             best_theta = theta.clone()
             for it in range(maxiters):
                 eng.loss_grad(theta, sc, out=out)
-                if process_group is not None:
+                if comm is not None:                       # colnde.distributed.Comm: RCCL behind the C ABI
+                    comm.allreduce_result(eng, out)
+                elif process_group is not None:
                     import torch.distributed as dist
                     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
                 total = out[n + 6]

@@ -157,6 +157,24 @@ int colnde_coarse_grain_dev(colnde_handle* h, const float* d_in, int n_rows, int
 int colnde_zscore_stats_dev(colnde_handle* h, const float* d_x, int64_t count, float* d_mu_sigma);
 int colnde_scale_dev(colnde_handle* h, const float* d_x, int64_t count, const float* d_mu_sigma, float* d_out);
 
+/* ---- multi-GPU: the path's one exchange step, over RCCL (xGMI inside a node) -----------------------------------
+ * One process per GPU, columns sharded over the ranks (each handle normalises by colnde_set_global_columns); per optimiser
+ * iteration every rank SUM-all-reduces its result buffer [grad(n_params); 6 terms; total; 0] and then applies the identical
+ * ADAM step.  The reference has no distributed code: nothing is replaced here, the reference's serial comprehension over
+ * simulations (NDE_training.jl:291,304) is what gets sharded.  RCCL is bound lazily (dlopen): these calls fail with a message
+ * on a box without it.  Bootstrap: rank 0 calls colnde_comm_unique_id and hands the 128 bytes to every rank through any host
+ * channel (MPI, a file, a TCP store); every rank then calls colnde_comm_create, which returns once all ranks have joined. */
+typedef struct colnde_comm colnde_comm;
+int  colnde_comm_unique_id(void* out128);
+int  colnde_comm_create(int rank, int nranks, const void* unique_id128, int device, colnde_comm** out);
+void colnde_comm_destroy(colnde_comm* c);
+int  colnde_comm_rank(const colnde_comm* c);
+int  colnde_comm_size(const colnde_comm* c);
+/* in-place all-reduce of n device floats, enqueued on hip_stream (not synchronised); op 0 = sum, 1 = max */
+int  colnde_comm_allreduce_dev(colnde_comm* c, float* d_buf, int64_t n, int op, void* hip_stream);
+/* the result buffer of colnde_loss_grad_dev (n_params + 8 floats), summed over the communicator on the handle's stream */
+int  colnde_allreduce_result_dev(colnde_handle* h, colnde_comm* comm, float* d_out);
+
 /* How the handle runs its gradient path (filled in by the first colnde_loss_grad[_dev]; zeros before that):
  * info[0] engine (COLNDE_ENGINE_*), [1] columns per block of the gradient path (the tapes hold one block), [2] number of blocks, [3] regtile: layer-1
  * pre-activations taped (1) or recomputed (0), [4] tile16: weight gradients taped (1) or accumulated in registers (0),
