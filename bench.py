@@ -134,12 +134,26 @@ def main():
     dist = comm = None
     if world > 1 or os.environ.get("COLNDE_BENCH_FORCE_DIST"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("COLNDE_BENCH_COMM", "colnde") == "torch":
-            import torch.distributed as dist
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            from colnde.distributed import bootstrap_comm
-            comm = bootstrap_comm(rank, world, local_rank)
+        # RCCL prints a version banner on stdout when a communicator comes up; stdout carries the ONE JSON line, so the
+        # banner goes to stderr (file-descriptor level: the print comes from native code)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if os.environ.get("COLNDE_BENCH_COMM", "colnde") == "torch":
+                import torch.distributed as dist
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()
+            else:
+                from colnde.distributed import bootstrap_comm
+                comm = bootstrap_comm(rank, world, local_rank)
+                warm = torch.zeros(1, dtype=torch.float32, device=dev)
+                comm.allreduce(warm, "sum")
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     ncol = args.columns
     # each rank generates only its shard of the global synthetic suite (seeded per rank: independent columns)
