@@ -6,5 +6,5 @@ from .config import (NDEConfig, ZeroMeanUnitVarianceScaling, WIND_MIXING, FREE_C
                      CONVECTIVE_ADJUSTMENT_NDE)
 from . import flux_compat, synthetic
 from ._lib import ColndeError, build as build_extension, LIB_PATH
-from .nde import ColumnNDE, min_substeps
+from .nde import ColumnNDE, min_substeps, rkc_stages
 from . import distributed, wind_mixing, free_convection

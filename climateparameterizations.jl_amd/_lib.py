@@ -17,6 +17,7 @@ SYMBOLS = [
     ("colnde_last_error", ctypes.c_char_p, []),
     ("colnde_version", ctypes.c_int, []),
     ("colnde_min_substeps", ctypes.c_int, [_V]),
+    ("colnde_rkc_stages", ctypes.c_int, [_V]),
     ("colnde_create", ctypes.c_int, [_V, ctypes.POINTER(_V)]),
     ("colnde_destroy", None, [_V]),
     ("colnde_n_params", ctypes.c_int, [_V]),

@@ -26,6 +26,7 @@ ACT_IDS = {"identity": 0, "relu": 1, "mish": 2, "swish": 3, "tanh": 4, "leakyrel
 ACT_NAMES = {v: k for k, v in ACT_IDS.items()}
 
 COLNDE_MAX_LAYERS = 8
+STEPPER_IDS = {"rk4": 0, "rkc2": 1}      # colnde.h: COLNDE_STEPPER_*
 
 
 @dataclass(frozen=True)
@@ -93,6 +94,14 @@ class NDEConfig:
     # classical-RK4 sub-steps per save interval
     save_times: Tuple[float, ...] = (0.0, 1.0)
     substeps: int = 2
+    # time stepper: "rk4" (classical, `substeps` per save interval) or "rkc2" (stabilised second-order Runge-Kutta-Chebyshev for the
+    # stiff variants, `substeps` steps of `rkc_stages` stages each; 0 = the least stage count whose stability interval covers the
+    # stiffest diffusive mode, colnde_rkc_stages)
+    stepper: str = "rk4"
+    rkc_stages: int = 0
+    # oracle-only diagnostic (tests/test_oracle.py::test_rkc2_switch_pullback): pull the convective-adjustment switch back stage
+    # by stage — the exact discrete adjoint of the RKC recurrence, unbounded on switching right-hand sides; the product never does
+    rkc_exact_switch_pullback: bool = False
 
     # ---- derived -------------------------------------------------------
     @property
@@ -150,6 +159,10 @@ class NDEConfig:
             if self.zero_weights and not self.modified_pacanowski_philander:
                 # NDE_training.jl:192-194
                 raise ValueError("zero_weights requires modified_pacanowski_philander")
+        if self.stepper not in ("rk4", "rkc2"):
+            raise ValueError("stepper must be 'rk4' or 'rkc2'")
+        if self.rkc_stages != 0 and not (2 <= self.rkc_stages <= 256):
+            raise ValueError("rkc_stages must be 0 (automatic) or 2..256")
         if self.n_save < 2 or self.substeps < 1:
             raise ValueError("need >= 2 save times and >= 1 substep")
         if self.Nz < 4 or self.Nz > 128:
@@ -188,6 +201,8 @@ class CConfig(ctypes.Structure):
         ("n_columns", ctypes.c_int32),
         ("device", ctypes.c_int32),
         ("engine", ctypes.c_int32),
+        ("stepper", ctypes.c_int32),
+        ("rkc_stages", ctypes.c_int32),
     ]
 
 
@@ -212,4 +227,5 @@ def to_c_config(cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0
     c.n_save, c.substeps = cfg.n_save, cfg.substeps
     c.save_times = times.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
     c.n_columns, c.device, c.engine = int(n_columns), int(device), int(engine)
+    c.stepper, c.rkc_stages = STEPPER_IDS[cfg.stepper], int(cfg.rkc_stages)
     return c, times

@@ -77,6 +77,7 @@ struct colnde_handle {
     bool have_problem = false, have_truth = false;
     bool prof = false;
     int min_substeps = 1;           // least RK4 sub-steps per save interval inside the diffusive stability bound
+    float* d_rkc = nullptr;         // RKC2 coefficient table (DevModel::rkc)
     std::vector<PendingEvent> pending;
     double ms[K_COUNT] = {0, 0, 0, 0, 0, 0};
     int launches[K_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -112,6 +113,8 @@ static int validate(const colnde_config* c) {
     if (c->n_columns < 1) return fail("n_columns must be >= 1");
     if (c->engine != COLNDE_ENGINE_AUTO && c->engine != COLNDE_ENGINE_GENERIC && c->engine != COLNDE_ENGINE_MFMA)
         return fail("unknown engine %d", c->engine);
+    if (c->stepper != COLNDE_STEPPER_RK4 && c->stepper != COLNDE_STEPPER_RKC2) return fail("unknown stepper %d", c->stepper);
+    if (c->rkc_stages != 0 && (c->rkc_stages < 2 || c->rkc_stages > 256)) return fail("rkc_stages = %d outside 2..256 (0 = automatic)", c->rkc_stages);
     return 0;
 }
 
@@ -141,10 +144,62 @@ static double stiff_lambda(const colnde_config* c) {
 
 #define COLNDE_RK4_REAL_BOUND 2.785
 
-extern "C" int colnde_min_substeps(const colnde_config* c) {
-    if (validate(c)) return -1;
+// ---- RKC2 (Sommeijer, Shampine, Verwer 1998, eqs. 2.1-2.8; damping eps = 2/13) ------------------------------------------------
+//   Y_0 = y,  Y_1 = Y_0 + mu~_1 h F_0,  Y_j = (1 - mu_j - nu_j) Y_0 + mu_j Y_{j-1} + nu_j Y_{j-2} + mu~_j h F_{j-1} + gamma~_j h F_0
+// tab = [5][s + 1]: mu, nu, mu~, gamma~, c; returns the real stability boundary beta(s).
+static double rkc_tables(int s, std::vector<double>* tab) {
+    const double eps = 2.0 / 13.0, w0 = 1.0 + eps / ((double)s * s);
+    std::vector<double> T(s + 1, 0.0), dT(s + 1, 0.0), d2T(s + 1, 0.0), b(s + 1, 0.0);
+    T[0] = 1.0; T[1] = w0; dT[1] = 1.0;
+    for (int j = 2; j <= s; j++) {
+        T[j] = 2 * w0 * T[j - 1] - T[j - 2];
+        dT[j] = 2 * T[j - 1] + 2 * w0 * dT[j - 1] - dT[j - 2];
+        d2T[j] = 4 * dT[j - 1] + 2 * w0 * d2T[j - 1] - d2T[j - 2];
+    }
+    const double w1 = dT[s] / d2T[s];
+    for (int j = 2; j <= s; j++) b[j] = d2T[j] / (dT[j] * dT[j]);
+    b[0] = b[1] = b[2];
+    if (tab) {
+        tab->assign((size_t)5 * (s + 1), 0.0);
+        double* mu = tab->data(), *nu = mu + (s + 1), *mut = nu + (s + 1), *gat = mut + (s + 1), *c = gat + (s + 1);
+        mut[1] = b[1] * w1;
+        c[1] = mut[1];
+        for (int j = 2; j <= s; j++) {
+            mu[j] = 2 * b[j] * w0 / b[j - 1];
+            nu[j] = -b[j] / b[j - 2];
+            mut[j] = 2 * b[j] * w1 / b[j - 1];
+            gat[j] = -(1.0 - b[j - 1] * T[j - 1]) * mut[j];
+            c[j] = w1 * d2T[j] / dT[j];
+        }
+    }
+    return (w0 + 1.0) * d2T[s] / dT[s];
+}
+
+#define COLNDE_RKC_SAFETY 0.9
+
+static double widest_interval(const colnde_config* c) {
     double span = 0.0;
     for (int i = 1; i < c->n_save; i++) span = fmax(span, (double)c->save_times[i] - (double)c->save_times[i - 1]);
+    return span;
+}
+
+extern "C" int colnde_rkc_stages(const colnde_config* c) {
+    if (validate(c)) return -1;
+    if (c->rkc_stages) return c->rkc_stages;
+    const double z = stiff_lambda(c) * widest_interval(c) / c->substeps;
+    int s = 2;
+    while (s < 256 && COLNDE_RKC_SAFETY * rkc_tables(s, nullptr) < z) s++;
+    return s;
+}
+
+extern "C" int colnde_min_substeps(const colnde_config* c) {
+    if (validate(c)) return -1;
+    const double span = widest_interval(c);
+    if (c->stepper == COLNDE_STEPPER_RKC2) {          // s stages cover lambda dt <= 0.9 beta(s); at most 256 stages per step
+        const int s = c->rkc_stages ? c->rkc_stages : 256;
+        const double need = span * stiff_lambda(c) / (COLNDE_RKC_SAFETY * rkc_tables(s, nullptr));
+        return need <= 1.0 ? 1 : (int)ceil(need);
+    }
     const double need = span * stiff_lambda(c) / COLNDE_RK4_REAL_BOUND;
     return need <= 1.0 ? 1 : (int)ceil(need);
 }
@@ -262,6 +317,25 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     h->n_tiles = (cfg->n_columns + CT - 1) / CT;
     h->min_substeps = colnde_min_substeps(cfg);
     build_model(cfg, &h->m, &h->pk);
+    h->m.nst = 4;
+    h->m.rkc = nullptr;
+    if (cfg->stepper == COLNDE_STEPPER_RKC2) {
+        const int s = colnde_rkc_stages(cfg);
+        std::vector<double> tab;
+        rkc_tables(s, &tab);
+        std::vector<float> ft((size_t)6 * RKC_LD, 0.0f);
+        for (int q = 0; q < 5; q++)
+            for (int j = 0; j <= s; j++) ft[(size_t)q * RKC_LD + j] = (float)tab[(size_t)q * (s + 1) + j];
+        // 1 - mu_j - nu_j (~ 1/s^2: formed in double — in float32 the cancellation would cost four digits of the Y_0 weight)
+        for (int j = 0; j <= s; j++) ft[(size_t)5 * RKC_LD + j] = (float)(1.0 - tab[j] - tab[(size_t)(s + 1) + j]);
+        if (hipMalloc((void**)&h->d_rkc, ft.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(h->d_rkc, ft.data(), ft.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            delete h;
+            return fail("allocating the RKC coefficient table failed");
+        }
+        h->m.nst = s;
+        h->m.rkc = h->d_rkc;
+    }
     std::vector<TileDesc> tiles;
     std::vector<int> bz, bg;
     build_tables(h->m, &tiles, &bz, &bg);
@@ -299,12 +373,12 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     // AUTO: regtile where it applies, except for small problems (< 4,096 columns), which are latency points — one wavefront per
     // SIMD at most — where tile16's eight cooperating waves per 16-column tile finish a gradient sooner (8 columns x 576 steps:
     // 66 vs 83 ms per iteration)
-    h->use_rt = rt_supported(h->m) && cfg->engine != COLNDE_ENGINE_GENERIC &&
+    h->use_rt = rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine != COLNDE_ENGINE_GENERIC &&
                 (cfg->engine == COLNDE_ENGINE_MFMA || cfg->n_columns >= 4096 || !h->geo_ok);
     h->rt_fwd32 = h->use_rt && rt_forward_is32();
     if (cfg->engine == COLNDE_ENGINE_MFMA && !h->use_rt) {
         delete h;
-        return fail("engine = regtile requested, but it covers only Nz=32, three 96-50-20-31 nets, no smoothing, training RHS");
+        return fail("engine = regtile requested, but it covers only Nz=32, three 96-50-20-31 nets, no smoothing, training RHS, RK4");
     }
     const DevModel& m = h->m;
 #define ALLOC(ptr, n, T)                                                                   \
@@ -356,7 +430,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     (void)hipSetDevice(h->device);
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
-                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape};
+                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -570,7 +644,7 @@ static int rt_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int 
 static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape, int c0, int nc) {
     const size_t ns = h->m.ns;
     if (with_tape && !h->d_tape) {     // in-register gradient mode: the whole problem's stage tape
-        const size_t n = (size_t)h->n_tiles * (h->cfg.n_save - 1) * h->cfg.substeps * 4 * CT * ns;
+        const size_t n = (size_t)h->n_tiles * (h->cfg.n_save - 1) * h->cfg.substeps * h->m.nst * CT * ns;
         hipError_t e = hipMalloc((void**)&h->d_tape, n * sizeof(float));
         if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tape failed: %s", n * sizeof(float), hipGetErrorString(e));
     }
@@ -589,6 +663,10 @@ static int check_stability(const colnde_handle* h) {
     if (h->cfg.substeps >= h->min_substeps) return 0;
     const char* e = getenv("COLNDE_ALLOW_UNSTABLE_DT");
     if (e && atoi(e) != 0) return 0;
+    if (h->cfg.stepper == COLNDE_STEPPER_RKC2)
+        return fail("substeps = %d with %d RKC2 stages does not cover the stiffest diffusive mode (lambda = -%.4g): need substeps >= %d, "
+                    "or rkc_stages = 0 for the automatic stage count (COLNDE_ALLOW_UNSTABLE_DT=1 overrides)",
+                    h->cfg.substeps, h->m.nst, stiff_lambda(&h->cfg), h->min_substeps);
     return fail("substeps = %d puts the RK4 step outside its stability region: the stiffest diffusive mode this configuration can "
                 "switch on has lambda = -%.4g (4 D Nz^2), and lambda dt must stay within %.3f — need substeps >= %d "
                 "(colnde_min_substeps; the reference uses a stabilised ROCK4 here; COLNDE_ALLOW_UNSTABLE_DT=1 overrides)",
@@ -675,7 +753,7 @@ static int t16_plan_dwtape(colnde_handle* h) {
     if (want && (MODEL_FLOATS + lds_floats_adjoint(m)) * sizeof(float) > 160 * 1024) want = false;
     // The tapes hold ONE block of columns (a multiple of the 16-column tile; whole rounds of 4,096 columns = one workgroup per CU when
     // possible); larger problems run forward -> adjoint -> dW GEMM block after block.  COLNDE_T16_BLOCK=<columns> forces a size.
-    const size_t per_col = (size_t)n_steps * 4 * (R + t16_ztape_col_floats(m) + m.ns) * sizeof(float);
+    const size_t per_col = (size_t)n_steps * m.nst * (R + t16_ztape_col_floats(m) + m.ns) * sizeof(float);
     const int n16 = h->n_tiles * CT;
     int block = 0;
     if (want) {
@@ -696,7 +774,7 @@ static int t16_plan_dwtape(colnde_handle* h) {
     }
     if (!want) { h->t16_dwtape = 0; return 0; }
     const int tiles_b = block / CT;
-    const size_t n_rec = (size_t)tiles_b * n_steps * 4;
+    const size_t n_rec = (size_t)tiles_b * n_steps * h->m.nst;
     const size_t need = n_rec * CT * R * sizeof(float);
     h->t16_block = block;
     h->t16_nblocks = (n16 + block - 1) / block;
@@ -831,7 +909,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
             }
             {
                 Timed tm(h, K_DW1);
-                hipError_t e = launch_dw_gemm(h->d_dwtape, (size_t)tiles_b * n_steps * 4, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros,
+                hipError_t e = launch_dw_gemm(h->d_dwtape, (size_t)tiles_b * n_steps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros,
                                               h->dw_slices, h->d_slab + ((size_t)h->n_tiles + (size_t)b * h->dw_slices) * stride, stride, h->stream);
                 if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
             }

@@ -45,7 +45,12 @@ struct DevModel {
     float cs[3], A[3], s0[3], B, cor_u, cor_v, C_fc;
     float sig_u, sig_v, mu_u, mu_v, mu_wT, sig_wT, mu_T, sig_T;
     float nu0, nu_minus, Ric, dRi, inv_dRi, Pr, inv_Pr, c_rib, kappa, eps, ca_K, tau, alpha_g;
+    // time stepper: nst = RHS evaluations (= taped stage inputs) per step: 4 for classical RK4, s for the s-stage RKC2 step;
+    // rkc = device table [6][RKC_LD] of (mu, nu, mu~, gamma~, c, 1 - mu - nu), index j = 0..s (nullptr: RK4)
+    int nst;
+    const float* rkc;
 };
+#define RKC_LD 260
 
 // a / b on the reciprocal unit (v_rcp_f32, 1 ulp).  NOTE: HIP's __fdividef(a, b) compiles to the full IEEE division
 // sequence (v_div_scale / v_div_fmas / v_div_fixup, ~10 instructions) unless fast-math is on: not used here.

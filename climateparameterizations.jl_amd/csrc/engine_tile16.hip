@@ -362,8 +362,13 @@ __device__ void physics_forward(const DevModel& m, const float* xs, const float*
 
 // Pullback of the physics for cotangent dbar: writes xb (physics part) and dZ_L into Z's last-layer slot.
 // gb: [3][CT][ld_f] scratch, Ri_l / Rib_l: [CT][ld_f] scratch.  Ends with a barrier.
+// sw_mode (RKC2 only): the pullback of the convective-adjustment switch min(0, K dT/dz).  Within one stabilised step the stage
+// Jacobians must share ONE switch pattern: the stage polynomials rely on cancellations that hold only for a common Jacobian, and
+// with per-stage patterns the exact discrete adjoint of the recurrence grows without bound (1e12 .. 1e57 measured on the oracle,
+// DESIGN §2).  0: evaluate the switch at this stage's state (RK4: exact discrete adjoint); 1: evaluate it and record it in Ri_l
+// (the first stage of a step the backward sweep meets, Y_{s-1}); 2: use the recorded pattern.
 __device__ void physics_vjp(const DevModel& m, const float* xs, const float* dbar, float* Z, float* xb, float* gb,
-                            float* Ri_l, float* Rib_l, int tid, int nth) {
+                            float* Ri_l, float* Rib_l, int tid, int nth, int sw_mode = 0) {
     const int Nz = m.Nz, nf = Nz + 1, nout = Nz - 1;
     const int L = m.n_layers;
     const int oo = m.act_off[L - 1];
@@ -406,7 +411,10 @@ __device__ void physics_vjp(const DevModel& m, const float* xs, const float* dba
                 } else if (m.ca) {
                     const float* x = xs + c * m.ld_x;
                     const float gT = (x[2 * Nz + f] - x[2 * Nz + f - 1]) * (float)Nz;
-                    g2 = gT < 0.0f ? -Fb2 * m.cs[2] * m.kappa : 0.0f;
+                    bool on = gT < 0.0f;
+                    if (sw_mode == 2) on = Ri_l[c * m.ld_f + f] != 0.0f;
+                    if (sw_mode == 1) Ri_l[c * m.ld_f + f] = on ? 1.0f : 0.0f;
+                    g2 = on ? -Fb2 * m.cs[2] * m.kappa : 0.0f;
                 }
             }
             gb[(0 * CT + c) * m.ld_f + f] = g0;
@@ -469,7 +477,10 @@ __device__ void physics_vjp(const DevModel& m, const float* xs, const float* dba
                 const float* db = dbar + c * m.ld_x;
                 const float wbf = CN * (db[f] - db[f - 1]);
                 const float gT = (x[f] - x[f - 1]) * (float)Nz;
-                g = gT < 0.0f ? -wbf * m.ca_K : 0.0f;
+                bool on = gT < 0.0f;
+                if (sw_mode == 2) on = Ri_l[c * m.ld_f + f] != 0.0f;
+                if (sw_mode == 1) Ri_l[c * m.ld_f + f] = on ? 1.0f : 0.0f;
+                g = on ? -wbf * m.ca_K : 0.0f;
             }
             gb[c * m.ld_f + f] = g;
         }
@@ -576,8 +587,61 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
         }
     }
     const int n_steps = (n_save - 1) * substeps;
-    float* tp = tape ? tape + (size_t)blockIdx.x * n_steps * 4 * n_items : nullptr;
+    const int nst = m.nst;                               // RHS evaluations (taped stage inputs) per step: 4 (RK4) or s (RKC2)
+    float* tp = tape ? tape + (size_t)blockIdx.x * n_steps * nst * n_items : nullptr;
     int step = 0;
+    if (m.rkc) {
+        // ---- s-stage RKC2 steps (colnde_dev.h; coefficients from the host table): per owner item Y_0 = xn, Y_{j-1} = ym1,
+        //      Y_{j-2} = ym2 and F_0 = f0 stay in registers; stage st evaluates F_st = f(Y_st), the step ends with Y_s
+        const float* mu_t = m.rkc, *nu_t = m.rkc + RKC_LD, *mut_t = m.rkc + 2 * RKC_LD, *gat_t = m.rkc + 3 * RKC_LD, *c_t = m.rkc + 4 * RKC_LD;
+        float ym1[FMAXR], ym2[FMAXR];                    // acc[] serves as f0
+        for (int iv = 0; iv < n_save - 1; iv++) {
+            const float t0 = save_times[iv];
+            const float dt = (save_times[iv + 1] - t0) / (float)substeps;
+            for (int s = 0; s < substeps; s++, step++) {
+                const float ts = t0 + (float)s * dt;
+#pragma nounroll
+                for (int st = 0; st <= nst; st++) {      // st = nst: only the final combination Y_s
+                    const float cmu = mu_t[st], cnu = nu_t[st], cmt = mut_t[st] * dt, cga = gat_t[st] * dt;
+                    const bool last = st == nst;
+                    const bool save = last && s == substeps - 1;
+#pragma unroll
+                    for (int r = 0; r < FMAXR; r++) {
+                        const int it = tid + r * nth;
+                        if (it < n_items) {
+                            const int c = it / m.ns, i = it - c * m.ns;
+                            const int o = c * m.ld_x + i;
+                            // increment form d_j = Y_j - Y_0 (the weights of Y_0, Y_{j-1}, Y_{j-2} sum to one): the differences
+                            // 2 d_{j-1} - d_{j-2} are taken between increments, not O(1) states — float32 stays accurate
+                            float dj = 0.0f;
+                            if (st == 1) {
+                                acc[r] = kk[o];                                        // F_0
+                                dj = cmt * acc[r];
+                            } else if (st >= 2) {
+                                dj = cmu * ym1[r] + cnu * ym2[r] + cmt * kk[o] + cga * acc[r];
+                            }
+                            const float v = xn[r] + dj;
+                            ym2[r] = st == 0 ? 0.0f : ym1[r];
+                            ym1[r] = dj;
+                            if (last) {
+                                xn[r] = v;
+                                if (save && sol && col0 + c < n_col) sol[((size_t)(col0 + c) * n_save + iv + 1) * m.ns + i] = v;
+                            } else {
+                                xs[o] = v;
+                                if (tp) tp[((size_t)step * nst + st) * n_items + it] = v;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (last) break;
+                    mlp_forward<false, WLDS>(m, pk, wsrc, wf, xs, nullptr, A, wave, nwaves, lane,
+                                             ztape ? ztape + ((size_t)blockIdx.x * n_steps * nst + (size_t)step * nst + st) * ((size_t)CT * zld) : nullptr, zld);
+                    physics_forward(m, xs, A, F, Ri_l, bcl, ts + c_t[st] * dt, kk, tid, nth);
+                }
+            }
+        }
+        return;
+    }
     for (int iv = 0; iv < n_save - 1; iv++) {
         const float t0 = save_times[iv];
         const float dt = (save_times[iv + 1] - t0) / (float)substeps;
@@ -765,13 +829,21 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
     }
 
     const int n_steps = (n_save - 1) * substeps;
-    const float* tp = tape + (size_t)blockIdx.x * n_steps * 4 * n_items;
+    const int nst = m.nst;                               // taped stage inputs per step: 4 (RK4) or s (RKC2)
+    const bool rkc = m.rkc != nullptr;
+    const float* mu_t = m.rkc, *nu_t = m.rkc + RKC_LD, *mut_t = m.rkc + 2 * RKC_LD, *gat_t = m.rkc + 3 * RKC_LD, *kap_t = m.rkc + 5 * RKC_LD;
+    const float* tp = tape + (size_t)blockIdx.x * n_steps * nst * n_items;
     // the tape is read one stage ahead of its use (xpre) so that its HBM latency hides under the previous stage
 #pragma unroll
     for (int r = 0; r < MAXR; r++) {
         const int it = tid + r * nth;
-        xpre[r] = it < n_items ? tp[((size_t)n_steps * 4 - 1) * n_items + it] : 0.0f;
+        xpre[r] = it < n_items ? tp[((size_t)n_steps * nst - 1) * n_items + it] : 0.0f;
     }
+    // RKC2 (discrete adjoint of the recurrence in colnde_dev.h): cotangents of Y_j (lam), Y_{j-1} (yb1), Y_{j-2} (yb2), Y_0 (yb0)
+    // and F_0 (f0b) per owner item; unused by the RK4 path
+    float yb1[MAXR], yb2[MAXR], yb0[MAXR], f0b[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) { yb1[r] = 0.0f; yb2[r] = 0.0f; yb0[r] = 0.0f; f0b[r] = 0.0f; }
 
     // save point 0 enters the loss value only (x0 does not depend on the weights)
 #pragma unroll
@@ -804,10 +876,13 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
 #pragma unroll
             for (int r = 0; r < MAXR; r++) xbs[r] = 0.0f;
 #pragma nounroll
-            for (int st = 3; st >= 0; st--) {
+            for (int st = nst - 1; st >= 0; st--) {
                 // k̄4 = dt/6 λ; k̄3 = dt/3 λ + dt x̄4; k̄2 = dt/3 λ + dt/2 x̄3; k̄1 = dt/6 λ + dt/2 x̄2
                 const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
                 const float cwx = st == 2 ? dt : 0.5f * dt;
+                // RKC2, stage input Y_st feeds Y_j, j = st + 1, through mu~_j h F_st:
+                const float cmu = rkc ? mu_t[st + 1] : 0.0f, cnu = rkc ? nu_t[st + 1] : 0.0f;
+                const float cmt = rkc ? mut_t[st + 1] * dt : 0.0f, cga = rkc ? gat_t[st + 1] * dt : 0.0f, ck0 = rkc ? kap_t[st + 1] : 0.0f;
                 STAMP_BEGIN();
                 // stage input from the tape; stage cotangent k̄_st = wl λ + wx x̄_{st+1}
 #pragma unroll
@@ -817,13 +892,37 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                         const int c = it / m.ns, i = it - c * m.ns;
                         const int o = c * m.ld_x + i;
                         xs[o] = xpre[r];
-                        float kb = cwl * lam[r];
-                        if (st < 3) kb += cwx * xb[o];
+                        float kb;
+                        if (rkc) {
+                            // lam = cotangent of Y_j, complete once the previous iteration's pullback (xb: J(Y_j)^T F̄_j) is added
+                            if (st < nst - 1) {
+                                const float yj = yb1[r] + xb[o];
+                                yb1[r] = yb2[r];
+                                yb2[r] = 0.0f;
+                                lam[r] = yj;
+                            }
+                            if (st >= 1) {
+                                yb0[r] += ck0 * lam[r];
+                                yb1[r] += cmu * lam[r];
+                                yb2[r] += cnu * lam[r];
+                                f0b[r] += cga * lam[r];
+                                kb = cmt * lam[r];
+                            } else {
+                                // Y_1 = Y_0 + mu~_1 h F_0: lam holds Ȳ_1, yb1 the nu_2 part of Ȳ_0
+                                yb0[r] += lam[r] + yb1[r];
+                                kb = f0b[r] + cmt * lam[r];
+                                yb1[r] = 0.0f;
+                                f0b[r] = 0.0f;
+                            }
+                        } else {
+                            kb = cwl * lam[r];
+                            if (st < 3) kb += cwx * xb[o];
+                        }
                         dbar[o] = kb;
                     }
                 }
                 {
-                    const int qn = step * 4 + st - 1;            // the stage handled next (tape order is time order)
+                    const int qn = step * nst + st - 1;            // the stage handled next (tape order is time order)
                     if (qn >= 0) {
 #pragma unroll
                         for (int r = 0; r < MAXR; r++) {
@@ -838,7 +937,7 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                     // hidden-layer pre-activations taped by the forward kernel: Z and A = act(Z) without the forward GEMMs (the output
                     // layer enters the pullback linearly: its values are not needed)
                     const int hid = m.act_off[m.n_layers - 1], zld = (m.n_nets * hid + 3) & ~3;
-                    const float* zr = ztape + ((size_t)blockIdx.x * n_steps * 4 + (size_t)step * 4 + st) * ((size_t)CT * zld);
+                    const float* zr = ztape + ((size_t)blockIdx.x * n_steps * nst + (size_t)step * nst + st) * ((size_t)CT * zld);
                     // (segments start at multiples of 4 floats: one float4 never straddles two layers; up to four float4 per lane
                     //  are fetched back to back so that one HBM latency covers them)
                     const int nq = (m.n_nets * hid) >> 2;                      // float4 items per column
@@ -867,7 +966,7 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                 } else
                     mlp_forward<true, WLDS>(m, pk, wsrc, wf, xs, Z, A, wave, nwaves, lane);
                 STAMP(1);
-                physics_vjp(m, xs, dbar, Z, xb, gb, Ri_l, Rib_l, tid, nth);
+                physics_vjp(m, xs, dbar, Z, xb, gb, Ri_l, Rib_l, tid, nth, rkc ? (st == nst - 1 ? 1 : 2) : 0);
                 STAMP(2);
                 mlp_backward<WLDS>(m, pk, wsrc, wb, Z, xb, wave, nwaves, lane);
                 STAMP(3);
@@ -879,7 +978,7 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                     // == 2 mod 4), tape rows 16-byte aligned: copied two floats at a time
                     const int ns4 = (m.ns + 3) & ~3, act4 = (m.act_total + 3) & ~3;
                     const int R = ns4 + 2 * m.n_nets * act4;
-                    float* rec = dwtape + ((size_t)blockIdx.x * n_steps * 4 + (size_t)step * 4 + st) * ((size_t)CT * R);
+                    float* rec = dwtape + ((size_t)blockIdx.x * n_steps * nst + (size_t)step * nst + st) * ((size_t)CT * R);
                     const int hx = ns4 >> 1, ha = act4 >> 1;                                        // float2 items per segment
                     for (int c = wave; c < CT; c += nwaves) {                                       // one wave per column
                         float* row = rec + (size_t)c * R;
@@ -940,8 +1039,21 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                 __syncthreads();
                 STAMP(5);
             }
+            if (rkc) {
+                // λ_n = Ȳ_0 + J(Y_0)^T F̄_0 (xb of the st = 0 pullback; visible after the stage's closing barrier)
 #pragma unroll
-            for (int r = 0; r < MAXR; r++) lam[r] += xbs[r];
+                for (int r = 0; r < MAXR; r++) {
+                    const int it = tid + r * nth;
+                    if (it < n_items) {
+                        const int c = it / m.ns, i = it - c * m.ns;
+                        lam[r] = yb0[r] + xb[c * m.ld_x + i];
+                    }
+                    yb0[r] = 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < MAXR; r++) lam[r] += xbs[r];
+            }
         }
     }
 

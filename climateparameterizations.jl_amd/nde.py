@@ -43,6 +43,15 @@ def min_substeps(cfg: NDEConfig) -> int:
     return int(n)
 
 
+def rkc_stages(cfg: NDEConfig) -> int:
+    """`colnde_rkc_stages`: stages per RKC2 step this configuration runs with (no GPU needed)."""
+    c, keep = to_c_config(cfg, 1, 0, 0)
+    n = _lib.lib().colnde_rkc_stages(ctypes.byref(c))
+    if n < 0:
+        raise _lib.ColndeError(_lib.lib().colnde_last_error().decode("utf-8", "replace"))
+    return int(n)
+
+
 class ColumnNDE:
     def __init__(self, cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0):
         cfg.validate()

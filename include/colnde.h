@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define COLNDE_VERSION 100
+#define COLNDE_VERSION 101
 #define COLNDE_MAX_LAYERS 8
 
 enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_training.jl:56-165 */
@@ -36,6 +36,11 @@ enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it 
        COLNDE_ENGINE_GENERIC = 1,   /* tile16: 16-column MFMA tiles staged through LDS, any layer sizes / model */
        COLNDE_ENGINE_MFMA = 2 };    /* regtile: 32 columns per wavefront resident in registers (static 96-50-20-31 wind-mixing
                                        shape; colnde_create fails if the configuration is not covered) */
+
+enum { COLNDE_STEPPER_RK4 = 0,      /* classical RK4, `substeps` per save interval (what the bench measures) */
+       COLNDE_STEPPER_RKC2 = 1 };   /* stabilised second-order Runge-Kutta-Chebyshev for the stiff variants: `substeps` steps per
+                                       save interval of `rkc_stages` stages each (tile16 engine).  Stands where the reference
+                                       uses ROCK4 (wind_mixing/train_NDE.jl:143, free_convection/test_free_convection_nde.jl:32-35) */
 
 /* Mirrors the `constants`, `scalings`, `conditions` NamedTuples of prepare_parameters_NDE_training
  * (wind_mixing/src/NDE_training.jl:1-44, :205-207) and the parameter tail of the free-convection NDEs
@@ -64,6 +69,8 @@ typedef struct colnde_config {
     int32_t n_columns;                           /* columns (simulations) held by this handle */
     int32_t device;                              /* HIP device ordinal */
     int32_t engine;                              /* COLNDE_ENGINE_* */
+    int32_t stepper;                             /* COLNDE_STEPPER_* (0 = RK4) */
+    int32_t rkc_stages;                          /* RKC2: stages per step, 2..256; 0 = automatic (colnde_rkc_stages) */
 } colnde_config;
 
 typedef struct colnde_handle colnde_handle;
@@ -78,6 +85,11 @@ int colnde_version(void);
  * _loss_grad refuse a configuration below it (instead of returning a blown-up solve with rc = 0) unless
  * COLNDE_ALLOW_UNSTABLE_DT=1; colnde_rhs is not affected.  Returns -1 on an invalid configuration.  No GPU needed. */
 int  colnde_min_substeps(const colnde_config* cfg);
+
+/* Stage count an RKC2 configuration runs with: cfg->rkc_stages when given, else the least s >= 2 whose real stability interval
+ * beta(s) ~ 0.653 s^2 (damping 2/13), used to 90 %, covers lambda dt of the same stiffest mode.  A given stage count that does
+ * not cover it is refused by the solve calls like an unstable RK4 step.  Returns -1 on an invalid configuration. */
+int  colnde_rkc_stages(const colnde_config* cfg);
 
 int  colnde_create(const colnde_config* cfg, colnde_handle** out);
 void colnde_destroy(colnde_handle* h);

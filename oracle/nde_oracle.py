@@ -202,7 +202,7 @@ class Model:
         Q = bcs[:, 5]
         return (Q * np.sin(2 * np.pi / 86400.0 * (t * c.tau)) / (c.alpha * c.g) - self.mu_wT) / self.s_wT
 
-    def wm_rhs(self, x, bcs, nets, t=0.0, want_vjp=False):
+    def wm_rhs(self, x, bcs, nets, t=0.0, want_vjp=False, sw=None):
         c, Nz = self.cfg, self.Nz
         H, tau, f = c.H, c.tau, c.f
         u, v, T = x[:, :Nz], x[:, Nz:2 * Nz], x[:, 2 * Nz:]
@@ -303,7 +303,7 @@ class Model:
                 xb_T = xb_T + _face_grad_T(gTb, Nz)
             elif c.convective_adjustment:
                 gT = save["gT"]
-                gTb = -Fbar[2] * cs[2] * c.kappa * (gT < 0)
+                gTb = -Fbar[2] * cs[2] * c.kappa * ((gT < 0) if sw is None else sw)
                 xb_T = xb_T + _face_grad_T(gTb, Nz)
             xbar = np.concatenate([xb_u, xb_v, xb_T], axis=1)
             grads = []
@@ -320,7 +320,7 @@ class Model:
 
     # -- free convection: ∂T∂t (free_convection_nde.jl:29-38) and convective-adjustment NDE
     #    (convective_adjustment_nde.jl:33-48) ----------------------------------------------------
-    def fc_rhs(self, x, bcs, nets, t=0.0, want_vjp=False):
+    def fc_rhs(self, x, bcs, nets, t=0.0, want_vjp=False, sw=None):
         c, Nz = self.cfg, self.Nz
         C = (self.s_wT / self.s_T) * (c.tau / c.H)
         n = x.shape[0]
@@ -343,16 +343,26 @@ class Model:
             xbar, g = mlp_vjp(nets[0], self.acts, tape, wb[:, 1:Nz])
             if ca:
                 qb = -wb
-                gTb = qb * c.ca_K * (gT < 0)
+                gTb = qb * c.ca_K * ((gT < 0) if sw is None else sw)
                 xbar = xbar + _face_grad_T(gTb, Nz)
             return xbar, [g]
 
         return dT, vjp
 
-    def rhs(self, x, bcs, nets, t=0.0, want_vjp=False):
+    def rhs(self, x, bcs, nets, t=0.0, want_vjp=False, sw=None):
+        """`sw`: switch pattern (dT/dz < 0 per face) to use in the PULLBACK of min(0, K dT/dz) instead of this state's own."""
         if self.cfg.model == WIND_MIXING:
-            return self.wm_rhs(x, bcs, nets, t, want_vjp)
-        return self.fc_rhs(x, bcs, nets, t, want_vjp)
+            return self.wm_rhs(x, bcs, nets, t, want_vjp, sw)
+        return self.fc_rhs(x, bcs, nets, t, want_vjp, sw)
+
+    def switch_pattern(self, x):
+        """The faces where the convective-adjustment switch is on at state x (None for the models without one)."""
+        c, Nz = self.cfg, self.Nz
+        if c.model == CONVECTIVE_ADJUSTMENT_NDE:
+            return _face_grad(x, Nz) < 0
+        if c.model == WIND_MIXING and c.convective_adjustment and not c.modified_pacanowski_philander:
+            return _face_grad(x[:, 2 * Nz:], Nz) < 0
+        return None
 
 
 def rhs(cfg, x, bcs, theta, t=0.0, dtype=np.float64):
@@ -375,9 +385,127 @@ def _step_times(cfg):
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# stabilised explicit stepper: second-order Runge-Kutta-Chebyshev (RKC2)
+# The reference integrates its stiff variants with ROCK4 (wind_mixing/train_NDE.jl:143, free_convection/test_free_convection_nde.jl:32-35
+# — OrdinaryDiffEq 5.55.1, pinned in the Manifests, absent from /root/reference): an adaptive stabilised Chebyshev method whose stage
+# count follows the spectral radius.  A fixed-step product needs a fixed-stage member of the same family with a discrete adjoint:
+# RKC2 of van der Houwen & Sommeijer in Verwer's form (Sommeijer, Shampine, Verwer, "RKC: an explicit solver for parabolic PDEs",
+# J. Comput. Appl. Math. 88 (1998), eqs. 2.1-2.8), damping eps = 2/13.  Real stability interval beta(s) ~ 0.653 s^2.
+# ----------------------------------------------------------------------------------------------
+RKC_EPS = 2.0 / 13.0
+
+
+def _cheb(s, w0):
+    """T_j(w0), T_j'(w0), T_j''(w0) for j = 0..s by the three-term recurrences."""
+    T, dT, d2T = np.zeros(s + 1), np.zeros(s + 1), np.zeros(s + 1)
+    T[0], T[1], dT[1] = 1.0, w0, 1.0
+    for j in range(2, s + 1):
+        T[j] = 2 * w0 * T[j - 1] - T[j - 2]
+        dT[j] = 2 * T[j - 1] + 2 * w0 * dT[j - 1] - dT[j - 2]
+        d2T[j] = 4 * dT[j - 1] + 2 * w0 * d2T[j - 1] - d2T[j - 2]
+    return T, dT, d2T
+
+
+def rkc_coefficients(s):
+    """(mu[1..s], nu[1..s], mut[1..s], gat[1..s], c[0..s], beta) of the s-stage RKC2 (index 0 unused for the first four):
+         Y_0 = y,  Y_1 = Y_0 + mut_1 h F_0,
+         Y_j = (1 - mu_j - nu_j) Y_0 + mu_j Y_{j-1} + nu_j Y_{j-2} + mut_j h F_{j-1} + gat_j h F_0   (j = 2..s),   y+ = Y_s,
+       with F_j = f(t + c_j h, Y_j); beta = real stability boundary."""
+    assert s >= 2
+    w0 = 1.0 + RKC_EPS / s ** 2
+    T, dT, d2T = _cheb(s, w0)
+    w1 = dT[s] / d2T[s]
+    b = np.zeros(s + 1)
+    for j in range(2, s + 1):
+        b[j] = d2T[j] / dT[j] ** 2
+    b[0] = b[1] = b[2]
+    a = 1.0 - b * T
+    mu, nu, mut, gat = (np.zeros(s + 1) for _ in range(4))
+    mut[1] = b[1] * w1
+    for j in range(2, s + 1):
+        mu[j] = 2 * b[j] * w0 / b[j - 1]
+        nu[j] = -b[j] / b[j - 2]
+        mut[j] = 2 * b[j] * w1 / b[j - 1]
+        gat[j] = -a[j - 1] * mut[j]
+    c = np.zeros(s + 1)
+    c[1] = mut[1]
+    for j in range(2, s + 1):
+        c[j] = w1 * d2T[j] / dT[j]
+    beta = (w0 + 1.0) * d2T[s] / dT[s]
+    return mu, nu, mut, gat, c, beta
+
+
+def stiff_lambda(cfg):
+    """-lambda of the stiffest diffusive mode the configuration can switch on (4 D Nz^2; csrc/api.hip `stiff_lambda`)."""
+    D = 0.0
+    if cfg.model == WIND_MIXING:
+        k = cfg.tau / cfg.H ** 2
+        if cfg.modified_pacanowski_philander:
+            D = k * (cfg.nu0 + cfg.nu_minus) * max(1.0, 1.0 / cfg.Pr)
+            if cfg.inplace_variant and cfg.convective_adjustment:
+                D = max(D, k * cfg.kappa)
+        elif cfg.convective_adjustment:
+            D = k * cfg.kappa
+    elif cfg.model == CONVECTIVE_ADJUSTMENT_NDE:
+        D = cfg.sigma[5] / cfg.sigma[2] * cfg.tau / cfg.H * cfg.ca_K
+    return 4.0 * D * cfg.Nz ** 2
+
+
+RKC_SAFETY = 0.9      # use 90 % of the real stability interval (the switching diffusivities are not a constant-coefficient problem)
+
+
+def rkc_stages(cfg):
+    """Stage count of the RKC2 step: cfg.rkc_stages if given, else the least s >= 2 with 0.9 beta(s) >= lambda h."""
+    if getattr(cfg, "rkc_stages", 0):
+        return int(cfg.rkc_stages)
+    ts = np.asarray(cfg.save_times, np.float64)
+    h = float(np.max(np.diff(ts))) / cfg.substeps
+    z = stiff_lambda(cfg) * h
+    s = 2
+    while RKC_SAFETY * rkc_coefficients(s)[5] < z:
+        s += 1
+    return s
+
+
+def _rkc_step(m, nets, bcs, x, t, h, co, s, want_tape=False):
+    """One RKC2 step in increment form, d_j = Y_j - Y_0 (1 - mu_j - nu_j + mu_j + nu_j = 1):
+         d_1 = mu~_1 h F_0,   d_j = mu_j d_{j-1} + nu_j d_{j-2} + mu~_j h F_{j-1} + gamma~_j h F_0,   Y_j = Y_0 + d_j
+    — algebraically the recurrence of `rkc_coefficients`, but the differences 2 Y_{j-1} - Y_{j-2} are taken between increments
+    instead of O(1) states, which is what keeps a float32 run (the product's arithmetic) accurate."""
+    mu, nu, mut, gat, c, _ = co
+    dt_ = m.dtype                      # every coefficient in the working precision (a float32 run is float32 throughout)
+    mu, nu, mut, gat = (a.astype(dt_) for a in (mu, nu, mut, gat))
+    F0 = m.rhs(x, bcs, nets, t)
+    d = [np.zeros_like(x), mut[1] * h * F0]
+    Y = [x, x + d[1]]
+    for j in range(2, s + 1):
+        Fp = m.rhs(Y[j - 1], bcs, nets, t + c[j - 1] * h)
+        d.append(mu[j] * d[j - 1] + nu[j] * d[j - 2] + mut[j] * h * Fp + gat[j] * h * F0)
+        Y.append(x + d[j])
+    return (Y[s], Y[:s]) if want_tape else Y[s]
+
+
 def solve(cfg, x0, bcs, theta, dtype=np.float64, return_tape=False):
-    """Returns sol [n_col, n_save, n_state]; save point 0 is x0 (as `saveat` includes t_train[1])."""
+    """Returns sol [n_col, n_save, n_state]; save point 0 is x0 (as `saveat` includes t_train[1]).
+    cfg.stepper = "rkc2": each of the `substeps` steps per save interval is one s-stage RKC2 step (tape: its s stage states)."""
     m = Model(cfg, dtype)
+    if getattr(cfg, "stepper", "rk4") == "rkc2":
+        nets = m.unpack(theta)
+        x = np.array(x0, dtype=dtype)
+        bcs = np.asarray(bcs, dtype=dtype)
+        s = rkc_stages(cfg)
+        co = rkc_coefficients(s)
+        sol = np.zeros((x.shape[0], len(cfg.save_times), x.shape[1]), dtype=dtype)
+        sol[:, 0] = x
+        tape = []
+        for (t, dt, save_idx) in _step_times(cfg):
+            x, Ys = _rkc_step(m, nets, bcs, x, t, dtype(dt), co, s, True)
+            if return_tape:
+                tape.append(Ys)
+            if save_idx >= 0:
+                sol[:, save_idx] = x
+        return (sol, tape) if return_tape else sol
     nets = m.unpack(theta)
     x = np.array(x0, dtype=dtype)
     bcs = np.asarray(bcs, dtype=dtype)
@@ -488,11 +616,45 @@ def loss_and_grad(cfg, x0, bcs, theta, truth, scalings, dtype=np.float64, n_col_
     lam = np.zeros_like(sol[:, 0])
     gacc = None
     steps = _step_times(cfg)
+    rkc = getattr(cfg, "stepper", "rk4") == "rkc2"
+    if rkc:
+        s_ = rkc_stages(cfg)
+        mu, nu, mut, gat, cst, _ = rkc_coefficients(s_)
+        kap = (1.0 - mu - nu).astype(dtype)
+        mu, nu, mut, gat = (a.astype(dtype) for a in (mu, nu, mut, gat))
     for si in range(len(steps) - 1, -1, -1):
         t, dt, save_idx = steps[si]
         dt = dtype(dt)
         if save_idx >= 0:
             lam = lam + _loss_injection(cfg, sol[:, save_idx], truth[:, save_idx], scalings, n_col_total, n_save)
+        if rkc:
+            # discrete adjoint of one RKC2 step: cotangents Yb[j] of the stage states, F0b of F_0; one VJP per stage state Y_0..Y_{s-1}.
+            # The convective-adjustment switch is pulled back with ONE pattern per step, that of Y_{s-1}: with per-stage patterns
+            # the stage polynomials no longer cancel and the exact adjoint of the recurrence is unbounded (|grad| 1e12..1e57 on the
+            # 64-level CA-NDE; tests/test_oracle.py::test_rkc2_switch_pullback).  Smooth closures are unaffected (sw is None).
+            Ys = tape[si]
+            sw = m.switch_pattern(Ys[s_ - 1]) if not getattr(cfg, "rkc_exact_switch_pullback", False) else None
+            Yb = [np.zeros_like(lam) for _ in range(s_ + 1)]
+            Yb[s_] = lam
+            F0b = np.zeros_like(lam)
+            gs = None
+            for j in range(s_, 1, -1):
+                Yb[0] = Yb[0] + kap[j] * Yb[j]
+                Yb[j - 1] = Yb[j - 1] + mu[j] * Yb[j]
+                Yb[j - 2] = Yb[j - 2] + nu[j] * Yb[j]
+                F0b = F0b + gat[j] * dt * Yb[j]
+                _, v = m.rhs(Ys[j - 1], bcs, nets, t + cst[j - 1] * dt, True, sw)
+                xb, g = v(mut[j] * dt * Yb[j])
+                Yb[j - 1] = Yb[j - 1] + xb
+                gs = pack_grads(g) if gs is None else gs + pack_grads(g)
+            Yb[0] = Yb[0] + Yb[1]
+            F0b = F0b + mut[1] * dt * Yb[1]
+            _, v = m.rhs(Ys[0], bcs, nets, t, True, sw)
+            xb, g = v(F0b)
+            lam = Yb[0] + xb
+            gs = pack_grads(g) if gs is None else gs + pack_grads(g)
+            gacc = gs if gacc is None else gacc + gs
+            continue
         x = tape[si]
         k1, v1 = m.rhs(x, bcs, nets, t, True)
         X2 = x + dt / 2 * k1

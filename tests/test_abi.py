@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "%s declared in colnde.h but not exported" % name
         assert name in bound, "%s declared in colnde.h but missing from the ctypes binding" % name
-    assert L.colnde_version() == 100
+    header = open(os.path.join(ROOT, "include", "colnde.h")).read()
+    assert L.colnde_version() == int(re.search(r"#define COLNDE_VERSION (\d+)", header).group(1)) == 101
 
 
 def test_config_struct_layout_matches_header_order():

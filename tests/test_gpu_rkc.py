@@ -1,0 +1,149 @@
+"""The stabilised stepper (RKC2, COLNDE_STEPPER_RKC2) on the GPU against the float64 oracle's RKC2 — the same recurrence and the
+same discrete adjoint — on the stiff variants the reference integrates with ROCK4 (wind_mixing/train_NDE.jl:143,
+free_convection/test_free_convection_nde.jl:32-35), at a fraction of sub-stepped RK4's right-hand-side evaluations."""
+import numpy as np
+import pytest
+
+import colnde
+from colnde import synthetic
+from colnde.nde import ENGINE_REGTILE, ENGINE_TILE16
+from oracle import nde_oracle as O
+from tests.test_gpu_parity import _record, _rel, SOL_ATOL, LOSS_RTOL, GRAD_REL, FC_SOL_ATOL, FC_LOSS_RTOL, FC_GRAD_REL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["taped", "inregister"])
+def test_wind_mixing_kappa10_conv_adj_branch(mode, monkeypatch):
+    """kappa = 10 (the reference default, NDE_training.jl:141-143) makes the convective-adjustment branch stiff: lambda h = 375 per
+    10-minute frame, 135 RK4 sub-steps (540 RHS evaluations) — or one 26-stage RKC2 step."""
+    if mode == "inregister":
+        monkeypatch.setenv("COLNDE_T16_DWTAPE", "0")
+    p = synthetic.wind_mixing_problem(21, n_frames=9, weight_divisor=1e2, modified_pacanowski_philander=False, zero_weights=False,
+                                      convective_adjustment=True, kappa=10.0, stepper="rkc2", substeps=1)
+    cfg = p.cfg
+    assert colnde.rkc_stages(cfg) == 26
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(cfg, p.n_columns) as nde:
+        assert nde.engine == ENGINE_TILE16
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_l, terms_l = nde.loss(p.weights, sc)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    # a 26-stage step amplifies round-off (RKC's internal stability constant grows like s^2): the yardstick is the oracle itself run in
+    # float32 throughout, whose distance from float64 the HIP path must not exceed by more than a small factor
+    tot32, terms32, g32, sol32 = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc, dtype=np.float32)
+    e32 = (np.abs(sol32 - sol).max(), abs(tot32 - tot) / tot, _rel(g32, g))
+    _record("rkc2/wm_kappa10/" + mode, sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g),
+            sol_abs_oracle32_vs_64=e32[0], loss_rel_oracle32_vs_64=e32[1], grad_rel_oracle32_vs_64=e32[2])
+    assert np.abs(sol_g - sol).max() < 4 * e32[0] + RKC_WM[0]
+    assert abs(tot_g - tot) / tot < 4 * e32[1] + RKC_WM[1] and np.isclose(tot_l, tot_g, rtol=1e-5)
+    np.testing.assert_allclose(terms_g, terms, rtol=4 * np.abs(terms32 / terms - 1).max() + 10 * RKC_WM[1], atol=0)   # term by term
+    assert _rel(grad_g, g) < 4 * e32[2] + RKC_WM[2]
+    with pytest.raises(colnde.ColndeError, match="regtile"):           # the register-resident engine is RK4 only
+        colnde.ColumnNDE(p.cfg.with_(modified_pacanowski_philander=True, zero_weights=True, convective_adjustment=False), 8,
+                         engine=ENGINE_REGTILE)
+
+
+def test_mpp_training_rhs_with_rkc2_matches_oracle_and_rk4():
+    """The bench's own right-hand side under RKC2 (automatic stage count 3 for lambda h = 3.75): parity with the oracle's RKC2, and both
+    steppers integrate the same trajectory to their truncation errors."""
+    p = synthetic.wind_mixing_problem(37, n_frames=9, weight_divisor=1e2, stepper="rkc2", substeps=1)
+    cfg = p.cfg
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(cfg)
+    tot, terms, g, sol = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    _record("rkc2/mpp", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g))
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
+    assert _rel(grad_g, g) < GRAD_REL
+    # one 3-stage second-order step per frame against two fourth-order ones: the same trajectory to RKC2's truncation error
+    rk4 = O.solve(cfg.with_(stepper="rk4", substeps=2), p.x0, p.bcs, p.weights)
+    fine = O.solve(cfg.with_(substeps=4), p.x0, p.bcs, p.weights)
+    assert np.abs(rk4 - sol).max() < 0.2 and np.abs(rk4 - fine).max() < 0.25 * np.abs(rk4 - sol).max()
+
+
+def test_conv_adj_nde_64_levels_full_axis_unstable_profile():
+    """`ConvectiveAdjustmentNDE` (convective_adjustment_nde.jl:33-48, K = 10) at 64 levels over config 4's axis (129 save points,
+    t in [0, 1]) from a profile with a 24-cell inverted layer.  Sub-stepped RK4 needs 230 steps = 920 RHS evaluations per save
+    interval (colnde_min_substeps); RKC2 with 4 steps of 17 stages needs 68: 13.5x fewer, stable, and the HIP path follows the
+    oracle's RKC2 (same recurrence; same pullback with one switch pattern per step).  Accuracy, not stability, then sets the step:
+    tests/test_oracle.py::test_rkc2_accuracy_against_converged_rk4 and ::test_rkc2_switch_pullback hold those numbers."""
+    p = synthetic.free_convection_problem(5, Nz=64, n_save=129, substeps=4, convective_adjustment=True, t_end=1.0)
+    cfg = p.cfg.with_(stepper="rkc2")
+    x0 = p.x0.copy()
+    x0[:, 20:44] = x0[:, 20:44][:, ::-1]
+    s = colnde.rkc_stages(cfg)
+    rk4_evals = 4 * colnde.min_substeps(cfg.with_(stepper="rk4", substeps=1))
+    assert s == 17 and rk4_evals == 920 and rk4_evals >= 10 * cfg.substeps * s
+    truth = O.solve(cfg, x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(cfg)
+    tot, terms, g, sol = O.loss_and_grad(cfg, x0, p.bcs, p.weights, truth, sc)
+    tot32, _, g32, sol32 = O.loss_and_grad(cfg, x0, p.bcs, p.weights, truth, sc, dtype=np.float32)
+    assert np.isfinite(sol).all() and np.isfinite(g).all() and np.abs(sol[:, -1] - x0).max() > 1.0      # the inverted layer was mixed away
+    with colnde.ColumnNDE(cfg, p.n_columns) as nde:
+        nde.set_problem(x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    assert np.isfinite(sol_g).all() and np.isfinite(grad_g).all()
+    e32 = dict(sol=np.abs(sol32 - sol).max(), loss=abs(tot32 - tot) / tot, grad=_rel(g32, g))
+    _record("rkc2/ca_nde_64_axis", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g),
+            sol_abs_f32=np.abs(sol_g - sol32).max(), loss_rel_f32=abs(tot_g - tot32) / tot32, grad_rel_f32=_rel(grad_g, g32.astype(np.float64)),
+            sol_abs_oracle32_vs_64=e32["sol"], loss_rel_oracle32_vs_64=e32["loss"], grad_rel_oracle32_vs_64=e32["grad"])
+    # This scenario is round-off sensitive by construction: 512 steps of 17 stages through a switch that decides, face by face, on the
+    # sign of dT/dz of a layer being homogenised (dT/dz -> 0-), and RKC's internal amplification of round-off (~ s^2 eps).  Two float32
+    # evaluations that order their sums differently (the NumPy oracle in float32 and the HIP path) part ways at the 1e-2 level, each
+    # as far from float64 as the other: the bound is the float32 oracle's own distance from float64 (x5), plus absolute floors.
+    assert np.abs(sol_g - sol).max() < 5 * e32["sol"] + RKC_CA[0]
+    assert abs(tot_g - tot) / tot < 5 * e32["loss"] + RKC_CA[1]
+    assert _rel(grad_g, g) < 5 * e32["grad"] + RKC_CA[2]
+
+
+def test_conv_adj_nde_rkc2_tight_parity_on_a_stratified_profile():
+    """The same model and stepper on the stably stratified synthetic profile cooled from above (32 levels, 16 save intervals): the
+    cooled surface layer still sits on the switch, so float32 and float64 part at the 1e-3 level in EVERY implementation; the HIP
+    path is held to the float32 oracle's own distance from float64."""
+    p = synthetic.free_convection_problem(19, Nz=32, n_save=17, substeps=2, convective_adjustment=True, t_end=0.125)
+    cfg = p.cfg.with_(stepper="rkc2")
+    assert colnde.rkc_stages(cfg) >= 6 and 4 * colnde.min_substeps(cfg.with_(stepper="rk4", substeps=1)) > 5 * 2 * colnde.rkc_stages(cfg)
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(cfg)
+    tot, terms, g, sol = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc)
+    tot32, _, g32, sol32 = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc, dtype=np.float32)
+    with colnde.ColumnNDE(cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    e32 = (np.abs(sol32 - sol).max(), abs(tot32 - tot) / tot, _rel(g32, g))
+    _record("rkc2/ca_nde_32_stratified", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g),
+            sol_abs_oracle32_vs_64=e32[0], loss_rel_oracle32_vs_64=e32[1], grad_rel_oracle32_vs_64=e32[2])
+    assert np.abs(sol_g - sol).max() < 4 * e32[0] + RKC_CA32[0]
+    assert abs(tot_g - tot) / tot < 4 * e32[1] + RKC_CA32[1]
+    assert _rel(grad_g, g) < 4 * e32[2] + RKC_CA32[2]
+
+
+def test_explicit_stage_count_below_the_bound_is_refused():
+    p = synthetic.free_convection_problem(3, Nz=64, n_save=5, substeps=1, convective_adjustment=True, t_end=0.04)
+    cfg = p.cfg.with_(stepper="rkc2", rkc_stages=6)
+    need = colnde.min_substeps(cfg)
+    assert need > 1
+    with colnde.ColumnNDE(cfg, 3) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        with pytest.raises(colnde.ColndeError, match="substeps >= %d" % need):
+            nde.forward(p.weights)
+    with colnde.ColumnNDE(cfg.with_(substeps=need), 3) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        assert np.isfinite(nde.forward(p.weights)).all()
+
+
+# tolerances: ~10x the errors measured on an MI355X (profiles/r02_parity_errors.json)
+# absolute floors added to a small multiple of the float32 oracle's own distance from float64 (sol, loss, gradient)
+RKC_WM = (1e-4, 1e-4, 5e-4)                    # wind mixing kappa = 10, 26 stages
+RKC_CA = (2e-2, 2e-2, 5e-2)                    # CA-NDE axis from an inverted layer
+RKC_CA32 = (5e-4, 5e-4, 1e-3)                  # CA-NDE, stratified profile

@@ -350,3 +350,113 @@ def test_discrete_vs_continuous_adjoint_gradient_gap():
     _, _, g_t, _, _ = CAd.loss_and_grad_continuous(cfg, p.x0[:1], p.bcs[:1], p.weights, truth[:1], sc, rtol=1e-7, atol=1e-10)
     _, _, g_1, _ = O.loss_and_grad(cfg.with_(substeps=16), p.x0[:1], p.bcs[:1], p.weights, truth[:1], sc)
     assert rel(g_t, g_1) < 1e-5
+
+
+# ---------------------------------------------------------------- stabilised stepper (RKC2) in the oracle
+def test_rkc2_coefficients_and_linear_decay():
+    """Consistency (c_s = 1, second order: sum of the quadrature conditions through the stability polynomial), the stability
+    boundary beta(s) ~ 0.653 s^2, and the linear-diffusion known answer: a cosine mode decays by the RKC2 stability polynomial
+    P_s(z) = a_s + b_s T_s(w0 + w1 z) per step (Sommeijer-Shampine-Verwer 1998, eq. 2.3)."""
+    for s in (2, 3, 5, 12, 40):
+        mu, nu, mut, gat, c, beta = O.rkc_coefficients(s)
+        assert abs(c[s] - 1.0) < 1e-12
+        assert 0.49 * s * s <= beta <= 0.66 * s * s
+    p = synthetic.wind_mixing_problem(1, n_frames=9, substeps=1, Ric=1e30, f=0.0, stepper="rkc2", rkc_stages=6)
+    cfg = p.cfg
+    Nz = cfg.Nz
+    s0 = [-cfg.mu[3 + k] / cfg.sigma[3 + k] for k in range(3)]
+    bcs = np.array([[s0[0], s0[0], s0[1], s0[1], s0[2], s0[2]]])
+    kk = 5
+    mode = np.cos(kk * np.pi * (np.arange(Nz) + 0.5) / Nz)
+    x0 = np.concatenate([0.3 * mode, -0.2 * mode, 0.1 + 0.0 * mode])[None]
+    sol = O.solve(cfg, x0, bcs, np.zeros(cfg.n_params))
+    kap = cfg.tau * (cfg.nu0 + cfg.nu_minus) / cfg.H ** 2
+    lam = 4 * Nz ** 2 * np.sin(kk * np.pi / (2 * Nz)) ** 2
+    z = -kap * lam * (cfg.save_times[1] - cfg.save_times[0])
+    s = 6
+    w0 = 1 + O.RKC_EPS / s ** 2
+    T, dT, d2T = O._cheb(s, w0)
+    w1, b = dT[s] / d2T[s], d2T[s] / dT[s] ** 2
+    # T_s(w0 + w1 z) by the recurrence
+    x = w0 + w1 * z
+    Ta, Tb = 1.0, x
+    for _ in range(2, s + 1):
+        Ta, Tb = Tb, 2 * x * Tb - Ta
+    P = (1 - b * T[s]) + b * Tb
+    np.testing.assert_allclose(sol[0, -1, :Nz], 0.3 * mode * P ** 8, atol=1e-12)
+    assert abs(P - np.exp(z)) < 0.1 * abs(z) ** 3             # second order: the error of one step is O(z^3)
+
+
+def test_rkc2_adjoint_matches_finite_differences_on_a_stiff_case():
+    """kappa = 10 in the convective-adjustment branch (lambda h = 375: RK4 would need 135 sub-steps per frame) with one 26-stage RKC2
+    step per frame: the discrete adjoint of the recurrence against central differences of the loss."""
+    p = synthetic.wind_mixing_problem(2, n_frames=5, weight_divisor=1e2, modified_pacanowski_philander=False, zero_weights=False,
+                                      convective_adjustment=True, kappa=10.0, stepper="rkc2", substeps=1)
+    cfg = p.cfg
+    assert O.rkc_stages(cfg) == colnde.rkc_stages(cfg) == 26 and colnde.min_substeps(cfg) == 1
+    assert colnde.min_substeps(cfg.with_(stepper="rk4")) == 135
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth)
+    assert np.isfinite(truth).all()
+    sc = O.default_loss_scalings(cfg)
+    tot, _, g, _ = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc)
+    rng = np.random.default_rng(5)
+    w = p.weights.astype(np.float64)
+    for _ in range(3):
+        d = rng.standard_normal(w.shape)
+        d /= np.linalg.norm(d)
+        h = 1e-6
+        lp = O.loss(cfg, O.solve(cfg, p.x0, p.bcs, w + h * d), truth, sc)[0]
+        lm = O.loss(cfg, O.solve(cfg, p.x0, p.bcs, w - h * d), truth, sc)[0]
+        assert np.isclose((lp - lm) / (2 * h), g @ d, rtol=2e-5, atol=1e-12)
+
+
+def test_rkc2_stage_count_follows_the_stiffness_bound():
+    for Nz, n_save, sub in ((64, 129, 1), (64, 129, 4), (32, 33, 1)):
+        cfg = synthetic.free_convection_problem(1, Nz=Nz, n_save=n_save, substeps=sub, convective_adjustment=True).cfg.with_(stepper="rkc2")
+        s = colnde.rkc_stages(cfg)
+        assert s == O.rkc_stages(cfg)
+        zh = O.stiff_lambda(cfg) / (n_save - 1) / sub
+        assert 0.9 * O.rkc_coefficients(s)[5] >= zh and (s == 2 or 0.9 * O.rkc_coefficients(s - 1)[5] < zh)
+    # an explicit stage count that does not cover the stiffest mode asks for more sub-steps
+    cfg = synthetic.free_convection_problem(1, Nz=64, n_save=129, substeps=1, convective_adjustment=True).cfg.with_(stepper="rkc2", rkc_stages=10)
+    assert colnde.min_substeps(cfg) == int(np.ceil(O.stiff_lambda(cfg) / 128 / (0.9 * O.rkc_coefficients(10)[5])))
+
+
+def test_rkc2_accuracy_against_converged_rk4():
+    """Where stability no longer sets the step, accuracy does: ConvectiveAdjustmentNDE at 64 levels from an inverted 24-cell layer,
+    RKC2 against a converged RK4 solve (230 sub-steps per interval; 460 agree to 7e-6) over the first 16 of config 4's 128 save
+    intervals — the error is made in the first adjustment and then stays.  Second-order convergence in the step count."""
+    p = synthetic.free_convection_problem(1, Nz=64, n_save=17, substeps=1, convective_adjustment=True, t_end=0.125)
+    x0 = p.x0.copy()
+    x0[:, 20:44] = x0[:, 20:44][:, ::-1]
+    ref = O.solve(p.cfg.with_(substeps=230), x0, p.bcs, p.weights)
+    errs = {}
+    for sub in (1, 4, 8):
+        cfg = p.cfg.with_(stepper="rkc2", substeps=sub)
+        errs[sub] = np.abs(O.solve(cfg, x0, p.bcs, p.weights) - ref)[:, -1].max()
+        print("RKC2 %d x %d stages: |error| at t = 0.125: %.2e" % (sub, O.rkc_stages(cfg), errs[sub]))
+    assert errs[1] < 0.3 and errs[4] < 2e-2 and errs[8] < 2e-4
+
+
+def test_rkc2_switch_pullback():
+    """The exact discrete adjoint of an s-stage stabilised step does not survive a switching right-hand side: with the switch of
+    min(0, K dT/dz) evaluated stage by stage, the stage Jacobians differ, the Chebyshev cancellations fail, and the back-propagated
+    cotangent grows without bound — while sub-stepped RK4's discrete gradient is benign.  The product (and this oracle) therefore
+    pull the switch back with ONE pattern per step (that of Y_{s-1}); the resulting gradient converges to RK4's as the step shrinks.
+    64-level ConvectiveAdjustmentNDE from an inverted layer, 8 save intervals of config 4's axis."""
+    p = synthetic.free_convection_problem(1, Nz=64, n_save=9, substeps=1, convective_adjustment=True, t_end=8 / 128)
+    x0 = p.x0.copy()
+    x0[:, 20:44] = x0[:, 20:44][:, ::-1]
+    sc = O.default_loss_scalings(p.cfg)
+    truth = O.solve(p.cfg.with_(substeps=230), x0, p.bcs, p.weights_truth)
+    _, _, g4, _ = O.loss_and_grad(p.cfg.with_(substeps=230), x0, p.bcs, p.weights, truth, sc)
+    cos = lambda a, b: a @ b / np.linalg.norm(a) / np.linalg.norm(b)
+    with np.errstate(all="ignore"):
+        _, _, g_exact, _ = O.loss_and_grad(p.cfg.with_(stepper="rkc2", substeps=8, rkc_exact_switch_pullback=True), x0, p.bcs, p.weights, truth, sc)
+    assert not np.isfinite(g_exact).all() or np.linalg.norm(g_exact) > 1e6 * np.linalg.norm(g4)
+    res = {}
+    for sub in (8, 16):
+        _, _, g, _ = O.loss_and_grad(p.cfg.with_(stepper="rkc2", substeps=sub), x0, p.bcs, p.weights, truth, sc)
+        res[sub] = (np.linalg.norm(g - g4) / np.linalg.norm(g4), cos(g, g4))
+        print("RKC2 %d steps per interval, one switch pattern per step: |g - g_RK4|/|g_RK4| = %.3f, cosine %.5f" % (sub, *res[sub]))
+    assert res[8][1] > 0.99 and res[16][1] > 0.999 and res[16][0] < res[8][0] < 0.15
