@@ -1,6 +1,8 @@
 # ColumnNDE.jl — thin `ccall` layer over libcolnde.so (include/colnde.h) that keeps the reference's call signatures.
-# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia (SURVEY §8c).  It mirrors, line for line, the
-# ctypes front-end that IS tested (climateparameterizations.jl_amd/nde.py, wind_mixing.py).
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia (SURVEY §8c).  It mirrors, call for call, the ctypes front-end
+# that IS tested (climateparameterizations.jl_amd/nde.py, wind_mixing.py, free_convection.py, distributed.py); the struct layout it
+# relies on is checked field by field against include/colnde.h by tests/test_abi.py::test_julia_config_mirrors_the_header, and the
+# same ABI is driven from plain C by tests/abi_smoke.c.
 module ColumnNDE
 
 using Flux, ChainRulesCore
@@ -21,12 +23,29 @@ Base.@kwdef mutable struct Config
     ca_K::Float32 = 10f0
     n_save::Int32 = 2; substeps::Int32 = 2; save_times::Ptr{Float32} = C_NULL
     n_columns::Int32 = 1; device::Int32 = 0; engine::Int32 = 0
+    stepper::Int32 = 0; rkc_stages::Int32 = 0                            # COLNDE_STEPPER_RK4 / _RKC2 (stands where the reference uses ROCK4)
 end
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:colnde_last_error, libcolnde), Cstring, ())))
 
 mutable struct Handle
     ptr::Ptr{Cvoid}; n_params::Int; n_state::Int; n_save::Int; n_columns::Int
+end
+
+"least RK4 sub-steps per save interval inside the stability bound / stages of the RKC2 step (no GPU needed)"
+function min_substeps(cfg::Config, save_times::Vector{Float32})
+    cfg.n_save = length(save_times)
+    GC.@preserve save_times begin
+        cfg.save_times = pointer(save_times)
+        ccall((:colnde_min_substeps, libcolnde), Cint, (Ref{Config},), cfg)
+    end
+end
+function rkc_stages(cfg::Config, save_times::Vector{Float32})
+    cfg.n_save = length(save_times)
+    GC.@preserve save_times begin
+        cfg.save_times = pointer(save_times)
+        ccall((:colnde_rkc_stages, libcolnde), Cint, (Ref{Config},), cfg)
+    end
 end
 
 "constants/scalings/conditions as built by prepare_parameters_NDE_training (NDE_training.jl:1-44); t_train ./ τ as save_times"
@@ -51,6 +70,13 @@ set_problem!(h::Handle, uvT₀s::Matrix{Float32}, BCs::Matrix{Float32}, uvT_trai
 function NDE(h::Handle, x::Vector{Float32}, p::Vector{Float32}, t)
     dx = similar(x)
     NDE!(h, dx, x, p, t); dx
+end
+
+"diurnal overload NDE(x, p, t) — NDE_training.jl:68-81: `p` carries only 5 BCs, wT_top(t) comes from Qᵇ (parsed from the file name,
+data_containers.jl:138-152); create the handle with diurnal = 1 and pass Qᵇ here (it fills the sixth BC slot of the C ABI)"
+function NDE(h::Handle, x::Vector{Float32}, p::Vector{Float32}, t, Qᵇ::Real)
+    length(p) == h.n_params + 5 || error("the diurnal NDE takes p = [weights; uw_b, uw_t, vw_b, vw_t, wT_b]")
+    NDE(h, x, vcat(p, Float32(Qᵇ)), t)
 end
 
 "NDE!(dx, x, p, t) — wind_mixing/src/training_postprocessing.jl:131-153 (create the handle with inplace_variant = 1)"
@@ -93,6 +119,100 @@ function ChainRulesCore.rrule(::typeof(loss_gradient_NDE), h::Handle, weights, l
     pullback(ȳ) = (NoTangent(), NoTangent(), ȳ[1] .* grad, NoTangent())
     (total, losses, loss_scalings), pullback
 end
+
+# ---- free convection: FreeConvectionNDE / ConvectiveAdjustmentNDE (model = 1 / 2) -------------------------------------------
+
+"∂T∂t(T, p, t) with p = [weights; bottom_flux, top_flux, σ_T, σ_wT, H, τ] — free_convection/src/free_convection_nde.jl:29-38,
+convective_adjustment_nde.jl:33-48 (the four trailing scalars are constants of the handle's configuration)"
+function ∂T∂t(h::Handle, T::Vector{Float32}, p::Vector{Float32}, t)
+    dT = similar(T); w = @view p[1:h.n_params]; bc = @view p[h.n_params+1:h.n_params+2]
+    check(ccall((:colnde_rhs, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Ptr{Float32}, Cint),
+                h.ptr, T, w, bc, Float32(t), dT, 1))
+    dT
+end
+
+"solve_nde(nde, NN, T₀, alg, nde_params) for every simulation of the handle — free_convection/src/solve.jl:1-6: Nz × Nt per simulation"
+solve_nde(h::Handle, NN) = solve_NDE(h, first(Flux.destructure(NN)))
+
+"nde_loss() = Flux.mse(cat(nde_sols...), true_sols) [+ causal_penalty(NN)] — free_convection/src/training.jl:55-62"
+function nde_loss(h::Handle, NN; causal_penalty=nothing)
+    θ = first(Flux.destructure(NN))
+    terms = zeros(Float32, 6); total = Ref{Float32}(0)
+    check(ccall((:colnde_loss, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ref{Float32}),
+                h.ptr, θ, Float32[0, 0, 1, 0, 0, 0], terms, total))
+    causal_penalty === nothing ? total[] : total[] + causal_penalty(NN)
+end
+
+"value of nde_loss and its gradient as a `Zygote.Grads` keyed by the arrays of `Flux.params(NN)` — what `Flux.train!`
+(training.jl:71) obtains from `gradient(() -> nde_loss(), ps)`.  `Flux.destructure` concatenates exactly the arrays of
+`Flux.params(NN)` in order (W₁, b₁, W₂, b₂, …), so the flat HIP gradient is cut back along the same sizes."
+function nde_loss_gradient(h::Handle, NN; causal_penalty=nothing)
+    θ = first(Flux.destructure(NN)); ps = Flux.params(NN)
+    terms = zeros(Float32, 6); total = Ref{Float32}(0); grad = similar(θ)
+    check(ccall((:colnde_loss_grad, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ref{Float32}, Ptr{Float32}),
+                h.ptr, θ, Float32[0, 0, 1, 0, 0, 0], terms, total, grad))
+    gs = IdDict{Any,Any}(); o = 0
+    for p in ps
+        gs[p] = reshape(grad[o+1:o+length(p)], size(p)); o += length(p)
+    end
+    loss = total[]
+    if causal_penalty !== nothing                      # a function of the weights alone: Zygote differentiates it as before
+        pen, back = Flux.Zygote.pullback(() -> causal_penalty(NN), ps)
+        gp = back(one(pen)); loss += pen
+        for p in ps
+            gp[p] === nothing || (gs[p] = gs[p] .+ gp[p])
+        end
+    end
+    loss, Flux.Zygote.Grads(gs, ps)
+end
+
+"train_neural_differential_equation! — training.jl:44-74: `Flux.train!(nde_loss, Flux.params(NN), repeated((), epochs), opt, cb)`
+with the gradient from the HIP adjoint; `opt`'s state is keyed by the arrays of `Flux.params(NN)` and persists across calls, as in Flux"
+function train_neural_differential_equation!(h::Handle, NN, opt, epochs; cb=() -> nothing, causal_penalty=nothing)
+    ps = Flux.params(NN)
+    for _ in 1:epochs
+        _, gs = nde_loss_gradient(h, NN; causal_penalty)
+        Flux.Optimise.update!(opt, ps, gs)
+        cb()
+    end
+    nothing
+end
+
+"compute_neural_network_forcing!(params, model) — free_convection/double_gyre_nn.jl:149-168: T_interior is `interior(model.tracers.T)`
+permuted to (Nz, Nx·Ny); surface_flux (Nx·Ny) is the relaxation flux of :163; writes −∂z wT into `forcing` (Nz, Nx·Ny)"
+function compute_neural_network_forcing!(forcing::Matrix{Float32}, h::Handle, weights::Vector{Float32}, T_interior::Matrix{Float32},
+                                         surface_flux::Vector{Float32}, Lz)
+    check(ccall((:colnde_infer_forcing, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Ptr{Float32}, Cint),
+                h.ptr, weights, T_interior, surface_flux, Float32(Lz), forcing, size(T_interior, 2)))
+    forcing
+end
+
+"how the gradient path runs: (engine, block_columns, n_blocks, z1_taped, dw_taped, dw_slices) — colnde_plan"
+function plan(h::Handle)
+    info = zeros(Cint, 8)
+    check(ccall((:colnde_plan, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Cint}), h.ptr, info))
+    (engine=info[1], block_columns=info[2], n_blocks=info[3], z1_taped=info[4] != 0, dw_taped=info[5] != 0, dw_slices=info[6])
+end
+
+# ---- multi-GPU: one Julia process per GPU, columns sharded, ONE exchange per optimiser iteration (include/colnde.h, colnde_comm_*) ----
+mutable struct Comm
+    ptr::Ptr{Cvoid}
+end
+"rank 0 makes the 128-byte RCCL id and hands it to every rank (MPI.Bcast!, a file, a socket) before `Comm(...)`"
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:colnde_comm_unique_id, libcolnde), Cint, (Ptr{UInt8},), id)); id
+end
+function Comm(rank, nranks, unique_id::Vector{UInt8}, device=0)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:colnde_comm_create, libcolnde), Cint, (Cint, Cint, Ptr{UInt8}, Cint, Ref{Ptr{Cvoid}}), rank, nranks, unique_id, device, out))
+    c = Comm(out[]); finalizer(x -> ccall((:colnde_comm_destroy, libcolnde), Cvoid, (Ptr{Cvoid},), x.ptr), c)
+end
+"set_global_columns!(h, N): losses and gradients of this rank are normalised by the GLOBAL simulation count (NDE_training.jl:312-317)"
+set_global_columns!(h::Handle, N) = check(ccall((:colnde_set_global_columns, libcolnde), Cint, (Ptr{Cvoid}, Int64), h.ptr, N))
+"SUM over the ranks of the device result buffer [grad; 6 terms; total; 0] of colnde_loss_grad_dev, on the handle's stream"
+allreduce_result!(h::Handle, c::Comm, d_out::Ptr{Float32}) =
+    check(ccall((:colnde_allreduce_result_dev, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}), h.ptr, c.ptr, d_out))
 
 "convective_adjustment!(model, Δt, K) — free_convection/double_gyre_nn.jl:27-62: T is `interior(model.tracers.T)` permuted to
 (Nz, Nx·Ny) column-major (= C-order [column][level]); halos are `nothing` for flux-bounded T (zero-gradient fill) or the two

@@ -106,3 +106,59 @@ def test_min_substeps_is_the_rk4_diffusive_bound():
     assert colnde.min_substeps(synthetic.free_convection_problem(1, Nz=64, n_save=129).cfg) == 1
     # a non-uniform axis is judged by its widest interval
     assert colnde.min_substeps(p.cfg.with_(save_times=(0.0, 0.001, 0.011))) == int(np.ceil(lam * 0.01 / 2.785))
+
+
+def _header_prototypes():
+    text = open(os.path.join(ROOT, "include", "colnde.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(colnde_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return protos
+
+
+def test_julia_config_mirrors_the_header():
+    """julia/ColumnNDE.jl cannot run here (no Julia in the image), so its `Config` struct — the one thing a silent layout drift would
+    break — is checked as text: same field names, order, element types and array lengths as `colnde_config` and its ctypes twin."""
+    jl = open(os.path.join(ROOT, "julia", "ColumnNDE.jl")).read()
+    body = jl[jl.index("Base.@kwdef mutable struct Config"):]
+    body = body[:body.index("\nend")]
+    body = re.sub(r"#.*", "", body)
+    fields = re.findall(r"([A-Za-z_][A-Za-z_0-9]*)::((?:NTuple\{\d+,\s*(?:Int32|Float32)\})|Int32|Float32|Ptr\{Float32\})", body)
+    cmap = {ctypes.c_int32: "Int32", ctypes.c_float: "Float32"}
+    expect = []
+    for name, ct in CConfig._fields_:
+        if hasattr(ct, "_length_"):
+            expect.append((name, "NTuple{%d,%s}" % (ct._length_, cmap[ct._type_])))
+        elif ct in cmap:
+            expect.append((name, cmap[ct]))
+        else:
+            expect.append((name, "Ptr{Float32}"))
+    assert [(n, t.replace(" ", "")) for n, t in fields] == expect
+
+
+def test_julia_ccalls_name_declared_symbols_with_the_right_arity():
+    jl = open(os.path.join(ROOT, "julia", "ColumnNDE.jl")).read()
+    protos = _header_prototypes()
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(colnde_[a-z_0-9]+),\s*libcolnde\),\s*\w+,\s*\(", jl):
+        i, depth = m.end(), 1                      # the balanced Julia argument-type tuple that follows
+        while depth:
+            depth += {"(": 1, ")": -1}.get(jl[i], 0)
+            i += 1
+        calls.append((m.group(1), jl[m.end():i - 1]))
+    assert len(calls) >= 20
+    for name, argtypes in calls:
+        assert name in protos, name
+        depth, parts, cur = 0, [], ""
+        for ch in argtypes:                       # top-level commas only (Ptr{...}, Ref{...} nest braces)
+            depth += {"{": 1, "(": 1, "}": -1, ")": -1}.get(ch, 0)
+            if ch == "," and depth == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        parts.append(cur)
+        n = len([q for q in parts if q.strip()])
+        assert n == protos[name], (name, n, protos[name])
