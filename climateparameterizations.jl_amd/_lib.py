@@ -39,6 +39,8 @@ SYMBOLS = [
     ("colnde_convective_adjustment", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, ctypes.c_float, ctypes.c_float, _V, ctypes.c_int]),
     ("colnde_convective_adjustment_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, ctypes.c_float, ctypes.c_float, _V, ctypes.c_int]),
     ("colnde_adam_step_dev", ctypes.c_int, [_V, _V, _V, _V, _V] + [ctypes.c_float] * 6 + [ctypes.c_int]),
+    ("colnde_pretrain_flux_dev", ctypes.c_int, [_V, ctypes.c_int, _V, _V, _V, _V, _V, _V, _V, ctypes.c_int] + [ctypes.c_float] * 5 +
+     [ctypes.POINTER(ctypes.c_double), ctypes.c_int, _F]),
     ("colnde_coarse_grain_dev", ctypes.c_int, [_V, _V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _V]),
     ("colnde_zscore_stats_dev", ctypes.c_int, [_V, _V, ctypes.c_int64, _V]),
     ("colnde_scale_dev", ctypes.c_int, [_V, _V, ctypes.c_int64, _V, _V]),

@@ -1090,6 +1090,38 @@ extern "C" int colnde_allreduce_result_dev(colnde_handle* h, colnde_comm* comm, 
     return colnde_comm_allreduce_dev(comm, d_out, (int64_t)h->m.n_params + 8, 0, (void*)h->stream);
 }
 
+// ---- flux-MLP pre-training (second half) ---------------------------------------------------------------------
+extern "C" int colnde_pretrain_flux_dev(colnde_handle* h, int flux_type, float* d_theta, float* d_m, float* d_v, const float* d_profiles,
+                                        const float* d_bcs, const float* d_flux, const int32_t* d_order, int n_samples,
+                                        float gradient_scaling, float eta, float beta1, float beta2, float eps, double beta_t[2],
+                                        int update, float* mean_loss) {
+    if (!h) return fail("null handle");
+    if (!d_theta || !d_profiles || !d_bcs || !d_flux || !beta_t || !mean_loss) return fail("null pointer argument");
+    if (update && (!d_m || !d_v)) return fail("the ADAM moments are needed when update != 0");
+    if (n_samples < 1) return fail("n_samples must be >= 1");
+    const bool wm = h->m.model == COLNDE_MODEL_WIND_MIXING;
+    if (flux_type < 0 || flux_type > 2 || (!wm && flux_type != 2)) return fail("flux_type: 0 = uw, 1 = vw, 2 = wT (T-only models: 2)");
+    if (h->m.smooth_NN || h->m.smooth_Ri) return fail("flux pre-training does not cover the smoothing options");
+    if (h->m.inplace) return fail("flux pre-training uses the training arithmetic (inplace_variant = 0)");
+    if (!(beta_t[0] < 1.0 && beta_t[1] < 1.0)) return fail("running powers beta^t must be < 1");
+    HIPCHK(hipSetDevice(h->device));
+    float* d_loss = nullptr;
+    HIPCHK(hipMalloc((void**)&d_loss, sizeof(float) + 2 * sizeof(double) + 8));
+    double* d_bt = reinterpret_cast<double*>(reinterpret_cast<char*>(d_loss) + 8);
+    hipError_t e = launch_pretrain(h->m, flux_type, d_theta, d_m, d_v, d_profiles, d_bcs, d_flux, d_order, n_samples, gradient_scaling,
+                                   eta, beta1, beta2, eps, beta_t[0], beta_t[1], update, d_loss, d_bt, h->stream);
+    float loss = 0.0f;
+    double bt[2] = {beta_t[0], beta_t[1]};
+    if (e == hipSuccess) e = hipMemcpyAsync(&loss, d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(bt, d_bt, sizeof(bt), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_loss);
+    if (e != hipSuccess) return fail("flux pre-training failed: %s", hipGetErrorString(e));
+    *mean_loss = loss / (float)n_samples;
+    if (update) { beta_t[0] = bt[0]; beta_t[1] = bt[1]; }
+    return 0;
+}
+
 extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
     if (!h || !info) return fail("null argument");
     for (int i = 0; i < 8; i++) info[i] = 0;

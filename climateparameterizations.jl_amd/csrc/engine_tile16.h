@@ -52,6 +52,10 @@ hipError_t launch_reduce(const float* slab, int n_tiles, int n_params, int strid
 hipError_t launch_infer(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* T,
                         const float* top_flux, float inv_dz, float* out, int n_col, int nthreads, size_t lds_bytes,
                         hipStream_t stream);
+// flux-MLP pre-training (train_NN): one pass over the data set, one ADAM update per sample (update = 0: mean-loss evaluation only)
+hipError_t launch_pretrain(const DevModel& m, int flux_type, float* theta, float* mom, float* vel, const float* X, const float* BC,
+                           const float* Y, const int* order, int n_samples, float gs, float eta, float b1, float b2, float eps,
+                           double bt1, double bt2, int update, float* loss_out, double* bt_out, hipStream_t stream);
 bool pick_adjoint_geom(const DevModel& m, AdjointGeom* geo, int force);
 size_t lds_floats_adjoint_geom(const DevModel& m, const AdjointGeom& g);
 hipError_t debug_read_stamps(unsigned long long* out16);

@@ -500,6 +500,157 @@ __device__ void physics_vjp(const DevModel& m, const float* xs, const float* dba
 }
 
 // ------------------------------------------------------------------------------------------------
+// flux-MLP pre-training: `train_NN` — wind_mixing/src/NN_training.jl:207-249 with predict_uw/vw/wT (:25-169) —
+// and the T -> wT pre-training of free_convection/train_free_convection_nde.jl:186-216.  `Flux.train!(NN_loss, params, data, opt)`
+// makes ONE ADAM update per data point, in order: an inherently serial chain of tiny dense products, so one workgroup walks the
+// whole (shuffled) data set with the weights, moments and activations on chip / in L2, and only the per-pass loss leaves the GPU.
+//     NN_flux = [b; NN(x); t]-style face vector minus the diffusive / adjustment flux of the state (independent of the weights)
+//     loss    = mse(NN_flux, flux) + gradient_scaling * mse(D^c flux, D^c NN_flux)
+// update = 0 evaluates the mean loss at fixed weights (`total_loss(training_data)`, :234-236).
+// LDS: act[act_total + ns] (a_0 = x, then every layer's activations), z[act_total] pre-activations, d[act_total] deltas,
+//      F, y, c: [Nz + 1] face vectors, red[64].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+pretrain_kernel(DevModel m, int flux_type, float* __restrict__ theta, float* __restrict__ mom, float* __restrict__ vel,
+                const float* __restrict__ X, const float* __restrict__ BC, const float* __restrict__ Y, const int* __restrict__ order,
+                int n_samples, float gs, float eta, float b1, float b2, float eps_adam, double bt1, double bt2, int update,
+                float* __restrict__ loss_out, double* __restrict__ bt_out) {
+    extern __shared__ __attribute__((aligned(16))) float pt_smem[];
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int Nz = m.Nz, nf = Nz + 1, L = m.n_layers, ns = m.ns;
+    float* a0 = pt_smem;                       // x
+    float* act = a0 + ((ns + 3) & ~3);         // a_l at act + act_off[l-1]... (act_off[l] = offset of layer l+1's outputs)
+    float* zz = act + m.act_total + 4;
+    float* dd = zz + m.act_total + 4;
+    float* F = dd + m.act_total + 4;
+    float* yv = F + nf + 3;
+    float* cf = yv + nf + 3;
+    float* red = cf + nf + 3;
+    const bool wm = m.model == COLNDE_MODEL_WIND_MIXING;
+    const int k = wm ? flux_type : 2;
+    double p1 = bt1, p2 = bt2;                 // running powers beta^t (uniform over the workgroup)
+    float loss_sum = 0.0f;
+    for (int s = 0; s < n_samples; s++) {
+        const int idx = order ? order[s] : s;
+        for (int i = tid; i < ns; i += nth) a0[i] = X[(size_t)idx * ns + i];
+        for (int f = tid; f < nf; f += nth) yv[f] = Y[(size_t)idx * nf + f];
+        __syncthreads();
+        // weight-independent part of the face flux: boundary faces and the diffusive / adjustment flux of the state
+        for (int f = tid; f < nf; f += nth) {
+            const float* bc = BC + (size_t)idx * m.n_bc;
+            float c = 0.0f;
+            if (wm) {
+                const float bb = bc[2 * k], bt = bc[2 * k + 1];
+                const bool in = f >= 1 && f < Nz;
+                if (!in) c = m.zero_w ? (f == 0 ? bb : bt) - m.s0[k] : (f == 0 ? bb : bt);      // (MPP's end faces: NN_training.jl:62-66)
+                else if (m.mpp) {
+                    const FaceGrad g = wm_face(m, a0, f, m.eps);
+                    const float nu = m.nu0 + m.nu_minus * (1.0f - fast_tanh((g.Ri - m.Ric) * m.inv_dRi)) * 0.5f;
+                    c = -m.cs[k] * (k == 2 ? nu * m.inv_Pr : nu) * (k == 0 ? g.gu : (k == 1 ? g.gv : g.gT));
+                } else if (m.ca && k == 2) {
+                    const float gT = (a0[2 * Nz + f] - a0[2 * Nz + f - 1]) * (float)Nz;
+                    c = -m.cs[2] * m.kappa * fminf(0.0f, gT);
+                }
+            } else {
+                c = f == 0 ? bc[0] : (f == Nz ? bc[1] : 0.0f);
+            }
+            cf[f] = c;
+        }
+        // forward
+        const float* th = theta + (wm ? k * m.net_size : 0);
+        for (int l = 0; l < L; l++) {
+            const int ni = m.sizes[l], no = m.sizes[l + 1];
+            const float* ain = l == 0 ? a0 : act + m.act_off[l - 1];
+            const float* W = th + m.w_off[l];
+            for (int o = tid; o < no; o += nth) {
+                float acc = th[m.b_off[l] + o];
+                for (int i = 0; i < ni; i++) acc = fmaf(W[i * no + o], ain[i], acc);
+                zz[m.act_off[l] + o] = acc;
+                act[m.act_off[l] + o] = dev_act(m.acts[l], acc);
+            }
+            __syncthreads();
+        }
+        // face flux, loss and its cotangent on the network output
+        const float* out = act + m.act_off[L - 1];
+        for (int f = tid; f < nf; f += nth) F[f] = cf[f] + ((f >= 1 && f < Nz) ? out[f - 1] : 0.0f);
+        __syncthreads();
+        float part = 0.0f;
+        for (int f = tid; f < nf; f += nth) {
+            const float r = F[f] - yv[f];
+            part += r * r * (1.0f / (float)nf);
+            if (f < Nz) {
+                const float dg = ((F[f + 1] - F[f]) - (yv[f + 1] - yv[f])) * (float)Nz;
+                part += gs * dg * dg * (1.0f / (float)Nz);
+            }
+            if (f >= 1 && f < Nz) {
+                const float dgm = ((F[f] - F[f - 1]) - (yv[f] - yv[f - 1])) * (float)Nz;
+                const float dgp = ((F[f + 1] - F[f]) - (yv[f + 1] - yv[f])) * (float)Nz;
+                const float g = 2.0f / (float)nf * r + gs * 2.0f * (dgm - dgp);
+                dd[m.act_off[L - 1] + f - 1] = g * dev_act_grad(m.acts[L - 1], zz[m.act_off[L - 1] + f - 1]);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.0f;
+            for (int w = 0; w < (nth >> 6); w++) t += red[w];
+            loss_sum += t;
+        }
+        if (!update) { __syncthreads(); continue; }
+        // backward: every delta with the weights as they stood before this sample's update
+        for (int l = L - 1; l >= 1; l--) {
+            const int ni = m.sizes[l], no = m.sizes[l + 1];
+            const float* W = th + m.w_off[l];
+            for (int i = tid; i < ni; i += nth) {
+                float acc = 0.0f;
+                for (int o = 0; o < no; o++) acc = fmaf(W[i * no + o], dd[m.act_off[l] + o], acc);
+                dd[m.act_off[l - 1] + i] = acc * dev_act_grad(m.acts[l - 1], zz[m.act_off[l - 1] + i]);
+            }
+            __syncthreads();
+        }
+        // Flux ADAM (apply! + update!) on every parameter of this net; gradient element = delta_out * input (bias: delta_out)
+        const float c1 = (float)(1.0 / (1.0 - p1)), c2 = (float)(1.0 / (1.0 - p2));
+        float* tw = theta + (wm ? k * m.net_size : 0);
+        float* tm = mom + (wm ? k * m.net_size : 0);
+        float* tv = vel + (wm ? k * m.net_size : 0);
+        for (int l = 0; l < L; l++) {
+            const int ni = m.sizes[l], no = m.sizes[l + 1];
+            const float* ain = l == 0 ? a0 : act + m.act_off[l - 1];
+            const int nw = ni * no;
+            for (int e = tid; e < nw + no; e += nth) {
+                const bool bias = e >= nw;
+                const int o = bias ? e - nw : e % no, i = bias ? 0 : e / no;
+                const float g = dd[m.act_off[l] + o] * (bias ? 1.0f : ain[i]);
+                const int q = (bias ? m.b_off[l] - nw : m.w_off[l]) + e;
+                const float mt = b1 * tm[q] + (1.0f - b1) * g;
+                const float vt = b2 * tv[q] + (1.0f - b2) * g * g;
+                tm[q] = mt;
+                tv[q] = vt;
+                tw[q] -= eta * (mt * c1) / (sqrtf(vt * c2) + eps_adam);
+            }
+        }
+        p1 *= (double)b1;
+        p2 *= (double)b2;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        loss_out[0] = loss_sum;
+        if (bt_out) { bt_out[0] = p1; bt_out[1] = p2; }
+    }
+}
+
+hipError_t launch_pretrain(const DevModel& m, int flux_type, float* theta, float* mom, float* vel, const float* X, const float* BC,
+                           const float* Y, const int* order, int n_samples, float gs, float eta, float b1, float b2, float eps,
+                           double bt1, double bt2, int update, float* loss_out, double* bt_out, hipStream_t stream) {
+    const size_t lds = (size_t)(((m.ns + 3) & ~3) + 3 * (m.act_total + 4) + 3 * (m.Nz + 4) + 64) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pretrain_kernel, dim3(1), dim3(512), lds, stream, m, flux_type, theta, mom, vel, X, BC, Y, order, n_samples, gs, eta,
+                       b1, b2, eps, bt1, bt2, update, loss_out, bt_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS carving (must match engine_tile16.h: lds_floats_*)
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) float smem[];

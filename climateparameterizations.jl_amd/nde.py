@@ -114,6 +114,32 @@ class ColumnNDE:
         return dict(engine=info[0], block_columns=info[1], n_blocks=info[2], z1_taped=bool(info[3]),
                     dw_taped=bool(info[4]), dw_slices=info[5])
 
+    def pretrain_flux(self, flux_type: int, theta, m, v, profiles, bcs, fluxes, order, gradient_scaling: float, opt, update: bool = True):
+        """`colnde_pretrain_flux_dev`: one `Flux.train!` pass (one ADAM update per sample, in `order`) over device tensors; `opt` is a
+        flux_compat.ADAM whose running powers are advanced.  Returns the mean per-sample loss (update=False: at fixed weights)."""
+        self._chk_dev(theta, (self.n_params,))
+        n = int(profiles.shape[0])
+        self._chk_dev(profiles, (n, self.cfg.n_state))
+        self._chk_dev(bcs, (n, self.cfg.n_bc))
+        self._chk_dev(fluxes, (n, self.cfg.Nz + 1))
+        if update:
+            self._chk_dev(m, (self.n_params,))
+            self._chk_dev(v, (self.n_params,))
+        import torch
+        if order is not None and (order.dtype != torch.int32 or not order.is_cuda or order.numel() != n):
+            raise ValueError("order must be an int32 device tensor of n entries")
+        self.use_torch_stream()
+        bt = (ctypes.c_double * 2)(*opt.beta_t)
+        loss = ctypes.c_float(0)
+        _lib.check(self._L.colnde_pretrain_flux_dev(self._h, int(flux_type), theta.data_ptr(), m.data_ptr() if m is not None else None,
+                                                    v.data_ptr() if v is not None else None, profiles.data_ptr(), bcs.data_ptr(),
+                                                    fluxes.data_ptr(), order.data_ptr() if order is not None else None, n,
+                                                    float(gradient_scaling), opt.eta, opt.beta[0], opt.beta[1], opt.eps, bt, int(bool(update)),
+                                                    ctypes.byref(loss)))
+        if update:
+            opt.beta_t = [bt[0], bt[1]]
+        return float(loss.value)
+
     def reset_kernel_times(self):
         _lib.check(self._L.colnde_reset_kernel_times(self._h))
 

@@ -212,3 +212,32 @@ def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM]
     H = torch.stack(hist).cpu().numpy() if hist else np.zeros((0, 7), np.float32)
     history = [dict(total=float(r[6]), **{k: float(r[i]) for i, k in enumerate(LOSS_KEYS)}) for r in H]
     return TrainResult(theta.cpu().numpy(), history)
+
+
+def train_NN(engine: ColumnNDE, NN_type: str, weights, profiles, BCs, fluxes, optimizers: Sequence[ADAM], train_epochs: Sequence[int],
+             gradient_scaling: float = 1e-4, order=None, cb: Optional[Callable] = None):
+    """`train_NN(NN, 𝒟train, optimizers, train_epochs, FILE_PATH, NN_type; …)` — wind_mixing/src/NN_training.jl:207-249: for each
+    optimiser and epoch one `Flux.train!(NN_loss, Flux.params(NN), training_data, opt)` (ONE ADAM update per shuffled sample) followed by
+    `total_loss(training_data)`, which `cb(total_loss, weights)` receives where the reference calls `write_data_NN_training`.
+    The whole pass runs on the GPU (`colnde_pretrain_flux_dev`); `profiles` [n, 3Nz] = columns of 𝒟.uvT_scaled, `BCs` [n, 6],
+    `fluxes` [n, Nz+1] = columns of 𝒟.<NN_type>.scaled, `order` = the shuffled sample order (default: as given).
+    `weights`: the full [uw; vw; wT] vector — only the net being trained changes.  Returns (weights, [total loss per epoch])."""
+    import torch
+    k = {"uw": 0, "vw": 1, "wT": 2}[NN_type]
+    dev = torch.device("cuda", engine.device)
+    t = lambda a, dt=np.float32: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    theta, X, B, Y = t(weights), t(profiles), t(BCs), t(fluxes)
+    od = None if order is None else t(order, np.int32)
+    hist = []
+    for opt, n_ep in zip(optimizers, train_epochs):
+        m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+        if opt.m is not None:
+            m.copy_(t(opt.m)); v.copy_(t(opt.v))
+        for _ in range(n_ep):
+            engine.pretrain_flux(k, theta, m, v, X, B, Y, od, gradient_scaling, opt, update=True)
+            total = engine.pretrain_flux(k, theta, None, None, X, B, Y, od, gradient_scaling, opt, update=False)
+            hist.append(total)
+            if cb is not None:
+                cb(total, theta)
+        opt.m, opt.v = m.double().cpu().numpy(), v.double().cpu().numpy()
+    return theta.cpu().numpy(), hist

@@ -160,6 +160,21 @@ int colnde_convective_adjustment_dev(colnde_handle* h, const float* d_T, const f
 int colnde_adam_step_dev(colnde_handle* h, float* d_weights, const float* d_grad, float* d_m, float* d_v, float eta, float beta1,
                          float beta2, float eps, float beta1_t, float beta2_t, int n);
 
+/* Flux-MLP pre-training: one pass of `Flux.train!(NN_loss, Flux.params(NN), training_data, opt)` — `train_NN`,
+ * wind_mixing/src/NN_training.jl:207-249 with the flux closures predict_uw / predict_vw / predict_wT (:25-169); T -> wT pre-training of
+ * free_convection/train_free_convection_nde.jl:186-216 — i.e. ONE Flux-ADAM update per sample, in the order given:
+ *   NN_flux = face vector of net `flux_type` (0 = uw, 1 = vw, 2 = wT; T-only models: 2) for the sample's profile and BCs, as the
+ *             handle's conditions say (MPP / convective adjustment / zero_weights; the smoothing options are not covered);
+ *   loss    = mse(NN_flux, flux) + gradient_scaling * mse(D^c flux, D^c NN_flux).
+ * d_theta / d_m / d_v: the handle's full weight vector and its ADAM moments (n_params floats; only the net trained is touched);
+ * d_profiles [n][n_state], d_bcs [n][n_bc], d_flux [n][Nz+1] scaled fluxes on faces, d_order [n] sample order (NULL: 0..n-1);
+ * beta_t[2]: the optimiser's running powers (host, updated in place).  update = 0: no update, *mean_loss = mean loss at the given
+ * weights (`total_loss(training_data)`, :234-236); update != 0: *mean_loss = mean of each sample's loss just before its update.
+ * Synchronises the handle's stream. */
+int colnde_pretrain_flux_dev(colnde_handle* h, int flux_type, float* d_theta, float* d_m, float* d_v, const float* d_profiles,
+                             const float* d_bcs, const float* d_flux, const int32_t* d_order, int n_samples, float gradient_scaling,
+                             float eta, float beta1, float beta2, float eps, double beta_t[2], int update, float* mean_loss);
+
 /* Data preparation on device (wind_mixing/src/data_containers.jl:343-427).  d_in [n_rows][N] -> d_out [n_rows][n], one row per
  * profile.  location 0 = Center: coarse_grain(Φ, n, Center) (src/DataWrangling/coarse_graining.jl:8-16), block means, n divides N;
  * location 1 = Face: coarse_grain_linear_interpolation(Φ, n, Face) (:47-62), end points kept (the form data_containers.jl:357 uses). */

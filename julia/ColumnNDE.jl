@@ -233,4 +233,16 @@ function adam_step!(h::Handle, dθ::Ptr{Float32}, dg::Ptr{Float32}, dm::Ptr{Floa
     βᵗ .* β
 end
 
+"one `Flux.train!(NN_loss, Flux.params(NN), training_data, opt)` pass of train_NN (NN_training.jl:207-249) on device arrays: one ADAM
+update per sample in `order`; returns (mean loss, βᵗ).  update = false evaluates `total_loss(training_data)` at fixed weights."
+function pretrain_flux!(h::Handle, flux_type, dθ::Ptr{Float32}, dm::Ptr{Float32}, dv::Ptr{Float32}, dX::Ptr{Float32}, dBCs::Ptr{Float32},
+                        dflux::Ptr{Float32}, dorder::Ptr{Int32}, n, gradient_scaling, η, β, ϵ, βᵗ::Vector{Float64}; update=true)
+    loss = Ref{Float32}(0)
+    check(ccall((:colnde_pretrain_flux_dev, libcolnde), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Int32}, Cint,
+         Cfloat, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Float64}, Cint, Ref{Float32}),
+        h.ptr, flux_type, dθ, dm, dv, dX, dBCs, dflux, dorder, n, gradient_scaling, η, β[1], β[2], ϵ, βᵗ, update ? 1 : 0, loss))
+    loss[], βᵗ
+end
+
 end # module

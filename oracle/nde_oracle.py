@@ -767,3 +767,87 @@ def zero_mean_unit_variance(data):
     data = np.asarray(data, np.float64)
     mu, sigma = data.mean(), data.std(ddof=1)
     return (data - mu) / sigma, mu, sigma
+
+
+# ----------------------------------------------------------------------------------------------
+# flux-MLP pre-training: predict_uw / predict_vw / predict_wT and train_NN
+# (wind_mixing/src/NN_training.jl:25-169, 207-249; free convection: train_free_convection_nde.jl:124-128, 186-216)
+# ----------------------------------------------------------------------------------------------
+def predict_single_flux(cfg, k, x, bcs, layers, want_tape=False, dtype=np.float64):
+    """Face vector of ONE flux net (k = 0 uw, 1 vw, 2 wT) for profiles x [n, n_state], as predict_uw/vw/wT build it: NN output on the
+    interior faces, boundary faces 0 (zero_weights) or the BCs, minus the Richardson-number diffusive flux (MPP; with zero_weights
+    the end faces carry -(BC - scaling(0))) or, for wT, the convective-adjustment flux.  T-only models: [bottom; NN(T); top]."""
+    m = Model(cfg, dtype)
+    Nz = cfg.Nz
+    x = np.asarray(x, dtype)
+    bcs = np.asarray(bcs, dtype)
+    o, tape = mlp_forward(layers, m.acts, x)
+    if cfg.smooth_NN:
+        o = o @ m.F_int.T
+    n = x.shape[0]
+    F = np.zeros((n, Nz + 1), dtype)
+    F[:, 1:Nz] = o
+    if cfg.model != WIND_MIXING:
+        F[:, 0], F[:, Nz] = bcs[:, 0], bcs[:, 1]
+        return (F, tape) if want_tape else F
+    sg, mu = cfg.sigma, cfg.mu
+    s0 = -mu[3 + k] / sg[3 + k]
+    if not cfg.zero_weights:
+        F[:, 0], F[:, Nz] = bcs[:, 2 * k], bcs[:, 2 * k + 1]
+    u, v, T = x[:, :Nz], x[:, Nz:2 * Nz], x[:, 2 * Nz:]
+    cs = sg[k] / sg[3 + k] / cfg.H
+    if cfg.modified_pacanowski_philander:
+        gu, gv, gT = _face_grad(u, Nz), _face_grad(v, Nz), _face_grad(T, Nz)
+        eps = cfg.eps
+        Ri = cfg.H * cfg.g * cfg.alpha * sg[2] * (gT + eps) / ((sg[0] * (gu + eps)) ** 2 + (sg[1] * (gv + eps)) ** 2)
+        if cfg.smooth_Ri:
+            Ri = Ri @ m.F_face.T
+        nu = cfg.nu0 + cfg.nu_minus * (1 - np.tanh((Ri - cfg.Ric) / cfg.dRi)) / 2
+        D = cs * (nu / cfg.Pr if k == 2 else nu) * (gu, gv, gT)[k]
+        if cfg.zero_weights:
+            D[:, 0] = -(bcs[:, 2 * k] - s0)
+            D[:, Nz] = -(bcs[:, 2 * k + 1] - s0)
+        F = F - D
+    elif cfg.convective_adjustment and k == 2:
+        F = F - cs * cfg.kappa * np.minimum(0.0, _face_grad(T, Nz))
+    return (F, tape) if want_tape else F
+
+
+def nn_pretrain_loss_and_grad(cfg, k, x, bcs, layers, flux, gradient_scaling):
+    """`NN_loss(input, output)` of train_NN (:218-229) for one sample batch of size 1..n (mean over the batch is NOT taken: one value
+    per sample) and its gradient w.r.t. the net's parameters, per sample: returns (loss [n], [per-sample packed gradients])."""
+    Nz = cfg.Nz
+    F, tape = predict_single_flux(cfg, k, x, bcs, layers, True)
+    y = np.asarray(flux, np.float64)
+    r = F - y
+    dg = ((F[:, 1:] - F[:, :-1]) - (y[:, 1:] - y[:, :-1])) * Nz
+    loss = (r ** 2).mean(axis=1) + gradient_scaling * (dg ** 2).mean(axis=1)
+    Fb = 2.0 / (Nz + 1) * r
+    Fb[:, 1:] += gradient_scaling * 2.0 / Nz * dg * Nz
+    Fb[:, :-1] -= gradient_scaling * 2.0 / Nz * dg * Nz
+    ob = Fb[:, 1:Nz]
+    if cfg.smooth_NN:
+        ob = ob @ Model(cfg).F_int
+    grads = []
+    acts = tuple(cfg.activations)
+    for i in range(x.shape[0]):
+        tp = [(a[i:i + 1], z[i:i + 1]) for a, z in tape]
+        _, g = mlp_vjp(layers, acts, tp, ob[i:i + 1])
+        grads.append(pack_grads([g]))
+    return loss, grads
+
+
+def train_NN(cfg, k, theta_net, profiles, bcs, fluxes, order, eta, epochs, gradient_scaling=1e-4, beta=(0.9, 0.999), eps=1e-8):
+    """One optimiser of train_NN (:238-246): `epochs` calls of `Flux.train!(NN_loss, Flux.params(NN), training_data, opt)` — one ADAM
+    update per sample in `order` — each followed by `total_loss(training_data)`.  Returns (theta, [total loss after each epoch])."""
+    th = np.array(theta_net, np.float64)
+    mm, vv, bt = np.zeros_like(th), np.zeros_like(th), (beta[0], beta[1])
+    hist = []
+    for _ in range(epochs):
+        for i in order:
+            layers = unpack(th, cfg.layer_sizes, 1)[0]
+            _, g = nn_pretrain_loss_and_grad(cfg, k, profiles[i:i + 1], bcs[i:i + 1], layers, fluxes[i:i + 1], gradient_scaling)
+            th, mm, vv, bt = adam_step(th, g[0], mm, vv, eta, beta, eps, bt)
+        layers = unpack(th, cfg.layer_sizes, 1)[0]
+        hist.append(float(nn_pretrain_loss_and_grad(cfg, k, profiles, bcs, layers, fluxes, gradient_scaling)[0].mean()))
+    return th, hist
