@@ -227,8 +227,8 @@ static void build_model(const colnde_config* c, DevModel* m, PackInfo* pk) {
         nb += no;
         pk->pf_off[l] = pf;
         pk->pb_off[l] = pb;
-        pf += ((no + 15) / 16) * ((ni + 3) / 4) * 64;
-        pb += ((ni + 15) / 16) * ((no + 3) / 4) * 64;
+        pf += ((no + 15) / 16) * ((ni + 15) / 16) * 256;      // [m-tile][group of 16 k][64 lanes][4]
+        pb += ((ni + 15) / 16) * ((no + 15) / 16) * 256;
     }
     pk->pf_off[c->n_layers] = pf;
     pk->pb_off[c->n_layers] = pb;
@@ -904,7 +904,8 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                                               h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                               h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
                                               lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, g,
-                                              (MODEL_FLOATS + lds_floats_adjoint(h->m)) * sizeof(float), h->stream, h->d_dwtape, h->d_t16_ztape);
+                                              (MODEL_FLOATS + (h->d_t16_ztape ? lds_floats_adjoint_noA(h->m) : lds_floats_adjoint(h->m))) * sizeof(float),
+                                              h->stream, h->d_dwtape, h->d_t16_ztape);
                 if (e != hipSuccess) return fail("adjoint (taped dW) launch failed: %s", hipGetErrorString(e));
             }
             {

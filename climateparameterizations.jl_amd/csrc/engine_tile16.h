@@ -24,6 +24,9 @@ static inline size_t lds_floats_adjoint(const DevModel& m) {
     return (size_t)3 * CT * m.ld_x + (size_t)2 * m.n_nets * CT * m.ld_a + (size_t)5 * CT * m.ld_f + CT * 8 + 16 * 8;
 }
 
+// taped mode with the hidden pre-activations taped: no activation array on chip
+static inline size_t lds_floats_adjoint_noA(const DevModel& m) { return lds_floats_adjoint(m) - (size_t)m.n_nets * CT * m.ld_a; }
+
 hipError_t set_kernel_attributes(size_t max_lds_bytes);
 hipError_t launch_pack(const DevModel& m, const PackInfo& pk, const float* w, float* wf, float* wb, hipStream_t stream);
 hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x,

@@ -71,11 +71,51 @@ __device__ __forceinline__ f32x4 gemm_chain(const float* ap, int a_step, const f
     return acc;
 }
 
+// The same chain with both operands fetched FOUR k-steps at a time: the packed weight image holds, per lane, the A operands of four
+// consecutive MFMAs contiguously (one 16-byte load from L2 instead of four dword loads, each of which cost a 64-bit address add), and
+// the K index is dealt so that the matching four B operands are four consecutive floats of the activation row (two 8-byte LDS
+// reads): k = 16 S + 4 q + j for group S, lane quarter q, MFMA j.  ~1.75 memory instructions per MFMA become ~0.75.
+//   ap4: this lane's float4 of group 0 (groups are 64 lanes x 16 bytes apart); bp: the activation row + 4 q; n = groups of 16 k
+template <int U>
+__device__ __forceinline__ f32x4 gemm_chain4(const float4* ap4, const float* bp, int n, f32x4 acc) {
+    int s = 0;
+    for (; s + U <= n; s += U) {
+        float4 a[U];
+        float2 b0[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            a[u] = ap4[(size_t)(s + u) * 64];
+            b0[u] = *reinterpret_cast<const float2*>(bp + (s + u) * 16);
+            b1[u] = *reinterpret_cast<const float2*>(bp + (s + u) * 16 + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            acc = mfma16(a[u].x, b0[u].x, acc);
+            acc = mfma16(a[u].y, b0[u].y, acc);
+            acc = mfma16(a[u].z, b1[u].x, acc);
+            acc = mfma16(a[u].w, b1[u].y, acc);
+        }
+    }
+    if (U > 1) return s < n ? gemm_chain4<(U > 1 ? U / 2 : 1)>(ap4 + (size_t)s * 64, bp + s * 16, n - s, acc) : acc;
+    for (; s < n; s++) {
+        const float4 a = ap4[(size_t)s * 64];
+        const float2 b0 = *reinterpret_cast<const float2*>(bp + s * 16), b1 = *reinterpret_cast<const float2*>(bp + s * 16 + 2);
+        acc = mfma16(a.x, b0.x, acc);
+        acc = mfma16(a.y, b0.y, acc);
+        acc = mfma16(a.z, b1.x, acc);
+        acc = mfma16(a.w, b1.y, acc);
+    }
+    return acc;
+}
+#ifndef GU4
+#define GU4 8     // groups (of four k-steps) in flight in the L2-streamed chains: the same 32 k-steps of prefetch as GU
+#endif
+
 // ------------------------------------------------------------------------------------------------
-// weight packing: raw Flux.destructure weights -> A-operand images (one float per lane per MFMA)
-//   forward image  Wf[net][l][mt][k4][lane]: A[i = mt*16 + (lane&15)][k = k4*4 + (lane>>4)] = W_l[i][k]
-//   backward image Wb[net][l][it][j4][lane]: A[i = it*16 + (lane&15)][j = j4*4 + (lane>>4)] = W_l[j][i]
-// W_l[j][k] (out j, in k) sits at w_off[l] + k*no + j  (column-major out x in).
+// weight packing: raw Flux.destructure weights -> A-operand images (four floats per lane per group of four MFMAs)
+//   forward image  Wf[net][l][mt][S][lane][j]: A[i = mt*16 + (lane&15)][k = 16 S + 4 (lane>>4) + j] = W_l[i][k]
+//   backward image Wb[net][l][it][S][lane][j]: A[i = it*16 + (lane&15)][o = 16 S + 4 (lane>>4) + j] = W_l[o][i]
+// (K padded with zeros to a multiple of 16.)  W_l[j][k] (out j, in k) sits at w_off[l] + k*no + j  (column-major out x in).
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, float* __restrict__ wf,
                                     float* __restrict__ wb) {
@@ -90,20 +130,20 @@ __global__ void pack_weights_kernel(DevModel m, PackInfo pk, const float* __rest
         while (l + 1 < m.n_layers && e >= (fwd ? pk.pf_off[l + 1] : pk.pb_off[l + 1])) l++;
         e -= fwd ? pk.pf_off[l] : pk.pb_off[l];
         const int ni = m.sizes[l], no = m.sizes[l + 1];
-        const int lane = e & 63;
-        const int blk = e >> 6;
+        const int jj = e & 3, lane = (e >> 2) & 63;
+        const int blk = e >> 8;
         const float* W = w + (size_t)net * m.net_size + m.w_off[l];
         float v = 0.0f;
         if (fwd) {
-            const int nk4 = (ni + 3) >> 2;
-            const int mt = blk / nk4, k4 = blk - mt * nk4;
-            const int i = mt * 16 + (lane & 15), k = k4 * 4 + (lane >> 4);
+            const int nS = (ni + 15) >> 4;
+            const int mt = blk / nS, S = blk - mt * nS;
+            const int i = mt * 16 + (lane & 15), k = 16 * S + 4 * (lane >> 4) + jj;
             if (i < no && k < ni) v = W[(size_t)k * no + i];
             wf[idx] = v;
         } else {
-            const int nj4 = (no + 3) >> 2;
-            const int it = blk / nj4, j4 = blk - it * nj4;
-            const int i = it * 16 + (lane & 15), j = j4 * 4 + (lane >> 4);
+            const int nS = (no + 15) >> 4;
+            const int it = blk / nS, S = blk - it * nS;
+            const int i = it * 16 + (lane & 15), j = 16 * S + 4 * (lane >> 4) + jj;
             if (i < ni && j < no) v = W[(size_t)i * no + j];
             wb[idx - total_f] = v;
         }
@@ -145,8 +185,9 @@ __device__ __forceinline__ void mlp_forward(const DevModel& m, const PackInfo& p
                 const float* ap = w + net * m.net_size + m.w_off[l] + kq * no + min(mt * 16 + (lane & 15), no - 1);
                 acc = gemm_chain<4>(ap, 4 * no, in + kq, 4, nk4, acc);
             } else {
-                const float* ap = wf + (size_t)net * pk.pf_net + pk.pf_off[l] + (size_t)mt * nk4 * 64 + lane;
-                acc = gemm_chain<GU>(ap, 64, in + kq, 4, nk4, acc);
+                const int nS = (ni + 15) >> 4;
+                const float4* ap4 = reinterpret_cast<const float4*>(wf + (size_t)net * pk.pf_net + pk.pf_off[l]) + (size_t)mt * nS * 64 + lane;
+                acc = gemm_chain4<GU4>(ap4, in + 4 * kq, nS, acc);
             }
             FINE(2);
             const int ro = (net * CT + c) * m.ld_a + m.act_off[l];
@@ -196,8 +237,9 @@ __device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& 
                     const float* ap = w + net * m.net_size + m.w_off[l] + min(it * 16 + (lane & 15), ni - 1) * no + jq;
                     acc = gemm_chain<4>(ap, 4, dz + jq, 4, nj4, acc);
                 } else {
-                    const float* ap = wb + (size_t)net * pk.pb_net + pk.pb_off[l] + (size_t)it * nj4 * 64 + lane;
-                    acc = gemm_chain<GU>(ap, 64, dz + jq, 4, nj4, acc);
+                    const int nS = (no + 15) >> 4;
+                    const float4* ap4 = reinterpret_cast<const float4*>(wb + (size_t)net * pk.pb_net + pk.pb_off[l]) + (size_t)it * nS * 64 + lane;
+                    acc = gemm_chain4<GU4>(ap4, dz + 4 * jq, nS, acc);
                 }
                 const int ro = (net * CT + c) * m.ld_a + m.act_off[l - 1];
 #pragma unroll
@@ -215,8 +257,9 @@ __device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& 
                         const float* ap = w + net * m.net_size + m.w_off[0] + min(it * 16 + (lane & 15), ni - 1) * no + jq;
                         acc = gemm_chain<4>(ap, 4, dz + jq, 4, nj4, acc);
                     } else {
-                        const float* ap = wb + (size_t)net * pk.pb_net + pk.pb_off[0] + (size_t)it * nj4 * 64 + lane;
-                        acc = gemm_chain<GU>(ap, 64, dz + jq, 4, nj4, acc);
+                        const int nS = (no + 15) >> 4;
+                        const float4* ap4 = reinterpret_cast<const float4*>(wb + (size_t)net * pk.pb_net + pk.pb_off[0]) + (size_t)it * nS * 64 + lane;
+                        acc = gemm_chain4<GU4>(ap4, dz + 4 * jq, nS, acc);
                     }
                 }
 #pragma unroll
@@ -700,7 +743,7 @@ __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const
 // forward solve: classical RK4, S sub-steps per save interval, state at save points -> sol,
 // stage inputs of every step -> tape (read back by the adjoint kernel)
 // ------------------------------------------------------------------------------------------------
-template <bool WLDS, int NTH>
+template <bool WLDS, int NTH, bool RKC = false>
 __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                                const float* __restrict__ x0, const float* __restrict__ bcs,
                                const float* __restrict__ save_times, int n_save, int substeps,
@@ -741,7 +784,7 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
     const int nst = m.nst;                               // RHS evaluations (taped stage inputs) per step: 4 (RK4) or s (RKC2)
     float* tp = tape ? tape + (size_t)blockIdx.x * n_steps * nst * n_items : nullptr;
     int step = 0;
-    if (m.rkc) {
+    if (RKC) {     // (a template parameter: the RK4 instantiation must not carry this branch's registers — 244 -> 262 VGPRs cost it a wave per SIMD)
         // ---- s-stage RKC2 steps (colnde_dev.h; coefficients from the host table): per owner item Y_0 = xn, Y_{j-1} = ym1,
         //      Y_{j-2} = ym2 and F_0 = f0 stay in registers; stage st evaluates F_st = f(Y_st), the step ends with Y_s
         const float* mu_t = m.rkc, *nu_t = m.rkc + RKC_LD, *mut_t = m.rkc + 2 * RKC_LD, *gat_t = m.rkc + 3 * RKC_LD, *c_t = m.rkc + 4 * RKC_LD;
@@ -904,8 +947,8 @@ __global__ void loss_kernel(DevModel m, const float* __restrict__ sol, const flo
 // TAPEDW: the weight gradients are not accumulated here.  Each stage's layer inputs and deltas are written to `dwtape` as
 // [tile][step][stage][CT columns][xs | A of every net | dZ of every net] and contracted by dw_gemm_kernel (networks whose
 // weight-gradient tiles would not fit the register file: 64-256-256-63 has 384 of them).
-template <int MAXT, int NTH, int MAXR, bool WLDS, bool TAPEDW = false>
-__global__ void __launch_bounds__(NTH)
+template <int MAXT, int NTH, int MAXR, bool WLDS, bool TAPEDW = false, bool RKC = false>
+__global__ void __launch_bounds__(NTH, (TAPEDW && NTH == 512) ? 4 : 1)   // taped mode, 512 threads: 128 registers, so that TWO workgroups share a CU and one's GEMMs cover the other's tape traffic
 adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                const float* __restrict__ wb, const TileDesc* __restrict__ tiles, const int* __restrict__ bias_zoff,
                const int* __restrict__ bias_goff, const float* __restrict__ bcs, const float* __restrict__ save_times,
@@ -924,8 +967,11 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
     float* dbar = xs + CT * m_arg.ld_x;
     float* xb = dbar + CT * m_arg.ld_x;
     float* Z = xb + CT * m_arg.ld_x;
+    // taped mode with the hidden pre-activations taped: the activations go from the Z tape straight into the delta tape and are never
+    // needed on chip — no A array, and two workgroups of a 64-level network fit in a CU's LDS
+    const bool noA = TAPEDW && ztape != nullptr;
     float* A = Z + m_arg.n_nets * CT * m_arg.ld_a;
-    float* gb = A + m_arg.n_nets * CT * m_arg.ld_a;
+    float* gb = noA ? A : A + m_arg.n_nets * CT * m_arg.ld_a;
     float* Ri_l = gb + 3 * CT * m_arg.ld_f;
     float* Rib_l = Ri_l + CT * m_arg.ld_f;
     float* bcl = Rib_l + CT * m_arg.ld_f;
@@ -981,7 +1027,7 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
 
     const int n_steps = (n_save - 1) * substeps;
     const int nst = m.nst;                               // taped stage inputs per step: 4 (RK4) or s (RKC2)
-    const bool rkc = m.rkc != nullptr;
+    constexpr bool rkc = RKC;            // a template parameter: the RK4 instantiations do not carry the RKC cotangent registers
     const float* mu_t = m.rkc, *nu_t = m.rkc + RKC_LD, *mut_t = m.rkc + 2 * RKC_LD, *gat_t = m.rkc + 3 * RKC_LD, *kap_t = m.rkc + 5 * RKC_LD;
     const float* tp = tape + (size_t)blockIdx.x * n_steps * nst * n_items;
     // the tape is read one stage ahead of its use (xpre) so that its HBM latency hides under the previous stage
@@ -1085,10 +1131,14 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                 __syncthreads();
                 STAMP(0);
                 if (TAPEDW && ztape) {
-                    // hidden-layer pre-activations taped by the forward kernel: Z and A = act(Z) without the forward GEMMs (the output
-                    // layer enters the pullback linearly: its values are not needed)
+                    // hidden-layer pre-activations taped by the forward kernel: Z into LDS, A = act(Z) straight into this stage's record of
+                    // the delta tape (the output layer enters the pullback linearly: its values are not needed; its A slot is never read
+                    // by the dW GEMM either)
                     const int hid = m.act_off[m.n_layers - 1], zld = (m.n_nets * hid + 3) & ~3;
                     const float* zr = ztape + ((size_t)blockIdx.x * n_steps * nst + (size_t)step * nst + st) * ((size_t)CT * zld);
+                    const int ns4r = (m.ns + 3) & ~3, act4r = (m.act_total + 3) & ~3;
+                    const int Rr = ns4r + 2 * m.n_nets * act4r;
+                    float* recA = dwtape + ((size_t)blockIdx.x * n_steps * nst + (size_t)step * nst + st) * ((size_t)CT * Rr) + ns4r;
                     // (segments start at multiples of 4 floats: one float4 never straddles two layers; up to four float4 per lane
                     //  are fetched back to back so that one HBM latency covers them)
                     const int nq = (m.n_nets * hid) >> 2;                      // float4 items per column
@@ -1107,9 +1157,9 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                                     while (o >= m.act_off[l + 1]) l++;
                                     const int a = m.acts[l];
                                     float* zd = Z + (net * CT + c) * m.ld_a + o;
-                                    float* ad = A + (net * CT + c) * m.ld_a + o;
                                     zd[0] = v[u].x; zd[1] = v[u].y; zd[2] = v[u].z; zd[3] = v[u].w;
-                                    ad[0] = dev_act(a, v[u].x); ad[1] = dev_act(a, v[u].y); ad[2] = dev_act(a, v[u].z); ad[3] = dev_act(a, v[u].w);
+                                    *reinterpret_cast<float4*>(recA + (size_t)c * Rr + net * act4r + o) =
+                                        make_float4(dev_act(a, v[u].x), dev_act(a, v[u].y), dev_act(a, v[u].z), dev_act(a, v[u].w));
                                 }
                             }
                         }
@@ -1135,7 +1185,7 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                         float* row = rec + (size_t)c * R;
                         for (int q = lane; q < hx; q += 64)
                             *reinterpret_cast<float2*>(row + 2 * q) = *reinterpret_cast<const float2*>(xs + c * m.ld_x + 2 * q);
-                        for (int seg = 0; seg < 2 * m.n_nets; seg++) {                              // A of every net, then dZ of every net
+                        for (int seg = noA ? m.n_nets : 0; seg < 2 * m.n_nets; seg++) {               // A of every net (unless already written), then dZ of every net
                             const int net = seg < m.n_nets ? seg : seg - m.n_nets;
                             const float* src = (seg < m.n_nets ? A : Z) + (net * CT + c) * m.ld_a;
                             float* dst = row + ns4 + seg * act4;
@@ -1460,9 +1510,18 @@ __global__ void __launch_bounds__(256) infer_kernel(DevModel m, PackInfo pk, con
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (declared in engine_tile16.h)
 // ------------------------------------------------------------------------------------------------
-#define LAUNCH_ADJ(MT, NT, MR, WL)                                                                             \
-    hipLaunchKernelGGL((adjoint_kernel<MT, NT, MR, WL>), dim3(n_tiles), dim3(NT), lds_bytes, stream, m, pk, w, wf, wb, \
-                       tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col)
+#define LAUNCH_ADJ_K(MT, NT, MR, WL, TD, ...)                                                                                   \
+    do {                                                                                                                        \
+        if (m.rkc)                                                                                                              \
+            hipLaunchKernelGGL((adjoint_kernel<MT, NT, MR, WL, TD, true>), dim3(n_tiles), dim3(NT), lds_bytes, stream, m, pk, w, wf, \
+                               wb, tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab,  \
+                               n_col, __VA_ARGS__);                                                                             \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((adjoint_kernel<MT, NT, MR, WL, TD, false>), dim3(n_tiles), dim3(NT), lds_bytes, stream, m, pk, w, wf, \
+                               wb, tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab,  \
+                               n_col, __VA_ARGS__);                                                                             \
+    } while (0)
+#define LAUNCH_ADJ(MT, NT, MR, WL) LAUNCH_ADJ_K(MT, NT, MR, WL, false, (float*)nullptr, (const float*)nullptr)
 
 // (threads, dW tiles per wave, state items per thread, weights in LDS) instantiations; the host picks the first that fits
 static const AdjointGeom kGeoms[] = {{512, 16, 3, 1}, {256, 32, 6, 1}, {256, 32, 6, 0}, {256, 32, 12, 0},
@@ -1504,9 +1563,15 @@ hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w,
                           const float* bcs, const float* save_times, int n_save, int substeps, float* sol, float* tape,
                           int n_col, int nthreads, bool wlds, size_t lds_bytes, hipStream_t stream, float* ztape) {
     const dim3 grid((n_col + CT - 1) / CT);
-#define LAUNCH_FWD(WL, NT)                                                                                           \
-    hipLaunchKernelGGL((forward_kernel<WL, NT>), grid, dim3(NT), lds_bytes, stream, m, pk, w, wf, x0, bcs, save_times, \
-                       n_save, substeps, sol, tape, n_col, ztape)
+#define LAUNCH_FWD(WL, NT)                                                                                                  \
+    do {                                                                                                                    \
+        if (m.rkc)                                                                                                          \
+            hipLaunchKernelGGL((forward_kernel<WL, NT, true>), grid, dim3(NT), lds_bytes, stream, m, pk, w, wf, x0, bcs,    \
+                               save_times, n_save, substeps, sol, tape, n_col, ztape);                                      \
+        else                                                                                                                \
+            hipLaunchKernelGGL((forward_kernel<WL, NT, false>), grid, dim3(NT), lds_bytes, stream, m, pk, w, wf, x0, bcs,   \
+                               save_times, n_save, substeps, sol, tape, n_col, ztape);                                      \
+    } while (0)
     if (wlds && nthreads == 512) LAUNCH_FWD(true, 512);
     else if (wlds && nthreads == 256) LAUNCH_FWD(true, 256);
     else if (!wlds && nthreads == 512) LAUNCH_FWD(false, 512);
@@ -1530,19 +1595,17 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
                           size_t lds_bytes, hipStream_t stream, float* dwtape, const float* ztape) {
     const int n_tiles = (n_col + CT - 1) / CT;
     if (dwtape) {
-        // 1,024 threads (four waves per SIMD, 101 VGPRs) hide the L2 latency of the streamed weights better than 512:
-        // 328 vs 377 ms on 64-256-256-63 (COLNDE_T16_TAPE_THREADS=512 selects the smaller workgroup)
+        // Two 512-thread workgroups per CU (128 registers each) when two fit in the LDS: one's GEMMs then cover the other's tape
+        // traffic, activations and physics (32-128-128-31: adjoint 84.6 -> 61.6 ms); one 1,024-thread workgroup (four waves per SIMD)
+        // otherwise.  COLNDE_T16_TAPE_THREADS=512|1024 forces either.
         const char* et = getenv("COLNDE_T16_TAPE_THREADS");
-        const int nth_env = et ? atoi(et) : 1024;
+        const int nth_env = et ? atoi(et) : ((n_tiles > 256 && 2 * lds_bytes + 2048 <= 160 * 1024) ? 512 : 1024);   // (fewer tiles than CUs: a latency point, the wider workgroup finishes sooner)
         if (nth_env == 1024 && CT * m.ns <= 2 * 1024)
-            hipLaunchKernelGGL((adjoint_kernel<1, 1024, 2, false, true>), dim3(n_tiles), dim3(1024), lds_bytes, stream, m, pk, w, wf, wb,
-                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape, ztape);
+            LAUNCH_ADJ_K(1, 1024, 2, false, true, dwtape, ztape);
         else if (CT * m.ns <= 3 * 512)
-            hipLaunchKernelGGL((adjoint_kernel<1, 512, 3, false, true>), dim3(n_tiles), dim3(512), lds_bytes, stream, m, pk, w, wf, wb,
-                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape, ztape);
+            LAUNCH_ADJ_K(1, 512, 3, false, true, dwtape, ztape);
         else if (CT * m.ns <= 6 * 512)
-            hipLaunchKernelGGL((adjoint_kernel<1, 512, 6, false, true>), dim3(n_tiles), dim3(512), lds_bytes, stream, m, pk, w, wf, wb,
-                               tiles, bias_zoff, bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape, ztape);
+            LAUNCH_ADJ_K(1, 512, 6, false, true, dwtape, ztape);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
@@ -1604,6 +1667,22 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     SETATTR((adjoint_kernel<1, 512, 3, false, true>));
     SETATTR((adjoint_kernel<1, 512, 6, false, true>));
     SETATTR((adjoint_kernel<1, 1024, 2, false, true>));
+    // the RKC2 instantiations
+    SETATTR((forward_kernel<true, 512, true>));
+    SETATTR((forward_kernel<true, 256, true>));
+    SETATTR((forward_kernel<false, 512, true>));
+    SETATTR((forward_kernel<false, 256, true>));
+    SETATTR((forward_kernel<true, 1024, true>));
+    SETATTR((forward_kernel<false, 1024, true>));
+    SETATTR((adjoint_kernel<16, 512, 3, true, false, true>));
+    SETATTR((adjoint_kernel<32, 256, 6, true, false, true>));
+    SETATTR((adjoint_kernel<32, 256, 6, false, false, true>));
+    SETATTR((adjoint_kernel<32, 256, 12, false, false, true>));
+    SETATTR((adjoint_kernel<32, 512, 6, false, false, true>));
+    SETATTR((adjoint_kernel<48, 512, 3, false, false, true>));
+    SETATTR((adjoint_kernel<1, 512, 3, false, true, true>));
+    SETATTR((adjoint_kernel<1, 512, 6, false, true, true>));
+    SETATTR((adjoint_kernel<1, 1024, 2, false, true, true>));
     SETATTR((dw_gemm_lds_kernel<DW_MAXM, DW_NW>));
 #undef SETATTR
     return hipSuccess;
