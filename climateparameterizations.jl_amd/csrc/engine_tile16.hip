@@ -1156,6 +1156,15 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                                     int l = 0;
                                     while (o >= m.act_off[l + 1]) l++;
                                     const int a = m.acts[l];
+                                    // the pad slots behind a layer's last feature were never written by the forward kernel: they must read as
+                                    // zero (a backward chain multiplies them with whatever weight sits behind the row's end)
+                                    const int nvalid = m.sizes[l + 1] - (o - m.act_off[l]);
+                                    if (nvalid < 4) {
+                                        if (nvalid < 1) v[u].x = 0.0f;
+                                        if (nvalid < 2) v[u].y = 0.0f;
+                                        if (nvalid < 3) v[u].z = 0.0f;
+                                        v[u].w = 0.0f;
+                                    }
                                     float* zd = Z + (net * CT + c) * m.ld_a + o;
                                     zd[0] = v[u].x; zd[1] = v[u].y; zd[2] = v[u].z; zd[3] = v[u].w;
                                     *reinterpret_cast<float4*>(recA + (size_t)c * Rr + net * act4r + o) =
@@ -1600,7 +1609,17 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
         // otherwise.  COLNDE_T16_TAPE_THREADS=512|1024 forces either.
         const char* et = getenv("COLNDE_T16_TAPE_THREADS");
         const int nth_env = et ? atoi(et) : ((n_tiles > 256 && 2 * lds_bytes + 2048 <= 160 * 1024) ? 512 : 1024);   // (fewer tiles than CUs: a latency point, the wider workgroup finishes sooner)
-        if (nth_env == 1024 && CT * m.ns <= 2 * 1024)
+        // latency points (fewer tiles than CUs) with a network that fits beside the tile's arrays: the raw weights staged in LDS, read in
+        // place for W^T — no L2 round trip at the head of every backward chain (8 simulations: adjoint stage 30 k -> cycles)
+        const size_t wl_bytes = ((size_t)((m.n_params + 3) & ~3) + 128) * sizeof(float);
+        const char* ew = getenv("COLNDE_T16_TAPE_WLDS");
+        const bool wlds_ok = nth_env == 1024 && CT * m.ns <= 2 * 1024 && lds_bytes + wl_bytes <= 160 * 1024;
+        if (wlds_ok && (ew ? atoi(ew) != 0 : n_tiles <= 256)) {
+            const size_t lds_save = lds_bytes;
+            lds_bytes += wl_bytes;
+            LAUNCH_ADJ_K(1, 1024, 2, true, true, dwtape, ztape);
+            lds_bytes = lds_save;
+        } else if (nth_env == 1024 && CT * m.ns <= 2 * 1024)
             LAUNCH_ADJ_K(1, 1024, 2, false, true, dwtape, ztape);
         else if (CT * m.ns <= 3 * 512)
             LAUNCH_ADJ_K(1, 512, 3, false, true, dwtape, ztape);
@@ -1683,6 +1702,8 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     SETATTR((adjoint_kernel<1, 512, 3, false, true, true>));
     SETATTR((adjoint_kernel<1, 512, 6, false, true, true>));
     SETATTR((adjoint_kernel<1, 1024, 2, false, true, true>));
+    SETATTR((adjoint_kernel<1, 1024, 2, true, true, false>));
+    SETATTR((adjoint_kernel<1, 1024, 2, true, true, true>));
     SETATTR((dw_gemm_lds_kernel<DW_MAXM, DW_NW>));
 #undef SETATTR
     return hipSuccess;
