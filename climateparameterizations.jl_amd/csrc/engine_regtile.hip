@@ -35,6 +35,7 @@ __device__ unsigned long long g_rt_stamps[16];
 #define RT_STAMP_FLUSH()
 #endif
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 #define RHO0(r) (((r) & 3) + 8 * ((r) >> 2))
 // (Tried and removed, see DESIGN.md §6: "parking" cotangents in an L2-resident scratch buffer to free registers — slower and
@@ -458,6 +459,96 @@ __device__ __forceinline__ void rt_act_pair(float z, float& a, float& d) {
     }
 }
 
+// Two activation value/derivative pairs at once on packed f32 arithmetic (v_pk_mul / v_pk_add / v_pk_fma: two lanes' worth of the same
+// instruction per issue slot).  With one wave per SIMD every vector instruction of these phases is exposed, and scalar v_fma runs the
+// vector unit at half its rate: 13 packed + 6 scalar (clamp, exp, rcp) instructions for two pairs instead of 34.
+template <int ACT>
+__device__ __forceinline__ void rt_act_pair2(f32x2v z, f32x2v& a, f32x2v& d) {
+    if (ACT == COLNDE_ACT_MISH) {
+        f32x2v zc;
+        zc.x = __builtin_amdgcn_fmed3f(z.x, -3.0e38f, 20.0f);
+        zc.y = __builtin_amdgcn_fmed3f(z.y, -3.0e38f, 20.0f);
+        const f32x2v t = zc * 1.4426950408889634f;
+        f32x2v e;
+        e.x = __builtin_amdgcn_exp2f(t.x);
+        e.y = __builtin_amdgcn_exp2f(t.y);
+        const f32x2v n = e * (e + 2.0f);
+        const f32x2v q = n + 2.0f;
+        f32x2v r;
+        r.x = __builtin_amdgcn_rcpf(q.x);
+        r.y = __builtin_amdgcn_rcpf(q.y);
+        const f32x2v p = z * 4.0f + 4.0f;
+        const f32x2v w = e * ((e * 2.0f + q) + p) + p;
+        a = z * (n * r);
+        d = (e * r) * (w * r);
+    } else {
+        float a0, d0, a1, d1;
+        rt_act_pair<ACT>(z.x, a0, d0);
+        rt_act_pair<ACT>(z.y, a1, d1);
+        a.x = a0; a.y = a1; d.x = d0; d.y = d1;
+    }
+}
+
+// activation VALUE only (forward kernels), four elements on packed arithmetic
+template <int ACT>
+__device__ __forceinline__ f32x4v rt_act4(f32x4v z) {
+    if (ACT == COLNDE_ACT_MISH) {
+        f32x2v z0 = {z[0], z[1]}, z1 = {z[2], z[3]}, c0, c1, e0, e1, r0, r1;
+        c0.x = __builtin_amdgcn_fmed3f(z0.x, -3.0e38f, 20.0f); c0.y = __builtin_amdgcn_fmed3f(z0.y, -3.0e38f, 20.0f);
+        c1.x = __builtin_amdgcn_fmed3f(z1.x, -3.0e38f, 20.0f); c1.y = __builtin_amdgcn_fmed3f(z1.y, -3.0e38f, 20.0f);
+        const f32x2v t0 = c0 * 1.4426950408889634f, t1 = c1 * 1.4426950408889634f;
+        e0.x = __builtin_amdgcn_exp2f(t0.x); e0.y = __builtin_amdgcn_exp2f(t0.y);
+        e1.x = __builtin_amdgcn_exp2f(t1.x); e1.y = __builtin_amdgcn_exp2f(t1.y);
+        const f32x2v n0 = e0 * (e0 + 2.0f), n1 = e1 * (e1 + 2.0f);
+        const f32x2v q0 = n0 + 2.0f, q1 = n1 + 2.0f;
+        r0.x = __builtin_amdgcn_rcpf(q0.x); r0.y = __builtin_amdgcn_rcpf(q0.y);
+        r1.x = __builtin_amdgcn_rcpf(q1.x); r1.y = __builtin_amdgcn_rcpf(q1.y);
+        const f32x2v a0 = z0 * (n0 * r0), a1 = z1 * (n1 * r1);
+        return (f32x4v){a0.x, a0.y, a1.x, a1.y};
+    }
+    return (f32x4v){rt_act<ACT>(z[0]), rt_act<ACT>(z[1]), rt_act<ACT>(z[2]), rt_act<ACT>(z[3])};
+}
+
+// four at once: two packed flows side by side, so that the results of the transcendental unit are not consumed by the very next instruction
+template <int ACT>
+__device__ __forceinline__ void rt_act_pair4(f32x2v z0, f32x2v z1, f32x2v& a0, f32x2v& d0, f32x2v& a1, f32x2v& d1) {
+    if (ACT == COLNDE_ACT_MISH) {
+        f32x2v c0, c1, e0, e1, r0, r1;
+        c0.x = __builtin_amdgcn_fmed3f(z0.x, -3.0e38f, 20.0f); c0.y = __builtin_amdgcn_fmed3f(z0.y, -3.0e38f, 20.0f);
+        c1.x = __builtin_amdgcn_fmed3f(z1.x, -3.0e38f, 20.0f); c1.y = __builtin_amdgcn_fmed3f(z1.y, -3.0e38f, 20.0f);
+        const f32x2v t0 = c0 * 1.4426950408889634f, t1 = c1 * 1.4426950408889634f;
+        e0.x = __builtin_amdgcn_exp2f(t0.x); e0.y = __builtin_amdgcn_exp2f(t0.y);
+        e1.x = __builtin_amdgcn_exp2f(t1.x); e1.y = __builtin_amdgcn_exp2f(t1.y);
+        const f32x2v p0 = z0 * 4.0f + 4.0f, p1 = z1 * 4.0f + 4.0f;
+        const f32x2v n0 = e0 * (e0 + 2.0f), n1 = e1 * (e1 + 2.0f);
+        const f32x2v q0 = n0 + 2.0f, q1 = n1 + 2.0f;
+        r0.x = __builtin_amdgcn_rcpf(q0.x); r0.y = __builtin_amdgcn_rcpf(q0.y);
+        r1.x = __builtin_amdgcn_rcpf(q1.x); r1.y = __builtin_amdgcn_rcpf(q1.y);
+        const f32x2v w0 = e0 * ((e0 * 2.0f + q0) + p0) + p0, w1 = e1 * ((e1 * 2.0f + q1) + p1) + p1;
+        a0 = z0 * (n0 * r0); a1 = z1 * (n1 * r1);
+        d0 = (e0 * r0) * (w0 * r0); d1 = (e1 * r1) * (w1 * r1);
+    } else {
+        rt_act_pair2<ACT>(z0, a0, d0);
+        rt_act_pair2<ACT>(z1, a1, d1);
+    }
+}
+template <int ACT>
+__device__ __forceinline__ void rt_act_pair4_at(f32x16 (&A)[2], f32x16 (&D)[2], int G) {     // registers G .. G+3 (G % 4 == 0)
+    f32x2v z0 = {A[G >> 4][G & 15], A[G >> 4][(G & 15) + 1]}, z1 = {A[G >> 4][(G & 15) + 2], A[G >> 4][(G & 15) + 3]}, a0, d0, a1, d1;
+    rt_act_pair4<ACT>(z0, z1, a0, d0, a1, d1);
+    A[G >> 4][G & 15] = a0.x; A[G >> 4][(G & 15) + 1] = a0.y; A[G >> 4][(G & 15) + 2] = a1.x; A[G >> 4][(G & 15) + 3] = a1.y;
+    D[G >> 4][G & 15] = d0.x; D[G >> 4][(G & 15) + 1] = d0.y; D[G >> 4][(G & 15) + 2] = d1.x; D[G >> 4][(G & 15) + 3] = d1.y;
+}
+
+// registers G', G'+1 (G' even: the same tile, adjacent registers) of a two-tile layer-1 block
+template <int ACT>
+__device__ __forceinline__ void rt_act_pair2_at(f32x16 (&A)[2], f32x16 (&D)[2], int G) {
+    f32x2v z = {A[G >> 4][G & 15], A[G >> 4][(G & 15) + 1]}, av, dv;
+    rt_act_pair2<ACT>(z, av, dv);
+    A[G >> 4][G & 15] = av.x; A[G >> 4][(G & 15) + 1] = av.y;
+    D[G >> 4][G & 15] = dv.x; D[G >> 4][(G & 15) + 1] = dv.y;
+}
+
 // in place on register G' of a two-tile layer-1 block: A <- act(A), D <- act'(A)
 template <int ACT>
 __device__ __forceinline__ void rt_act_pair_at(f32x16 (&A)[2], f32x16 (&D)[2], int G) {
@@ -723,7 +814,8 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         if (n == 0) {
                             load_z1(step, st, 0, A1);
 #pragma unroll
-                            for (int G = 0; G < 25; G++) rt_act_pair_at<ACT>(A1, D1, G);
+                            for (int G = 0; G < 24; G += 4) rt_act_pair4_at<ACT>(A1, D1, G);
+                            rt_act_pair_at<ACT>(A1, D1, 24);
                         }
                     } else {
 #pragma unroll
@@ -761,11 +853,12 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         b3acc[n] += rt_sum16(TA);
                         f32x16 A2;
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            float av = 0.0f, dv = 0.0f;
-                            if (r < 10) rt_act_pair<ACT>(Z2[r], av, dv);
-                            A2[r] = av;
-                            Z2[r] = dv;                                             // Z2 now holds act'(z2)
+                        for (int r = 0; r < 16; r += 4) {
+                            f32x2v a0 = {0.0f, 0.0f}, d0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f}, d1 = {0.0f, 0.0f};
+                            if (r < 8) rt_act_pair4<ACT>((f32x2v){Z2[r], Z2[r + 1]}, (f32x2v){Z2[r + 2], Z2[r + 3]}, a0, d0, a1, d1);
+                            else if (r == 8) rt_act_pair2<ACT>((f32x2v){Z2[8], Z2[9]}, a0, d0);
+                            A2[r] = a0.x; A2[r + 1] = a0.y; A2[r + 2] = a1.x; A2[r + 3] = a1.y;
+                            Z2[r] = d0.x; Z2[r + 1] = d0.y; Z2[r + 2] = d1.x; Z2[r + 3] = d1.y;     // Z2 now holds act'(z2)
                         }
                         const f32x16 TB = rt_transpose(tb, A2, wbase, rbase);
                         gW3[n] = rt_outer(gW3[n], TA, TB);
@@ -817,9 +910,10 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                                                          // net n + 1's 25 activation pairs, spread over the 15 chunks
                                                          if (ZT && n < 2 && (q > 0 || c > 0)) {
 #pragma unroll
-                                                             for (int G = 0; G < 25; G++)
-                                                                 if ((G * 14) / 25 + 1 == q * 5 + c)
-                                                                     rt_act_pair_at<ACT>(A1n, D1n, G);
+                                                             for (int G = 0; G < 24; G += 4)
+                                                                 if ((G >> 2) * 2 + 2 == q * 5 + c)
+                                                                     rt_act_pair4_at<ACT>(A1n, D1n, G);
+                                                             if (q * 5 + c == 14) rt_act_pair_at<ACT>(A1n, D1n, 24);
                                                          }
                                                      });
                     }
@@ -1156,8 +1250,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                             if (Q < 39 && (qq < 12 || g < 2)) oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = acc[r];
                         }
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) A1[t][r] = rt_act<ACT>(acc[r]);
+                    A1[t] = rt_act4<ACT>(acc);
                 }
                 RT_STAMP(1);
                 V16 O[3];
@@ -1172,8 +1265,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                         const int base = a2b[u] + n * 20 * RT_LD2, basel = a2l[u] + n * 20 * RT_LD2;
                         acc = rt16_chain<13, 13>(wl, acc, [=](int k) { return k < 12 ? base + 4 * k : basel; },
                                                  [&](int k) { return A1[(13 * n + k) >> 2][(13 * n + k) & 3]; });
-#pragma unroll
-                        for (int r = 0; r < 4; r++) A2[u][r] = rt_act<ACT>(acc[r]);
+                        A2[u] = rt_act4<ACT>(acc);
                     }
 #pragma unroll
                     for (int v = 0; v < 2; v++) {
