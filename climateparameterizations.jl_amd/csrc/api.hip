@@ -349,9 +349,12 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     h->lds_adj = h->geo_ok ? lds_floats_adjoint_geom(h->m, h->geo) * sizeof(float) : lds_floats_adjoint(h->m) * sizeof(float);
     {
         const size_t wl = ((size_t)((h->m.n_params + 3) & ~3) + 128) * sizeof(float);
-        h->fwd_wlds = h->lds_fwd + wl <= lds_cap;
+        // Weights staged in LDS when they fit — unless that leaves room for only ONE workgroup per CU on a problem with more tiles than
+        // CUs: there two 256-thread workgroups streaming the packed image from L2 (four k-steps per load) are faster
+        // (32-128-128-31, 16,384 columns: forward 55.8 -> 42.9 ms); latency points keep the LDS copy (no L2 round trip per chain).
+        h->fwd_wlds = h->lds_fwd + wl <= lds_cap && (h->n_tiles <= 256 || 2 * (h->lds_fwd + wl) <= lds_cap);
         const char* ew = getenv("COLNDE_FWD_WLDS");
-        if (ew) h->fwd_wlds = h->fwd_wlds && atoi(ew) != 0;
+        if (ew) h->fwd_wlds = h->lds_fwd + wl <= lds_cap && atoi(ew) != 0;
         // weights in LDS: 1,024 threads (four waves per SIMD; 8 simulations 19.7 vs 21.3 ms at 512, 32-128-128-31 54.7 vs 55.7 ms);
         // weights streamed from L2 (64-256-256-63): two independent 256-thread workgroups per CU do better (113 vs 121 ms)
         h->fwd_threads = h->fwd_wlds ? 1024 : 256;
