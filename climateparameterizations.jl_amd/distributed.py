@@ -84,10 +84,10 @@ class Comm:
             pass
 
 
-def bootstrap_comm(rank: int, world: int, device: int, key: str = "colnde_uid") -> Comm:
-    """Rank 0 makes the RCCL unique id and publishes it through the launcher's TCP store (MASTER_ADDR / MASTER_PORT, as
-    torch.distributed's env:// rendezvous uses it: every rank a client when torchrun hosts the store, rank 0 the server
-    otherwise); every rank then joins.  Host-side bytes only — no process group, no collective through torch."""
+def exchange_unique_id(rank: int, world: int, make_id, key: str = "colnde_uid") -> bytes:
+    """Host-side bootstrap: rank 0 calls `make_id()` and publishes the bytes through the launcher's TCP store (MASTER_ADDR /
+    MASTER_PORT, as torch.distributed's env:// rendezvous uses it: every rank a client when torchrun hosts the store, rank 0 the server
+    otherwise); every rank returns the same bytes.  No process group, no collective, no GPU."""
     from datetime import timedelta
     from torch.distributed import TCPStore
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
@@ -95,6 +95,18 @@ def bootstrap_comm(rank: int, world: int, device: int, key: str = "colnde_uid") 
     agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
     store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300), multi_tenant=True)
     if rank == 0:
-        store.set(key, Comm.unique_id())
+        store.set(key, make_id())
     uid = bytes(store.get(key))
-    return Comm(rank, world, uid, device)
+    # keep the store alive until every rank has read the id (rank 0 may host it)
+    store.add(key + "/read", 1)
+    if rank == 0:
+        import time
+        t0 = time.time()
+        while int(store.add(key + "/read", 0)) < world and time.time() - t0 < 300:
+            time.sleep(0.01)
+    return uid
+
+
+def bootstrap_comm(rank: int, world: int, device: int, key: str = "colnde_uid") -> Comm:
+    """Rank 0 makes the RCCL unique id, `exchange_unique_id` hands it to every rank, every rank joins."""
+    return Comm(rank, world, exchange_unique_id(rank, world, Comm.unique_id, key), device)
