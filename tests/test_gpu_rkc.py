@@ -13,12 +13,14 @@ from tests.test_gpu_parity import _record, _rel, SOL_ATOL, LOSS_RTOL, GRAD_REL, 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["taped", "inregister"])
+@pytest.mark.parametrize("mode", ["taped", "inregister", "blocked"])
 def test_wind_mixing_kappa10_conv_adj_branch(mode, monkeypatch):
     """kappa = 10 (the reference default, NDE_training.jl:141-143) makes the convective-adjustment branch stiff: lambda h = 375 per
     10-minute frame, 135 RK4 sub-steps (540 RHS evaluations) — or one 26-stage RKC2 step."""
     if mode == "inregister":
         monkeypatch.setenv("COLNDE_T16_DWTAPE", "0")
+    if mode == "blocked":                                   # tapes sized for one 16-column block: 21 columns run as two passes of s stages
+        monkeypatch.setenv("COLNDE_T16_BLOCK", "16")
     p = synthetic.wind_mixing_problem(21, n_frames=9, weight_divisor=1e2, modified_pacanowski_philander=False, zero_weights=False,
                                       convective_adjustment=True, kappa=10.0, stepper="rkc2", substeps=1)
     cfg = p.cfg
@@ -126,6 +128,24 @@ def test_conv_adj_nde_rkc2_tight_parity_on_a_stratified_profile():
     assert np.abs(sol_g - sol).max() < 4 * e32[0] + RKC_CA32[0]
     assert abs(tot_g - tot) / tot < 4 * e32[1] + RKC_CA32[1]
     assert _rel(grad_g, g) < 4 * e32[2] + RKC_CA32[2]
+
+
+def test_diurnal_forcing_sees_the_rkc_stage_times():
+    """Time-dependent top flux (NDE_training.jl:68-81): stage j of an RKC2 step is evaluated at t + c_j h; 12 explicit stages per step."""
+    p = synthetic.wind_mixing_problem(19, n_frames=9, weight_divisor=1e2, diurnal=True, stepper="rkc2", substeps=1, rkc_stages=12)
+    cfg = p.cfg
+    truth = O.solve(cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(cfg)
+    tot, terms, g, sol = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+    _record("rkc2/diurnal", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g))
+    assert np.abs(sol_g - sol).max() < SOL_ATOL and np.isclose(tot_g, tot, rtol=LOSS_RTOL) and _rel(grad_g, g) < GRAD_REL     # measured 1.3e-6, 1.9e-7, 2.8e-6
+    # the stage times matter: with the flux frozen at the step's start the trajectory differs visibly
+    frozen = O.solve(cfg.with_(diurnal=False), p.x0, np.concatenate([p.bcs[:, :5], O.Model(cfg).wm_top_flux(p.bcs.astype(np.float64), 0.0)[:, None]], axis=1), p.weights)
+    assert np.abs(frozen - sol).max() > 100 * SOL_ATOL
 
 
 def test_explicit_stage_count_below_the_bound_is_refused():
