@@ -1285,6 +1285,43 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                     if (m.mpp || m.ca) {
                         Ud = shift_down16(Xs[0], lane, 0.0f); Vd = shift_down16(Xs[1], lane, 0.0f); Td = shift_down16(Xs[2], lane, 0.0f);
                     }
+                    if (m.mpp) {
+                        // the Richardson-number closure on pairs of adjacent levels (packed f32 arithmetic: two levels per issue slot);
+                        // uniform factors folded (see rt_physics_vjp): d = level difference, a = σ (Nz d + ε), Ri = B (Nz d_T + ε) / S2,
+                        // tanh via exp2, ν = nB + nA tanh, diffusive flux = -(c Nz) ν d
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                            for (int r = 0; r < 4; r += 2) {
+                                const f32x2v dU = {Xs[0].t[tau][r] - Ud.t[tau][r], Xs[0].t[tau][r + 1] - Ud.t[tau][r + 1]};
+                                const f32x2v dV = {Xs[1].t[tau][r] - Vd.t[tau][r], Xs[1].t[tau][r + 1] - Vd.t[tau][r + 1]};
+                                const f32x2v dT = {Xs[2].t[tau][r] - Td.t[tau][r], Xs[2].t[tau][r + 1] - Td.t[tau][r + 1]};
+                                const f32x2v a1 = dU * pc.cU + pc.sU, a2 = dV * pc.cV + pc.sV;
+                                const f32x2v s2 = a2 * a2 + a1 * a1;
+                                f32x2v rS;
+                                rS.x = __builtin_amdgcn_rcpf(s2.x);
+                                rS.y = __builtin_amdgcn_rcpf(s2.y);
+                                const f32x2v arg = ((dT * pc.cB + pc.sB) * rS) * pc.kE + pc.oE;
+                                f32x2v e;
+                                e.x = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(arg.x, -pc.cE, pc.cE));
+                                e.y = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(arg.y, -pc.cE, pc.cE));
+                                const f32x2v e1 = e + 1.0f;
+                                f32x2v rc;
+                                rc.x = __builtin_amdgcn_rcpf(e1.x);
+                                rc.y = __builtin_amdgcn_rcpf(e1.y);
+                                const f32x2v nu = (rc * -2.0f + 1.0f) * pc.nA + pc.nB;
+                                const f32x2v o0 = {O[0].t[tau][r], O[0].t[tau][r + 1]}, o1 = {O[1].t[tau][r], O[1].t[tau][r + 1]},
+                                             o2 = {O[2].t[tau][r], O[2].t[tau][r + 1]};
+                                const f32x2v f0 = (nu * dU) * pc.f0 + o0, f1 = (nu * dV) * pc.f1 + o1, f2 = (nu * dT) * pc.f2 + o2;
+                                F[0].t[tau][r] = f0.x; F[0].t[tau][r + 1] = f0.y;
+                                F[1].t[tau][r] = f1.x; F[1].t[tau][r + 1] = f1.y;
+                                F[2].t[tau][r] = f2.x; F[2].t[tau][r + 1] = f2.y;
+                            }
+                        if (g == 0) {                                              // face 0: the bottom boundary
+#pragma unroll
+                            for (int k = 0; k < 3; k++) F[k].t[0][0] = m.zero_w ? bc.b[k] - m.s0[k] : bc.b[k];
+                        }
+                    } else
 #pragma unroll
                     for (int tau = 0; tau < 2; tau++)
 #pragma unroll
@@ -1292,23 +1329,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                             const bool in = !(tau == 0 && r == 0 && g == 0);       // face >= 1
                             float f0 = in ? O[0].t[tau][r] : 0.0f, f1 = in ? O[1].t[tau][r] : 0.0f, f2 = in ? O[2].t[tau][r] : 0.0f;
                             if (!m.zero_w && !in) { f0 = bc.b[0]; f1 = bc.b[1]; f2 = bc.b[2]; }
-                            if (m.mpp) {
-                                if (in) {
-                                    // uniform factors folded (see rt_physics_vjp): d = level difference, a = σ (Nz d + ε), Ri = B (Nz d_T + ε) / S2,
-                                    // tanh via exp2, ν = nB + nA tanh, diffusive flux = -(c Nz) ν d
-                                    const float dU = Xs[0].t[tau][r] - Ud.t[tau][r], dV = Xs[1].t[tau][r] - Vd.t[tau][r], dT = Xs[2].t[tau][r] - Td.t[tau][r];
-                                    const float a1 = fmaf(dU, pc.cU, pc.sU), a2 = fmaf(dV, pc.cV, pc.sV);
-                                    const float Ri = fmaf(dT, pc.cB, pc.sB) * __builtin_amdgcn_rcpf(fmaf(a2, a2, a1 * a1));
-                                    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(fmaf(Ri, pc.kE, pc.oE), -pc.cE, pc.cE));
-                                    const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-                                    const float nu = fmaf(th, pc.nA, pc.nB);
-                                    f0 = fmaf(nu * dU, pc.f0, f0);
-                                    f1 = fmaf(nu * dV, pc.f1, f1);
-                                    f2 = fmaf(nu * dT, pc.f2, f2);
-                                } else if (m.zero_w) {
-                                    f0 += bc.b[0] - m.s0[0]; f1 += bc.b[1] - m.s0[1]; f2 += bc.b[2] - m.s0[2];
-                                }
-                            } else if (m.ca && in) {
+                            if (m.ca && in) {
                                 const float gT = (Xs[2].t[tau][r] - Td.t[tau][r]) * Nz;
                                 f2 -= m.cs[2] * m.kappa * fminf(0.0f, gT);
                             }
