@@ -252,3 +252,41 @@ def test_two_engines_agree_at_the_bench_horizon_4096_columns():
     assert np.linalg.norm(ga - gb) <= 2e-2 * np.linalg.norm(gb)
     ref = cref.forward(p.cfg, p.x0[:8], p.bcs[:8], p.weights_truth, n_threads=4)
     assert np.abs(ta[:8] - ref).max() < 5e-4
+
+
+def test_non_finite_inputs_are_reported_not_returned():
+    """A NaN in the initial state poisons the solve: the host entry points say so instead of handing back NaN losses with rc 0."""
+    p = synthetic.wind_mixing_problem(9, n_frames=5, weight_divisor=1e2)
+    x0 = p.x0.copy()
+    x0[3, 40] = np.nan
+    with colnde.ColumnNDE(p.cfg, 9) as nde:
+        nde.set_problem(x0, p.bcs, np.zeros((9, 5, 96), np.float32))
+        with pytest.raises(colnde.ColndeError, match="not finite"):
+            nde.loss(p.weights, [1] * 6)
+        with pytest.raises(colnde.ColndeError, match="not finite"):
+            nde.loss_grad(p.weights, [1] * 6)
+
+
+def test_two_handles_side_by_side_do_not_disturb_each_other():
+    """Two handles of different models alive at once (own tapes, own slabs, one device): each gives what it gives alone."""
+    pw = synthetic.wind_mixing_problem(40, n_frames=5, weight_divisor=1e2)
+    pf = synthetic.free_convection_problem(19, Nz=32, n_save=5, substeps=2, t_end=0.01)
+    scw, scf = [1, 1, 1, 5e-3, 5e-3, 5e-3], [0, 0, 1, 0, 0, 0]
+
+    def alone(p, sc):
+        with colnde.ColumnNDE(p.cfg, p.n_columns) as h:
+            h.set_problem(p.x0, p.bcs)
+            t = h.forward(p.weights_truth)
+            h.set_problem(p.x0, p.bcs, t)
+            return t, h.loss_grad(p.weights, sc)
+    tw, gw = alone(pw, scw)
+    tf, gf = alone(pf, scf)
+    with colnde.ColumnNDE(pw.cfg, 40) as a, colnde.ColumnNDE(pf.cfg, 19) as b:
+        a.set_problem(pw.x0, pw.bcs, tw)
+        b.set_problem(pf.x0, pf.bcs, tf)
+        ga1 = a.loss_grad(pw.weights, scw)
+        gb1 = b.loss_grad(pf.weights, scf)
+        ga2 = a.loss_grad(pw.weights, scw)
+    for got, ref in ((ga1, gw), (ga2, gw), (gb1, gf)):
+        assert got[0] == ref[0]
+        np.testing.assert_array_equal(got[2], ref[2])
