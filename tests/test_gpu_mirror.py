@@ -290,3 +290,34 @@ def test_two_handles_side_by_side_do_not_disturb_each_other():
     for got, ref in ((ga1, gw), (ga2, gw), (gb1, gf)):
         assert got[0] == ref[0]
         np.testing.assert_array_equal(got[2], ref[2])
+
+
+def test_config4_shard_size_16384_columns_known_answer_and_conservation():
+    """One GPU's shard of BASELINE config 4 at full width (16,384 columns x 64 levels, 64-256-256-63): more tiles than CUs, so the
+    taped adjoint runs two workgroups per CU and the forward streams its weights from L2.  Size-independent checks: the zero-weight
+    known answer for every column (exact for any RK), the gradient of a loss that is exactly zero is exactly zero, determinism, and
+    heat conservation with non-zero weights (the flux divergence telescopes: only the boundary fluxes change a column's heat)."""
+    n = 16384
+    p = synthetic.free_convection_problem(n, Nz=64, n_save=5, substeps=2, t_end=0.02)
+    cfg = p.cfg
+    sc = [0, 0, 1.0, 0, 0, 0]
+    C = cfg.sigma[5] / cfg.sigma[2] * cfg.tau / cfg.H
+    t = np.asarray(cfg.save_times, np.float32)
+    with colnde.ColumnNDE(cfg, n) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        sol0 = nde.forward(np.zeros(cfg.n_params, np.float32))
+        np.testing.assert_array_equal(sol0[:, :, 1:-1], np.repeat(p.x0[:, None, 1:-1], 5, 1))
+        np.testing.assert_allclose(sol0[:, :, -1], p.x0[:, -1:] - C * 64 * p.bcs[:, 1:2] * t[None], rtol=1e-5, atol=2e-6)
+        sol = nde.forward(p.weights)
+        heat = sol.sum(axis=2) / 64.0                                    # column mean of T-hat
+        expect = heat[:, :1] + C * (p.bcs[:, 0:1] - p.bcs[:, 1:2]) * t[None]
+        np.testing.assert_allclose(heat, expect, rtol=0, atol=5e-5)
+        nde.set_problem(p.x0, p.bcs, sol)                                # truth = the model's own trajectory: loss and gradient vanish
+        tot, terms, grad = nde.loss_grad(p.weights, sc)
+        assert tot == 0.0 and not grad.any()
+        truth = nde.forward(p.weights_truth)
+        nde.set_problem(p.x0, p.bcs, truth)
+        a = nde.loss_grad(p.weights, sc)
+        b = nde.loss_grad(p.weights, sc)
+        assert a[0] == b[0] and a[0] > 0 and np.array_equal(a[2], b[2]) and np.isfinite(a[2]).all()
+        assert nde.plan()["dw_taped"]
