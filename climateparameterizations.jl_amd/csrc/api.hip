@@ -53,6 +53,7 @@ struct colnde_handle {
     size_t lds_fwd = 0, lds_adj = 0, lds_fwd_solve = 0;
     int fwd_threads = 256;
     bool fwd_wlds = false;
+    bool fwd_split = false;         // forward solves by rt16s_forward_kernel (three waves per tile) beside the tile16 adjoint
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
     float* d_wimg = nullptr;
     float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_tapez = nullptr;
@@ -379,6 +380,13 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     h->use_rt = rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine != COLNDE_ENGINE_GENERIC &&
                 (cfg->engine == COLNDE_ENGINE_MFMA || cfg->n_columns >= 4096 || !h->geo_ok);
     h->rt_fwd32 = h->use_rt && rt_forward_is32();
+    // AUTO on a regtile-shaped problem too small for regtile (a latency point): tile16 takes the gradient, the three-wave split kernel the
+    // forward solves (8 simulations: 19.8 -> ms).  An explicit engine = tile16 stays pure tile16; COLNDE_T16_FWD_SPLIT=0|1 overrides.
+    h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine == COLNDE_ENGINE_AUTO;
+    {
+        const char* es = getenv("COLNDE_T16_FWD_SPLIT");
+        if (es) h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && atoi(es) != 0;
+    }
     if (cfg->engine == COLNDE_ENGINE_MFMA && !h->use_rt) {
         delete h;
         return fail("engine = regtile requested, but it covers only Nz=32, three 96-50-20-31 nets, no smoothing, training RHS, RK4");
@@ -652,6 +660,17 @@ static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_
         if (e != hipSuccess) return fail("hipMalloc of the %zu-byte stage tape failed: %s", n * sizeof(float), hipGetErrorString(e));
     }
     Timed tm(h, K_FORWARD);
+    if (h->fwd_split) {
+        // latency points of the wind-mixing shape: three wavefronts per 16-column tile, one per flux net (engine_regtile.hip); the tapes
+        // come out in tile16's formats for its taped adjoint
+        hipError_t es = rt_launch_pack(h->m, d_weights, h->d_wimg, h->stream);
+        if (es == hipSuccess)
+            es = rt_launch_forward_split(h->m, h->d_wimg, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
+                                         h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
+                                         with_tape ? h->d_tape : nullptr, with_tape ? h->d_t16_ztape : nullptr, nc, h->stream);
+        if (es != hipSuccess) return fail("split forward launch failed: %s", hipGetErrorString(es));
+        return 0;
+    }
     hipError_t e = launch_forward(h->m, h->pk, d_weights, h->d_wf, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times,
                                   h->cfg.n_save, h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
                                   with_tape ? h->d_tape : nullptr, nc, h->fwd_threads, h->fwd_wlds, h->lds_fwd_solve, h->stream,

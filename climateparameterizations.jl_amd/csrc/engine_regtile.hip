@@ -1383,6 +1383,236 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward solve of ONE 16-column tile by THREE wavefronts — the latency points (8 .. a few thousand simulations: fewer tiles than CUs,
+// the shape the reference actually trains, NDE_training.jl:291).  The three flux nets are independent given the state, and so are the
+// three variables' tendencies given the fluxes: wave n runs net n (4 + 2 + 2 output tiles: 132 MFMAs instead of 348 in a row) and advances
+// variable n; the new stage input of each variable goes through a double-buffered LDS exchange (one barrier per stage).  Same
+// arithmetic, layouts and chains as rt16_forward_kernel.  The tapes are written in tile16's formats, because at these sizes the gradient
+// is taken by tile16's taped adjoint: stage inputs [tile][step][stage][column][3 Nz], hidden pre-activations [tile][step][stage][column][net][72].
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ void __launch_bounds__(192)
+rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
+                     const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
+                     float* __restrict__ t16_tape, float* __restrict__ t16_ztape, int n_col) {
+    float* wl = rt_smem;
+    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += 192) wl[e] = wimg[e];
+    f32x4v* ex = reinterpret_cast<f32x4v*>(rt_smem + ((RT_IMG_FLOATS + 3) & ~3));          // [2 buffers][3 variables][2 tiles][64 lanes]
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int n = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                        // this wave's net = its variable
+    const int j = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x;
+    const int col = tile * 16 + j;
+    const bool valid = col < n_col;
+    const int colc = min(col, n_col - 1);
+    const int i_ = lane & 15, g_i = i_ >> 2, r_i = i_ & 3;
+    int a1b[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int Q = 4 * t + r_i, f = 4 * Q + g_i;
+        a1b[t] = RT_W1C + (n * 50 + ((Q < 13 && f < 50) ? f : 0)) * RT_LD1 + 4 * g;       // padding rows read a valid row; never consumed
+    }
+    int a2b[2], a2l[2], a3b[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int Q2 = 4 * u + r_i;
+        const int row2 = n * 20 + (Q2 < 5 ? 4 * Q2 + g_i : 0);
+        a2b[u] = RT_W2C + row2 * RT_LD2 + g;
+        a2l[u] = RT_W2C + row2 * RT_LD2 + (g < 2 ? 48 + g : 50);
+        a3b[u] = RT_W3C + (n * 31 + 16 * u + i_ - 1) * RT_LD3 + g;
+    }
+    float bcb, bct, bc5;
+    {
+        const float* bp = bcs + (size_t)colc * 6;
+        bcb = bp[2 * n];
+        bct = bp[2 * n + 1];
+        bc5 = bp[5];
+    }
+    V16 Xs[3], Xn, Kacc;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++) Xs[q].t[tau] = *reinterpret_cast<const f32x4v*>(x0 + (size_t)colc * 96 + q * 32 + 16 * tau + 4 * g);
+    // (wave-uniform n: a select, not a dynamic register index)
+    Xn = n == 0 ? Xs[0] : (n == 1 ? Xs[1] : Xs[2]);
+    if (sol && valid)
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
+    const int n_steps = (n_save - 1) * substeps;
+    float* tp = t16_tape ? t16_tape + (size_t)tile * n_steps * 4 * 1536 + j * 96 + n * 32 + 4 * g : nullptr;
+    float* tz = t16_ztape ? t16_ztape + (size_t)tile * n_steps * 4 * (16 * 216) + j * 216 + n * 72 + g : nullptr;
+    const float Nz = 32.0f;
+    const float L2E = 1.4426950408889634f;
+    const float cU = m.sig_u * Nz, sU = m.sig_u * m.eps, cV = m.sig_v * Nz, sV = m.sig_v * m.eps, cB = m.B * Nz, sB = m.B * m.eps;
+    const float kE = 2.0f * m.inv_dRi * L2E, oE = -2.0f * m.Ric * m.inv_dRi * L2E, cE = 30.0f * L2E;
+    const float nA = -0.5f * m.nu_minus, nB = m.nu0 + 0.5f * m.nu_minus;
+    const float fn = n == 0 ? -m.cs[0] * Nz : (n == 1 ? -m.cs[1] * Nz : -m.cs[2] * m.inv_Pr * Nz);
+    const float s0n = n == 0 ? m.s0[0] : (n == 1 ? m.s0[1] : m.s0[2]);
+    const float An = n == 0 ? m.A[0] : (n == 1 ? m.A[1] : m.A[2]);
+    int step = 0, buf = 0;
+    for (int iv = 0; iv < n_save - 1; iv++) {
+        const float t0 = save_times[iv];
+        const float dt = (save_times[iv + 1] - t0) / (float)substeps;
+        for (int s = 0; s < substeps; s++, step++) {
+            const float ts = t0 + (float)s * dt;
+            Kacc.t[0] = (f32x4t)(0.0f);
+            Kacc.t[1] = (f32x4t)(0.0f);
+#pragma nounroll
+            for (int st = 0; st < 4; st++) {
+                const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);
+                const float cb = (st == 0 || st == 3) ? 1.0f / 6.0f : 1.0f / 3.0f;
+                const V16 Xme = n == 0 ? Xs[0] : (n == 1 ? Xs[1] : Xs[2]);
+                if (tp) {
+                    float* o = tp + ((size_t)step * 4 + st) * 1536;
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(o + 16 * tau) = Xme.t[tau];
+                }
+                float* oz = tz ? tz + ((size_t)step * 4 + st) * (16 * 216) : nullptr;
+                const float top_raw = n == 2 ? rt_top_flux(m, bc5, ts + ca * dt) : bct;
+                // ---- net n ----------------------------------------------------------------------------------------------
+                f32x4t A1[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    f32x4t acc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int Q = 4 * t + r;
+                        acc[r] = Q < 13 ? wl[RT_B1C + n * 50 + min(4 * Q + g, 49)] : 0.0f;
+                    }
+                    const int base = a1b[t];
+                    acc = rt16_chain<24, 8>(wl, acc, [=](int k) { return base + (k >> 3) * 32 + ((k >> 2) & 1) * 16 + (k & 3); },
+                                            [&](int k) { return Xs[k >> 3].t[(k >> 2) & 1][k & 3]; });
+                    if (oz) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int Q = 4 * t + r;
+                            if (Q < 13 && (Q < 12 || g < 2)) oz[4 * Q] = acc[r];             // feature 4 Q + g of layer 1
+                        }
+                    }
+                    A1[t] = rt_act4<ACT>(acc);
+                }
+                f32x4t A2[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    f32x4t acc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[r] = (4 * u + r < 5) ? wl[RT_B2C + n * 20 + 4 * (4 * u + r) + g] : 0.0f;
+                    const int base = a2b[u], basel = a2l[u];
+                    acc = rt16_chain<13, 13>(wl, acc, [=](int k) { return k < 12 ? base + 4 * k : basel; },
+                                             [&](int k) { return A1[k >> 2][k & 3]; });
+                    if (oz) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (4 * u + r < 5) oz[52 + 4 * (4 * u + r)] = acc[r];            // feature 4 Q2 + g of layer 2
+                    }
+                    A2[u] = rt_act4<ACT>(acc);
+                }
+                V16 O;
+#pragma unroll
+                for (int v = 0; v < 2; v++) {
+                    f32x4t acc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[r] = wl[RT_B3C + n * 32 + 16 * v + 4 * g + r];
+                    const int base = a3b[v];
+                    O.t[v] = rt16_chain<5, 5>(wl, acc, [=](int k) { return base + 4 * k; }, [&](int k) { return A2[k >> 2][k & 3]; });
+                }
+                // ---- physics: face flux and tendency of variable n (predict_flux / predict_NDE) -----------------------------
+                V16 F;
+                {
+                    V16 Ud, Vd, Td;
+                    if (m.mpp || m.ca) {
+                        Ud = shift_down16(Xs[0], lane, 0.0f); Vd = shift_down16(Xs[1], lane, 0.0f); Td = shift_down16(Xs[2], lane, 0.0f);
+                    }
+                    if (m.mpp) {
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                            for (int r = 0; r < 4; r += 2) {
+                                const f32x2v dU = {Xs[0].t[tau][r] - Ud.t[tau][r], Xs[0].t[tau][r + 1] - Ud.t[tau][r + 1]};
+                                const f32x2v dV = {Xs[1].t[tau][r] - Vd.t[tau][r], Xs[1].t[tau][r + 1] - Vd.t[tau][r + 1]};
+                                const f32x2v dT = {Xs[2].t[tau][r] - Td.t[tau][r], Xs[2].t[tau][r + 1] - Td.t[tau][r + 1]};
+                                const f32x2v a1 = dU * cU + sU, a2 = dV * cV + sV;
+                                const f32x2v s2 = a2 * a2 + a1 * a1;
+                                f32x2v rS;
+                                rS.x = __builtin_amdgcn_rcpf(s2.x);
+                                rS.y = __builtin_amdgcn_rcpf(s2.y);
+                                const f32x2v arg = ((dT * cB + sB) * rS) * kE + oE;
+                                f32x2v e;
+                                e.x = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(arg.x, -cE, cE));
+                                e.y = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(arg.y, -cE, cE));
+                                const f32x2v e1 = e + 1.0f;
+                                f32x2v rc;
+                                rc.x = __builtin_amdgcn_rcpf(e1.x);
+                                rc.y = __builtin_amdgcn_rcpf(e1.y);
+                                const f32x2v nu = (rc * -2.0f + 1.0f) * nA + nB;
+                                const f32x2v dn = n == 0 ? dU : (n == 1 ? dV : dT);
+                                const f32x2v on = {O.t[tau][r], O.t[tau][r + 1]};
+                                const f32x2v f = (nu * dn) * fn + on;
+                                F.t[tau][r] = f.x; F.t[tau][r + 1] = f.y;
+                            }
+                        if (g == 0) F.t[0][0] = m.zero_w ? bcb - s0n : bcb;                 // face 0: the bottom boundary
+                    } else {
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const bool in = !(tau == 0 && r == 0 && g == 0);
+                                float f = in ? O.t[tau][r] : (m.zero_w ? 0.0f : bcb);
+                                if (m.ca && in && n == 2) {
+                                    const float gT = (Xs[2].t[tau][r] - Td.t[tau][r]) * Nz;
+                                    f -= m.cs[2] * m.kappa * fminf(0.0f, gT);
+                                }
+                                F.t[tau][r] = f;
+                            }
+                    }
+                }
+                {
+                    const float top = m.zero_w ? top_raw - s0n : top_raw;
+                    const V16 Fu = shift_up16(F, lane, top);
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float v = -An * (Fu.t[tau][r] - F.t[tau][r]);
+                            if (n == 0) v += m.cor_u * (m.sig_v * Xs[1].t[tau][r] + m.mu_v);
+                            if (n == 1) v -= m.cor_v * (m.sig_u * Xs[0].t[tau][r] + m.mu_u);
+                            F.t[tau][r] = v;                                                // F now holds the tendency of variable n
+                        }
+                }
+                // ---- RK4 bookkeeping for variable n; the next stage input (or, after stage 3, the new state) is exchanged -------------
+                V16 Xnext;
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) {
+                    Kacc.t[tau] += cb * F.t[tau];
+                    if (st < 3) {
+                        const float can = st == 2 ? 1.0f : 0.5f;
+                        Xnext.t[tau] = Xn.t[tau] + (can * dt) * F.t[tau];
+                    } else {
+                        Xn.t[tau] += dt * Kacc.t[tau];
+                        Xnext.t[tau] = Xn.t[tau];
+                    }
+                }
+                f32x4v* eb = ex + buf * 384;
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) eb[(n * 2 + tau) * 64 + lane] = Xnext.t[tau];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) Xs[q].t[tau] = eb[(q * 2 + tau) * 64 + lane];
+                buf ^= 1;
+            }
+            if (s == substeps - 1 && sol && valid) {
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++)
+                    *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save + iv + 1) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 bool rt_supported(const DevModel& m) {
@@ -1418,6 +1648,12 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_SWISH>);
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_TANH>);
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_LEAKYRELU>);
+    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_IDENTITY>);
+    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_RELU>);
+    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_MISH>);
+    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_SWISH>);
+    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_TANH>);
+    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU>);
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -1482,6 +1718,25 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
         }
 #undef RT_FWD
     }
+    return hipGetLastError();
+}
+
+// the three-wavefronts-per-tile forward solve of the latency points; tapes (optional) in tile16's formats
+hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const float* x0, const float* bcs, const float* save_times,
+                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, hipStream_t stream) {
+    const size_t lds = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + 2 * 384 * 16;
+    const dim3 grid((n_col + 15) / 16), block(192);
+#define RT_FWDS(A) hipLaunchKernelGGL(rt16s_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col)
+    switch (m.acts[0]) {
+        case COLNDE_ACT_IDENTITY: RT_FWDS(COLNDE_ACT_IDENTITY); break;
+        case COLNDE_ACT_RELU: RT_FWDS(COLNDE_ACT_RELU); break;
+        case COLNDE_ACT_MISH: RT_FWDS(COLNDE_ACT_MISH); break;
+        case COLNDE_ACT_SWISH: RT_FWDS(COLNDE_ACT_SWISH); break;
+        case COLNDE_ACT_TANH: RT_FWDS(COLNDE_ACT_TANH); break;
+        case COLNDE_ACT_LEAKYRELU: RT_FWDS(COLNDE_ACT_LEAKYRELU); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RT_FWDS
     return hipGetLastError();
 }
 

@@ -87,7 +87,7 @@ for c in which:
             print("ADAM step: %d parameters: kernel %.4f ms -> %.0f GB/s (28 B/parameter); wall %.4f ms" % (n, kt * 1e3, n * 28 / kt / 1e9, dt * 1e3), flush=True)
         nde.close()
     if c == "3":      # latency point: 8 simulations x 32 levels x 289 frames, fwd+adjoint (BASELINE configs[2] as written), both engines
-        for eng in (2, 1):
+        for eng in (2, 1, 0):      # regtile, tile16, AUTO (tile16 gradient + three-wave split forward)
             p = synthetic.wind_mixing_problem(8)
             nde = colnde.ColumnNDE(p.cfg, 8, engine=eng)
             x0, bcs, w, wt = (torch.from_numpy(a).to(dev) for a in (p.x0, p.bcs, p.weights, p.weights_truth))
