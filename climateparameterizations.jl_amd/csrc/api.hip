@@ -381,7 +381,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
                 (cfg->engine == COLNDE_ENGINE_MFMA || cfg->n_columns >= 4096 || !h->geo_ok);
     h->rt_fwd32 = h->use_rt && rt_forward_is32();
     // AUTO on a regtile-shaped problem too small for regtile (a latency point): tile16 takes the gradient, the three-wave split kernel the
-    // forward solves (8 simulations: 19.8 -> ms).  An explicit engine = tile16 stays pure tile16; COLNDE_T16_FWD_SPLIT=0|1 overrides.
+    // forward solves (8 simulations: 19.8 -> 10.6 ms).  An explicit engine = tile16 stays pure tile16; COLNDE_T16_FWD_SPLIT=0|1 overrides.
     h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine == COLNDE_ENGINE_AUTO;
     {
         const char* es = getenv("COLNDE_T16_FWD_SPLIT");
