@@ -624,7 +624,7 @@ static int rt_plan_tapes(colnde_handle* h) {
     hipError_t e = hipMalloc((void**)&h->d_rt_tape, n1 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_rt_tape2, n2 * sizeof(float));
     h->rt_ztape = want_z;
-    if (e == hipSuccess && h->rt_ztape && hipMalloc((void**)&h->d_rt_tapez, n2 * sizeof(float)) != hipSuccess) {
+    if (e == hipSuccess && h->rt_ztape && hipMalloc((void**)&h->d_rt_tapez, rt_tapez_floats(block, n_steps) * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         h->d_rt_tapez = nullptr;
         h->rt_ztape = false;

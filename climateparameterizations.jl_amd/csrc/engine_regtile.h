@@ -33,6 +33,7 @@ bool rt_forward_is32();   // COLNDE_RT_FWD=32 in the environment (read when a ha
 size_t rt_adjoint_lds_bytes();
 size_t rt_tape_floats(int n_col, int n_steps);
 size_t rt_tape2_floats(int n_col, int n_steps);
+size_t rt_tapez_floats(int n_col, int n_steps);
 int rt_n_wtiles(int n_col);
 int rt_dw1_waves(int n_col, int n_steps);
 hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,

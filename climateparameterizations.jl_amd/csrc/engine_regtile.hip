@@ -24,10 +24,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // diagnostic build only (-DCOLNDE_STAMPS): per-phase cycle sums of wave 0 of workgroup 0
 #ifdef COLNDE_STAMPS
 __device__ unsigned long long g_rt_stamps[16];
-#define RT_STAMP_DECL unsigned long long rs_t0 = 0, rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RT_STAMP_DECL unsigned long long rs_t0 = 0, rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long rs_kk = __builtin_amdgcn_s_memtime(), rs_rr = __builtin_amdgcn_s_memrealtime()
 #define RT_STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); rs_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define RT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); rs_acc[i] += t_ - rs_t0; rs_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define RT_STAMP_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int q_ = 0; q_ < 8; q_++) g_rt_stamps[q_] = rs_acc[q_]; } while (0)
+// slots 8, 9: the whole kernel in shader ticks and in 100 MHz reference ticks (their ratio is the clock the kernel ran at)
+#define RT_STAMP_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int q_ = 0; q_ < 8; q_++) g_rt_stamps[q_] = rs_acc[q_]; g_rt_stamps[8] = __builtin_amdgcn_s_memtime() - rs_kk; g_rt_stamps[9] = __builtin_amdgcn_s_memrealtime() - rs_rr; } } while (0)
 #else
 #define RT_STAMP_DECL
 #define RT_STAMP_BEGIN()
@@ -46,7 +47,8 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #ifndef RT_ADJ_CH
 #define RT_ADJ_CH 8       // A-operand prefetch depth (k-steps) of the adjoint kernel's layer-1 chains
 #endif
-#define RT_TAPE2 (21 * 256)   // floats per (tile, step, stage) of the layer-1 delta tape: 3 nets x 7 groups x 64 lanes x 4
+#define RT_TAPEZ (21 * 256)   // floats per (tile, step, stage) of the layer-1 pre-activation tape: 3 nets x 7 groups x 64 lanes x 4
+#define RT_TAPE2 (20 * 256)   // ... of the layer-1 delta tape: 20 groups x 64 lanes x 4, the three nets' 25 registers stacked (G = 25 n + g)
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -664,8 +666,8 @@ __device__ __forceinline__ float rt_sum16(const f32x16 v) {
 __host__ __device__ constexpr int rt_combo(int n, int mt) { return n == 0 ? mt : (n == 1 ? 1 + mt : 2 + mt); }
 
 // tape of stage inputs (written by rt_forward_kernel):  [tile][step][stage][12 groups][64 lanes][4]
-// tape2 of layer-1 deltas (written here, read by rt_dw1_kernel): [tile][step][stage][net][7 groups][64 lanes][4]; element e of
-// group grp of net n is register g = 4 grp + e (features 2g, 2g+1 of net n; g >= 25: zero padding)
+// tape2 of layer-1 deltas (written here, read by rt_dw1_kernel): [tile][step][stage][20 groups][64 lanes][4]; element e of
+// group grp is stacked register G = 4 grp + e = 25 n + g (features 2g, 2g+1 of net n; G >= 75: never written, never used)
 template <int ACT, bool ZT>
 __global__ void __launch_bounds__(256)
 rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ bcs,
@@ -717,7 +719,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     const int n_steps = (n_save - 1) * substeps;
     const float* tp = tape + (size_t)tile * n_steps * 4 * 3072 + lane * 4;
     float* tp2 = tape2 + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4;
-    const float* tpz = ZT ? tapez + (size_t)tile * n_steps * 4 * RT_TAPE2 + lane * 4 : nullptr;
+    const float* tpz = ZT ? tapez + (size_t)tile * n_steps * 4 * RT_TAPEZ + lane * 4 : nullptr;
 
     // loss injection at save point n: λ += ∂loss/∂sol[:, n]; also the six raw sums of squares
     auto inject = [&](int n, bool add) {
@@ -752,7 +754,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 
     // taped layer-1 pre-activations of net n at (step, stage): registers G' < 25 of Z (padding registers untouched)
     auto load_z1 = [&](int step, int st, int n, f32x16 (&Z)[2]) {
-        const float* srcz = tpz + ((size_t)step * 4 + st) * RT_TAPE2 + n * 7 * 256;
+        const float* srcz = tpz + ((size_t)step * 4 + st) * RT_TAPEZ + n * 7 * 256;
 #pragma unroll
         for (int grp = 0; grp < 7; grp++) {
             const f32x4v v = *reinterpret_cast<const f32x4v*>(srcz + grp * 256);
@@ -893,11 +895,18 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                         for (int r = 0; r < 16; r++) D1[t][r] = da[r] * D1[t][r];     // dZ1 in place of act'(z1)
                     }
+                    // delta tape: register g of net n is stacked register G = 25 n + g, element G & 3 of 16-byte group G >> 2
+                    // (whole groups with one store, the registers at a net boundary one by one)
 #pragma unroll
-                    for (int grp = 0; grp < 7; grp++) {
-                        const f32x4v v = {D1[grp >> 2][(grp & 3) * 4], D1[grp >> 2][(grp & 3) * 4 + 1],
-                                          D1[grp >> 2][(grp & 3) * 4 + 2], D1[grp >> 2][(grp & 3) * 4 + 3]};
-                        *reinterpret_cast<f32x4v*>(dst + (n * 7 + grp) * 256) = v;
+                    for (int g = 0; g < 25; g++) {
+                        const int G = 25 * n + g;
+                        if ((G & 3) == 0 && g + 3 < 25) {
+                            const f32x4v v = {D1[g >> 4][g & 15], D1[(g + 1) >> 4][(g + 1) & 15], D1[(g + 2) >> 4][(g + 2) & 15],
+                                              D1[(g + 3) >> 4][(g + 3) & 15]};
+                            *reinterpret_cast<f32x4v*>(dst + (G >> 2) * 256) = v;
+                        } else if (g < (G & 3) || g - (G & 3) + 3 >= 25) {
+                            dst[(G >> 2) * 256 + (G & 3)] = D1[g >> 4][g & 15];
+                        }
                     }
                     RT_STAMP(5);
                     // (6) x̄ += W1_n^T dZ1_n
@@ -981,16 +990,24 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 // ------------------------------------------------------------------------------------------------
 // dW1 / db1: a streaming GEMM over the two tapes, contracted over (column, step, stage)
 //   dW1[n*50+f][c] = sum dZ1[(n,f)][col] * X[c][col]
-// Each wave walks items (tile, step, stage), transposes the two register images through LDS and accumulates all
-// 15 (layer-1 tile, state tile) products in registers; its partial result is one slab row.
+// Each wave walks items (tile, step, stage) and accumulates all 15 (layer-1 tile, state tile) products in registers; its
+// partial result is one slab row.  An item's two tape records are register images of the kernels that wrote them
+// (lane = column, registers = rows); the products contract over columns, so their MFMA operands are the transposed tiles.
+// The transposition costs nothing here: the record goes HBM -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane, no
+// registers), and because the DMA's SOURCE address is per lane while its destination is lane-linear, each 1-KB
+// wave-instruction gathers the 16-byte pieces (4 consecutive rows of one column) of 8 columns so that they land as a
+// column-major tile [col][row] — the operand of k-step s, lane (row m, kh), is then the conflict-free read
+// tile[(2 s + kh) * 32 + m].  The unit of the pipeline is a QUARTER item (8 columns of all 8 tiles: 8 DMA instructions,
+// 8 KB, 60 MFMAs): a ring of four quarter buffers per wave, DMA issued three quarters ahead (counted vmcnt), operands
+// read one quarter ahead into the other of two register sets — so neither the HBM latency nor the LDS reads are exposed.
 // ------------------------------------------------------------------------------------------------
+#define RT_DW1_LDS (4 * 2048)      // floats per wave: ring of four quarter-item buffers [8 tiles][8 cols][32 rows]
 __global__ void __launch_bounds__(256)
 rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restrict__ tape2, long n_items,
               float* __restrict__ slab_rows) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    float* tb = rt_smem + wave * 1056;
-    const int wbase = 4 * h * 33 + j, rbase = j * 33 + h;
+    float* buf = rt_smem + wave * RT_DW1_LDS;
     const long gw = (long)blockIdx.x * RT_WAVES + wave, GW = (long)gridDim.x * RT_WAVES;
     f32x16 gW1[5][3];
 #pragma unroll
@@ -998,58 +1015,64 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
 #pragma unroll
         for (int q = 0; q < 3; q++) gW1[mt][q] = (f32x16)(0.0f);
     float b1acc[5] = {0, 0, 0, 0, 0};
-    // register images of the item in flight; the next item's loads are issued as soon as these have been consumed, so
-    // that their HBM latency hides under the current item's outer products
-    f32x4v xq[12], zq[21];
-    if (gw < n_items) {
-        const float* sx = tape + (size_t)gw * 3072 + lane * 4;
-        const float* sz = tape2 + (size_t)gw * RT_TAPE2 + lane * 4;
+    const int NQ = gw < n_items ? 4 * (int)((n_items - gw + GW - 1) / GW) : 0;       // this wave's quarters
+    // DMA piece i of tile T: lane L fetches rows 4 k .. 4 k + 3 (k = L & 7) of column 8 i + (L >> 3), which the record holds in
+    // group 4 T + (k >> 1), lane (k & 1) * 32 + column
+    const int soff = ((lane >> 1) & 3) * 256 + ((lane & 1) * 32 + (lane >> 3)) * 4;
+    // quarter Q of this wave into ring slot `ring`; past the end the last quarter is fetched again (into a slot nobody reads), so that
+    // the counted waits below always see the same number of DMAs in flight
+    auto issue = [&](int Q, int ring) {
+        const int Qc = Q < NQ ? Q : NQ - 1;
+        const size_t item = (size_t)(gw + (long)(Qc >> 2) * GW);
+        const float* sx = tape + item * 3072 + soff + (Qc & 3) * 32;
+        const float* sz = tape2 + item * RT_TAPE2 + soff + (Qc & 3) * 32;
 #pragma unroll
-        for (int g = 0; g < 12; g++) xq[g] = *reinterpret_cast<const f32x4v*>(sx + g * 256);
+        for (int T = 0; T < 3; T++) __builtin_amdgcn_global_load_lds(sx + T * 1024, buf + ring * 2048 + T * 256, 16, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 21; g++) zq[g] = *reinterpret_cast<const f32x4v*>(sz + g * 256);
+        for (int T = 0; T < 5; T++) __builtin_amdgcn_global_load_lds(sz + T * 1024, buf + ring * 2048 + (3 + T) * 256, 16, 0, 0);
+    };
+    const float* rd = buf + h * 32 + j;
+    float op[2][8][4];                         // operand sets: [set][tile][k-step]: tile[(2 s + kh) * 32 + m]
+    auto read_set = [&](int set, int ring) {
+#pragma unroll
+        for (int T = 0; T < 8; T++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) op[set][T][s] = rd[ring * 2048 + T * 256 + 64 * s];
+    };
+    if (NQ > 0) {
+        issue(0, 0);
+        issue(1, 1);
+        issue(2, 2);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        read_set(0, 0);
     }
-    for (long item = gw; item < n_items; item += GW) {
-        const long nxt = item + GW;
-        f32x16 TB[3];
+    for (int Qb = 0; Qb < NQ; Qb += 4) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            f32x16 x;
+        for (int u = 0; u < 4; u++) {
+            const int cur = u & 1;
+            // first delta tile of this quarter; behind it the DMA three quarters ahead and the operand reads one quarter ahead
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                x[4 * g] = xq[q * 4 + g][0]; x[4 * g + 1] = xq[q * 4 + g][1]; x[4 * g + 2] = xq[q * 4 + g][2]; x[4 * g + 3] = xq[q * 4 + g][3];
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) gW1[0][q] = mfma32(op[cur][3][s], op[cur][q][s], gW1[0][q]);
+            b1acc[0] += (op[cur][3][0] + op[cur][3][1]) + (op[cur][3][2] + op[cur][3][3]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(Qb + u + 3, (u + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // quarter Qb + u + 1 has landed (two younger ones in flight)
+            read_set(cur ^ 1, (u + 1) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 1; mt < 5; mt++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) gW1[mt][q] = mfma32(op[cur][3 + mt][s], op[cur][q][s], gW1[mt][q]);
+                b1acc[mt] += (op[cur][3 + mt][0] + op[cur][3 + mt][1]) + (op[cur][3 + mt][2] + op[cur][3 + mt][3]);
             }
-            TB[q] = rt_transpose(tb, x, wbase, rbase);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (nxt < n_items) {
-            const float* sx = tape + (size_t)nxt * 3072 + lane * 4;
-#pragma unroll
-            for (int g = 0; g < 12; g++) xq[g] = *reinterpret_cast<const f32x4v*>(sx + g * 256);
-        }
-        // the 75 taped registers (net n, g) re-assembled into the stacked tiles: G = 25 n + g = 16 mt + r
-        f32x16 TA[5];
-#pragma unroll
-        for (int mt = 0; mt < 5; mt++) {
-            f32x16 z;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int G = mt * 16 + r;
-                const int e = (G / 25) * 28 + (G % 25);
-                z[r] = G < 75 ? zq[e >> 2][e & 3] : 0.0f;
-            }
-            TA[mt] = rt_transpose(tb, z, wbase, rbase);
-            b1acc[mt] += rt_sum16(TA[mt]);
-        }
-        if (nxt < n_items) {
-            const float* sz = tape2 + (size_t)nxt * RT_TAPE2 + lane * 4;
-#pragma unroll
-            for (int g = 0; g < 21; g++) zq[g] = *reinterpret_cast<const f32x4v*>(sz + g * 256);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 5; mt++)
-#pragma unroll
-            for (int q = 0; q < 3; q++) gW1[mt][q] = rt_outer(gW1[mt][q], TA[mt], TB[q]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* out = slab_rows + (size_t)gw * (m.n_params + 8);
     // D[m = layer-1 row rho(r,h) of tile mt][n' = state feature 32 q + j]
 #pragma unroll
@@ -1196,7 +1219,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
     float* tp = tape ? tape + (size_t)tile32 * n_steps * 4 * 3072 + ((g >> 1) * 64 + j + 16 * half + 32 * (g & 1)) * 4 : nullptr;
     // layer-1 pre-activations, taped in the adjoint kernel's per-net register-image format (same as the delta tape): feature
     // f = 4 qq + g of net n is element (2qq & 3) + (g >> 1) of group qq >> 1, lane32 = j + 16 half + 32 (g & 1)
-    float* tz = tapez ? tapez + (size_t)tile32 * n_steps * 4 * RT_TAPE2 + (j + 16 * half + 32 * (g & 1)) * 4 + (g >> 1) : nullptr;
+    float* tz = tapez ? tapez + (size_t)tile32 * n_steps * 4 * RT_TAPEZ + (j + 16 * half + 32 * (g & 1)) * 4 + (g >> 1) : nullptr;
     const float Nz = 32.0f;
     struct { float cU, sU, cV, sV, cB, sB, kE, oE, cE, nA, nB, f0, f1, f2; } pc;
     {
@@ -1243,7 +1266,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                     acc = rt16_chain<24, 8>(wl, acc, [=](int k) { return base + (k >> 3) * 32 + ((k >> 2) & 1) * 16 + (k & 3); },
                                             [&](int k) { return Xs[k >> 3].t[(k >> 2) & 1][k & 3]; });
                     if (tz) {
-                        float* oz = tz + ((size_t)step * 4 + st) * RT_TAPE2;
+                        float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int Q = 4 * t + r, qq = Q % 13;
@@ -1625,6 +1648,7 @@ size_t rt_forward_lds_bytes() { return (size_t)RT_IMG_FLOATS * sizeof(float); }
 size_t rt_adjoint_lds_bytes() { return ((size_t)RT_IMG_FLOATS + RT_WAVES * (3072 + 1056)) * sizeof(float); }
 size_t rt_tape_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * 3072; }
 size_t rt_tape2_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * RT_TAPE2; }
+size_t rt_tapez_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * RT_TAPEZ; }
 int rt_n_wtiles(int n_col) { return (n_col + RT_COLS - 1) / RT_COLS; }
 int rt_dw1_waves(int n_col, int n_steps) {
     const long items = (long)rt_n_wtiles(n_col) * n_steps * 4;
@@ -1654,6 +1678,7 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_SWISH>);
     RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_TANH>);
     RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU>);
+    RT_SETATTR(rt_dw1_kernel);
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -1770,14 +1795,14 @@ hipError_t rt_launch_dw1(const DevModel& m, const float* tape, const float* tape
                          hipStream_t stream) {
     const long items = (long)rt_n_wtiles(n_col) * n_steps * 4;
     const int waves = rt_dw1_waves(n_col, n_steps);
-    hipLaunchKernelGGL(rt_dw1_kernel, dim3(waves / RT_WAVES), dim3(64 * RT_WAVES), RT_WAVES * 1056 * sizeof(float), stream, m, tape,
+    hipLaunchKernelGGL(rt_dw1_kernel, dim3(waves / RT_WAVES), dim3(64 * RT_WAVES), RT_WAVES * RT_DW1_LDS * sizeof(float), stream, m, tape,
                        tape2, items, slab_rows);
     return hipGetLastError();
 }
 
 hipError_t rt_debug_read_stamps(unsigned long long* out8) {
 #ifdef COLNDE_STAMPS
-    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_rt_stamps), sizeof(unsigned long long) * 8);
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_rt_stamps), sizeof(unsigned long long) * 16);
 #else
     for (int i = 0; i < 8; i++) out8[i] = 0;
     return hipSuccess;

@@ -20,7 +20,8 @@ nde = colnde.ColumnNDE(p.cfg, ncol)
 nde.set_problem(p.x0, p.bcs)
 truth = nde.forward(p.weights_truth)
 nde.set_problem(p.x0, p.bcs, truth)
-nde.loss_grad(p.weights, [0, 0, 1, 0, 0, 0] if FC64 else [1, 1, 1, 5e-3, 5e-3, 5e-3])
+for _ in range(12 if ncol >= 16384 else 1):        # back-to-back launches, so that the clock stamp sees the sustained state
+    nde.loss_grad(p.weights, [0, 0, 1, 0, 0, 0] if FC64 else [1, 1, 1, 5e-3, 5e-3, 5e-3])
 buf = (ctypes.c_ulonglong * 16)()
 _lib.check(L.colnde_debug_stamps(nde._h, buf))
 if nde.engine == 2 and FWD:
@@ -39,6 +40,10 @@ if FWD:
     print("whole kernel (workgroup 0, wave 0): %d s_memtime ticks in %.3f ms (s_memrealtime, 100 MHz) -> %.3f ticks/ns; stage loop share %.1f %%"
           % (buf[6], buf[7] / 1e5, buf[6] / (buf[7] * 10.0), 100.0 * v.sum() / buf[6]))
 if nde.engine == 2:
+    # clock the stamped kernel ran at (MI355X_MICROARCH 'DVFS give-back' item 6); meaningful on launches of >= 10 ms (pass e.g. 32768 289)
+    if buf[9]:
+        print("whole kernel (workgroup 0, wave 0): %d shader ticks in %.3f ms of the 100 MHz reference -> in-kernel clock %.3f GHz"
+              % (buf[8], buf[9] / 1e5, buf[8] / (buf[9] * 10.0)))
     raise SystemExit(0)
 fine = np.array(list(buf)[8:13], dtype=np.float64)
 for n, x in zip(["layer setup", "job prologue (bias)", "MFMA chain", "epilogue (act + store)", "barrier"], fine):
