@@ -53,6 +53,7 @@ struct colnde_handle {
     size_t lds_fwd = 0, lds_adj = 0, lds_fwd_solve = 0;
     int fwd_threads = 256;
     bool fwd_wlds = false;
+    bool adj_split = false;         // ... and the gradient by rt16s_adjoint_kernel + tile16's dW GEMM
     bool fwd_split = false;         // forward solves by rt16s_forward_kernel (three waves per tile) beside the tile16 adjoint
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
     float* d_wimg = nullptr;
@@ -386,6 +387,9 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     {
         const char* es = getenv("COLNDE_T16_FWD_SPLIT");
         if (es) h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && atoi(es) != 0;
+        // the gradient behind a split forward: rt16s_adjoint_kernel (same decomposition) when the taped mode with both tapes is planned
+        const char* ea = getenv("COLNDE_T16_ADJ_SPLIT");
+        h->adj_split = h->fwd_split && !(ea && atoi(ea) == 0);
     }
     if (cfg->engine == COLNDE_ENGINE_MFMA && !h->use_rt) {
         delete h;
@@ -922,7 +926,14 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
             {
                 Timed tm(h, K_ADJOINT);
                 AdjointGeom g = {512, 1, 3, 0};
-                hipError_t e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
+                hipError_t e;
+                if (h->adj_split && h->d_t16_ztape)
+                    // the companion of the split forward: three wavefronts per tile, one per flux net, writing tile16's delta tape
+                    e = rt_launch_adjoint_split(h->m, h->d_wimg, h->d_times, h->cfg.n_save, h->cfg.substeps,
+                                                h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
+                                                h->d_t16_ztape, lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, h->d_dwtape, h->stream);
+                else
+                e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
                                               h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                               h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
                                               lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, g,
@@ -1167,7 +1178,7 @@ extern "C" int colnde_debug_stamps(colnde_handle* h, unsigned long long* out16) 
     if (!h || !out16) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->use_rt) {
+    if (h->use_rt || h->adj_split) {
         for (int i = 0; i < 16; i++) out16[i] = 0;
         HIPCHK(rt_debug_read_stamps(out16));
         return 0;

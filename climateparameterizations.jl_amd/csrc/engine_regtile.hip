@@ -145,6 +145,7 @@ __device__ __forceinline__ RtBases rt_bases(int lane) {
 // scheduled into the MFMA shadow but pins the DS reads to their region: left alone, the scheduler hoists hundreds of
 // operand reads and spills.
 #define RT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x00F)
+#define RT_SCHED_HARD() __builtin_amdgcn_sched_barrier(0)      // nothing crosses: the operand fetches of a software pipeline stay AHEAD of the MFMAs that cover them
 
 template <int N, int CH, class AF, class BF, class FF>
 __device__ __forceinline__ f32x16 rt_chain_fill(const float* wl, f32x16 acc, AF aidx, BF bval, FF fill) {
@@ -1458,7 +1459,10 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 #pragma unroll
         for (int tau = 0; tau < 2; tau++) Xs[q].t[tau] = *reinterpret_cast<const f32x4v*>(x0 + (size_t)colc * 96 + q * 32 + 16 * tau + 4 * g);
     // (wave-uniform n: a select, not a dynamic register index)
-    Xn = n == 0 ? Xs[0] : (n == 1 ? Xs[1] : Xs[2]);
+#pragma unroll
+    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Xn.t[tau][r] = n == 0 ? Xs[0].t[tau][r] : (n == 1 ? Xs[1].t[tau][r] : Xs[2].t[tau][r]);
     if (sol && valid)
 #pragma unroll
         for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
@@ -1485,7 +1489,11 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
             for (int st = 0; st < 4; st++) {
                 const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);
                 const float cb = (st == 0 || st == 3) ? 1.0f / 6.0f : 1.0f / 3.0f;
-                const V16 Xme = n == 0 ? Xs[0] : (n == 1 ? Xs[1] : Xs[2]);
+                V16 Xme;               // (element-wise selects on the wave-uniform n: a select between the aggregates becomes a scratch array)
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Xme.t[tau][r] = n == 0 ? Xs[0].t[tau][r] : (n == 1 ? Xs[1].t[tau][r] : Xs[2].t[tau][r]);
                 if (tp) {
                     float* o = tp + ((size_t)step * 4 + st) * 1536;
 #pragma unroll
@@ -1619,7 +1627,8 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                 f32x4v* eb = ex + buf * 384;
 #pragma unroll
                 for (int tau = 0; tau < 2; tau++) eb[(n * 2 + tau) * 64 + lane] = Xnext.t[tau];
-                __syncthreads();
+                // (a bare barrier behind the LDS writes: __syncthreads() would also drain vmcnt, i.e. wait for this stage's tape stores)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
                 for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -1632,6 +1641,431 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                     *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save + iv + 1) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// discrete adjoint of ONE 16-column tile by THREE wavefronts (the companion of rt16s_forward_kernel at the latency points).
+//
+// Wave n back-propagates flux net n: from the taped hidden pre-activations (no forward recomputation) through the three transposed
+// chains W3^T, W2^T, W1^T (114 dependent 16x16x4 MFMAs instead of 342 in a row).  The physics pullback couples the three variables
+// through the Richardson number and is cheap beside the chains, so every wave evaluates it in full — the three copies of λ, x̄ and
+// the stage cotangent are bit-identical by construction (same operations, same order).  What a wave alone knows is its net's part of
+// the state cotangent, W1_n^T δz1_n (96 rows): the three parts go through a double-buffered LDS exchange (one barrier per stage) and
+// are summed in net order by everybody.
+//
+// The weight gradients are not accumulated here: the kernel writes tile16's delta-tape records
+//   [tile][step][stage][column][ x (96) | a of net 0..2 (104 each: a1 at 0, a2 at 52) | δz of net 0..2 (104 each: δz1 at 0, δz2 at 52, δz3 at 72) ]
+// and tile16's split-K dW GEMM contracts them (dw_gemm_lds_kernel) — no transposition, no accumulator registers, no flush code here.
+// Bias gradients (column sums of the deltas) and the loss sums go to the tile's slab row, as in tile16's taped adjoint.
+// ------------------------------------------------------------------------------------------------
+#define RT16S_REC (16 * 720)       // floats per delta-tape record: 16 columns x (96 + 2 x 3 x 104)
+#define RT16S_ZREC (16 * 216)      // floats per pre-activation tape record: 16 columns x 3 nets x 72
+#define RT16S_STG (16 * 180)       // floats of one wave's record staging area in LDS
+
+// NC independent chains of N k-steps advanced together, k-major (consecutive MFMAs belong to different accumulators: no dependent-issue
+// bubble), their A operands fetched as one group — early enough, by the caller, that the LDS latency is covered by other work
+template <int NC, int N, class AF>
+__device__ __forceinline__ void rt16_fetch_ops(const float* wl, float (&a)[NC][N], AF aidx) {
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int k = 0; k < N; k++) a[c][k] = wl[aidx(c, k)];
+}
+template <int NC, int N, class BF>
+__device__ __forceinline__ void rt16_run_ops(const float (&a)[NC][N], f32x4t (&acc)[NC], BF bval) {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] = mfma16t(a[c][k], bval(k), acc[c]);
+}
+
+__device__ __forceinline__ void rt16_physics_vjp(const DevModel& m, const V16 (&X)[3], V16 (&kd)[3], int lane, V16 (&xb)[3]) {
+    const float Nz = 32.0f;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            xb[0].t[tau][r] = -m.cor_v * m.sig_u * kd[1].t[tau][r];
+            xb[1].t[tau][r] = m.cor_u * m.sig_v * kd[0].t[tau][r];
+            xb[2].t[tau][r] = 0.0f;
+        }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const V16 dn = shift_down16(kd[k], lane, 0.0f);
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                kd[k].t[tau][r] = (tau == 0 && r == 0 && g == 0) ? 0.0f : m.A[k] * (kd[k].t[tau][r] - dn.t[tau][r]);
+    }
+    if (!m.mpp && !m.ca) return;
+    V16 gb[3];
+    if (m.mpp) {
+        const V16 Ud = shift_down16(X[0], lane, 0.0f), Vd = shift_down16(X[1], lane, 0.0f), Td = shift_down16(X[2], lane, 0.0f);
+        // the arithmetic of rt_physics_vjp, uniform factors folded
+        const float cU = m.sig_u * Nz, sU = m.sig_u * m.eps, cV = m.sig_v * Nz, sV = m.sig_v * m.eps, cB = m.B * Nz, sB = m.B * m.eps;
+        const float L2E = 1.4426950408889634f;
+        const float kE = 2.0f * m.inv_dRi * L2E, oE = -2.0f * m.Ric * m.inv_dRi * L2E, cE = 30.0f * L2E;
+        const float nA = -0.5f * m.nu_minus, nB = m.nu0 + 0.5f * m.nu_minus;
+        const float m0 = -m.cs[0], m1 = -m.cs[1], m2 = -m.cs[2] * m.inv_Pr;
+        const float n0 = m0 * Nz * m.c_rib, n1 = m1 * Nz * m.c_rib, n2 = m2 * Nz * m.c_rib;
+        const float q0 = -2.0f * m.sig_u, q1 = -2.0f * m.sig_v;
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool in = !(tau == 0 && r == 0 && g == 0);
+                const float dU = X[0].t[tau][r] - Ud.t[tau][r], dV = X[1].t[tau][r] - Vd.t[tau][r], dT = X[2].t[tau][r] - Td.t[tau][r];
+                const float a1 = fmaf(dU, cU, sU), a2 = fmaf(dV, cV, sV);
+                const float rS = __builtin_amdgcn_rcpf(fmaf(a2, a2, a1 * a1));
+                const float Ri = fmaf(dT, cB, sB) * rS;
+                const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(fmaf(Ri, kE, oE), -cE, cE));
+                const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+                const float nu = fmaf(th, nA, nB);
+                const float k0 = kd[0].t[tau][r], k1 = kd[1].t[tau][r], k2 = kd[2].t[tau][r];
+                const float t0 = k0 * nu, t1 = k1 * nu, t2 = k2 * nu;
+                float nub = (k0 * dU) * n0;
+                nub = fmaf(k1 * dV, n1, nub);
+                nub = fmaf(k2 * dT, n2, nub);
+                const float w = nub * (fmaf(-th, th, 1.0f) * rS);
+                const float qq = w * Ri;
+                const float g2 = fmaf(w, m.B, t2 * m2);
+                const float g0 = fmaf(qq, a1 * q0, t0 * m0);
+                const float g1 = fmaf(qq, a2 * q1, t1 * m1);
+                gb[0].t[tau][r] = in ? g0 : 0.0f;
+                gb[1].t[tau][r] = in ? g1 : 0.0f;
+                gb[2].t[tau][r] = in ? g2 : 0.0f;
+            }
+    } else {
+        const V16 Td = shift_down16(X[2], lane, 0.0f);
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool in = !(tau == 0 && r == 0 && g == 0);
+                const float gT = (X[2].t[tau][r] - Td.t[tau][r]) * Nz;
+                gb[0].t[tau][r] = 0.0f;
+                gb[1].t[tau][r] = 0.0f;
+                gb[2].t[tau][r] = (in && gT < 0.0f) ? -kd[2].t[tau][r] * m.cs[2] * m.kappa : 0.0f;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const V16 gu_ = shift_up16(gb[k], lane, 0.0f);
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) xb[k].t[tau][r] += (gb[k].t[tau][r] - gu_.t[tau][r]) * Nz;
+    }
+}
+
+// value and derivative of the activation on a four-element tile
+template <int ACT>
+__device__ __forceinline__ void rt16_act_pair(const f32x4t z, f32x4t& a, f32x4t& d) {
+    const f32x2v z0 = {z[0], z[1]}, z1 = {z[2], z[3]};
+    f32x2v a0, d0, a1, d1;
+    rt_act_pair4<ACT>(z0, z1, a0, d0, a1, d1);
+    a = (f32x4t){a0.x, a0.y, a1.x, a1.y};
+    d = (f32x4t){d0.x, d0.y, d1.x, d1.y};
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(192)
+rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ save_times, int n_save, int substeps,
+                     const float* __restrict__ sol, const float* __restrict__ truth, const float* __restrict__ t16_tape,
+                     const float* __restrict__ t16_ztape, LossWeights lw, float* __restrict__ slab, int n_col,
+                     float* __restrict__ dwtape) {
+    float* wl = rt_smem;
+    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += 192) wl[e] = wimg[e];
+    f32x4v* ex = reinterpret_cast<f32x4v*>(rt_smem + ((RT_IMG_FLOATS + 3) & ~3));          // [2 buffers][3 nets][6 tiles][64 lanes]
+    // staging of each wave's part of the delta-tape record: [16 columns][a1 52 | a2 20 | δz1 52 | δz2 20 | δz3 32] with row stride 180
+    // (conflict-free for the element-wise writes, 16-byte aligned for the float4 read-back); the pad slots stay zero
+    float* stg_all = rt_smem + ((RT_IMG_FLOATS + 3) & ~3) + 2 * (3 * 6 * 64) * 4;
+    for (int e = threadIdx.x; e < 3 * RT16S_STG; e += 192) stg_all[e] = 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int n = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                        // this wave's net
+    float* stg = stg_all + n * RT16S_STG;
+    const int j = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x;
+    const int col = tile * 16 + j;
+    const bool valid = col < n_col;
+    const int colc = min(col, n_col - 1);
+    const int i_ = lane & 15, g_i = i_ >> 2, r_i = i_ & 3;
+    // A-operand bases of the transposed products (output row i_ of a tile, k-lane g): W3^T (rows = a2 features), W2^T (rows = a1 features),
+    // W1^T (rows = state features); rows that are padding read the image's zero column
+    int b3T[2], b2T[4];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int Q2 = 4 * u + r_i;
+        b3T[u] = RT_W3C + (n * 31 + 4 * g - 1) * RT_LD3 + (Q2 < 5 ? 4 * Q2 + g_i : 20);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int Q = 4 * t + r_i, f = 4 * Q + g_i;
+        b2T[t] = RT_W2C + (n * 20 + g) * RT_LD2 + ((Q < 13 && f < 50) ? f : 50);
+    }
+    const int b1T = RT_W1C + (n * 50 + g) * RT_LD1 + i_;
+
+    V16 lam[3], xb[3], xbs[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++) { lam[q].t[tau] = (f32x4t)(0.0f); xb[q].t[tau] = (f32x4t)(0.0f); xbs[q].t[tau] = (f32x4t)(0.0f); }
+    f32x4t gb1[4], gb2[2], gb3[2];                         // bias gradients: this lane's column of every delta, summed over the stages
+#pragma unroll
+    for (int t = 0; t < 4; t++) gb1[t] = (f32x4t)(0.0f);
+#pragma unroll
+    for (int u = 0; u < 2; u++) { gb2[u] = (f32x4t)(0.0f); gb3[u] = (f32x4t)(0.0f); }
+    float sum_d = 0.0f, sum_g = 0.0f;                      // loss sums of variable n (profile and gradient terms)
+    RT_STAMP_DECL;
+
+    const int n_steps = (n_save - 1) * substeps;
+    const float* tp = t16_tape + (size_t)tile * n_steps * 4 * 1536 + j * 96 + 4 * g;
+    const float* tz = t16_ztape + (size_t)tile * n_steps * 4 * RT16S_ZREC + j * 216 + n * 72 + g;
+    float* rec0 = dwtape + (size_t)tile * n_steps * 4 * RT16S_REC;
+    // the record's 11 float4 pieces this lane copies from the staging area each stage: piece e = 64 i + lane = column e / 44, float4 e % 44
+    // of that column's 72 a-floats and 104 δ-floats
+    int stg_rd[11], rec_wr[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+        const int e = 64 * i + lane, c = e / 44, f4 = e - 44 * c;
+        stg_rd[i] = c * 180 + 4 * f4;
+        rec_wr[i] = c * 720 + 96 + (f4 < 18 ? n * 104 + 4 * f4 : (3 + n) * 104 + 4 * (f4 - 18));
+    }
+    float* sw = stg + j * 180 + g;                          // element-wise staging writes of this lane: feature 4 Q + g of column j
+
+    // loss injection at save point sv: λ += ∂loss/∂sol[:, sv] (all three variables, every wave); the sums of squares of variable n only
+    auto inject = [&](int sv, bool add) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            V16 d;
+#pragma unroll
+            for (int tau = 0; tau < 2; tau++) {
+                const size_t o = ((size_t)colc * n_save + sv) * 96 + q * 32 + 16 * tau + 4 * g;
+                const f32x4v a = *reinterpret_cast<const f32x4v*>(sol + o);
+                const f32x4v b = *reinterpret_cast<const f32x4v*>(truth + o);
+#pragma unroll
+                for (int e = 0; e < 4; e++) d.t[tau][e] = valid ? a[e] - b[e] : 0.0f;
+            }
+            const V16 dd = shift_down16(d, lane, 0.0f);
+            V16 gg;
+            float sd = 0.0f, sg = 0.0f;
+#pragma unroll
+            for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    gg.t[tau][r] = (tau == 0 && r == 0 && g == 0) ? 0.0f : (d.t[tau][r] - dd.t[tau][r]) * 32.0f;
+                    sd += d.t[tau][r] * d.t[tau][r];
+                    sg += gg.t[tau][r] * gg.t[tau][r];
+                }
+            if (q == n) { sum_d += sd; sum_g += sg; }
+            if (add) {
+                const V16 gu_ = shift_up16(gg, lane, 0.0f);
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        lam[q].t[tau][r] += 2.0f * lw.w[q] * d.t[tau][r] + 2.0f * lw.w[3 + q] * 32.0f * (gg.t[tau][r] - gu_.t[tau][r]);
+            }
+        }
+    };
+    inject(0, false);
+
+    // stage inputs and hidden pre-activations, fetched one stage ahead of their use
+    V16 Xp[3];
+    float z1p[13], z2p[5];
+    auto prefetch = [&](int qs) {
+        const float* sx = tp + (size_t)qs * 1536;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int tau = 0; tau < 2; tau++) Xp[q].t[tau] = *reinterpret_cast<const f32x4v*>(sx + q * 32 + 16 * tau);
+        const float* sz = tz + (size_t)qs * RT16S_ZREC;
+#pragma unroll
+        for (int Q = 0; Q < 13; Q++) z1p[Q] = (Q < 12 || g < 2) ? sz[4 * Q] : 0.0f;
+#pragma unroll
+        for (int Q2 = 0; Q2 < 5; Q2++) z2p[Q2] = sz[52 + 4 * Q2];
+    };
+    prefetch(n_steps * 4 - 1);
+    int buf = 0;
+
+    for (int iv = n_save - 2; iv >= 0; iv--) {
+        const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
+        inject(iv + 1, true);
+        for (int s = substeps - 1; s >= 0; s--) {
+            const int step = iv * substeps + s;
+#pragma nounroll
+            for (int st = 3; st >= 0; st--) {
+                const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
+                const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
+                const int qs = step * 4 + st;
+                RT_STAMP_BEGIN();
+                V16 X[3];
+                f32x4t Z1[4], Z2[2];
+#pragma unroll
+                for (int q = 0; q < 3; q++) X[q] = Xp[q];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Z1[t][r] = (4 * t + r < 13) ? z1p[(4 * t + r) < 13 ? 4 * t + r : 0] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Z2[u][r] = (4 * u + r < 5) ? z2p[(4 * u + r) < 5 ? 4 * u + r : 0] : 0.0f;
+                if (qs > 0) prefetch(qs - 1);
+                // (1) stage cotangent k̄ = cwl λ + cwx x̄ (x̄: the state cotangent of the stage handled before), then the physics pullback
+                V16 kb[3], xbp[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) kb[q].t[tau] = cwl * lam[q].t[tau] + cwx * xb[q].t[tau];
+                rt16_physics_vjp(m, X, kb, lane, xbp);                                   // kb now holds dO
+                RT_STAMP(0);
+                V16 dO;                 // (element-wise selects on the wave-uniform n: a select between the aggregates becomes a scratch array)
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dO.t[tau][r] = n == 0 ? kb[0].t[tau][r] : (n == 1 ? kb[1].t[tau][r] : kb[2].t[tau][r]);
+                // operands of the W3^T and W2^T products (fetched here: the activations below cover their LDS latency)
+                float a3[2][8], a2[4][5];
+                rt16_fetch_ops<2, 8>(wl, a3, [&](int u, int k) { return b3T[u] + (16 * (k >> 2) + (k & 3)) * RT_LD3; });
+                rt16_fetch_ops<4, 5>(wl, a2, [&](int t, int k) { return b2T[t] + 4 * k * RT_LD2; });
+                RT_SCHED_HARD();
+                // (2) activations and their derivatives from the taped pre-activations
+                f32x4t A1[4], D1[4], A2[2], D2[2];
+#pragma unroll
+                for (int t = 0; t < 4; t++) rt16_act_pair<ACT>(Z1[t], A1[t], D1[t]);
+#pragma unroll
+                for (int u = 0; u < 2; u++) rt16_act_pair<ACT>(Z2[u], A2[u], D2[u]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (r > 0) { D1[3][r] = 0.0f; D2[1][r] = 0.0f; }                 // padding quads: Q >= 13, Q2 >= 5
+                }
+                if (g >= 2) D1[3][0] = 0.0f;                                             // features 50, 51 of quad 12
+                float* rec = rec0 + (size_t)qs * RT16S_REC;
+                {
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) {
+                        f32x4v xv;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) xv[r] = n == 0 ? X[0].t[tau][r] : (n == 1 ? X[1].t[tau][r] : X[2].t[tau][r]);
+                        *reinterpret_cast<f32x4v*>(rec + j * 720 + n * 32 + 16 * tau + 4 * g) = xv;
+                    }
+#pragma unroll
+                    for (int Q = 0; Q < 13; Q++)
+                        if (Q < 12 || g < 2) sw[4 * Q] = A1[Q >> 2][Q & 3];
+#pragma unroll
+                    for (int Q2 = 0; Q2 < 5; Q2++) sw[52 + 4 * Q2] = A2[Q2 >> 2][Q2 & 3];
+                }
+                RT_STAMP(1);
+                // (3) δz2 = (W3^T dO) ∘ act'(z2): 8 k-steps = the faces (v, r), lane g holding face 16 v + 4 g + r
+                f32x4t dZ2[2] = {(f32x4t)(0.0f), (f32x4t)(0.0f)};
+                rt16_run_ops<2, 8>(a3, dZ2, [&](int k) { return dO.t[k >> 2][k & 3]; });
+#pragma unroll
+                for (int u = 0; u < 2; u++) dZ2[u] *= D2[u];
+                // operands of the first two W1^T tiles, in flight under the W2^T products
+                float a1[2][2][13];
+                rt16_fetch_ops<2, 13>(wl, a1[0], [&](int c, int k) { return b1T + 16 * c + 4 * k * RT_LD1; });
+                RT_SCHED_HARD();
+                // (4) δz1 = (W2^T δz2) ∘ act'(z1): 5 k-steps = the quads of a2
+                f32x4t dZ1[4] = {(f32x4t)(0.0f), (f32x4t)(0.0f), (f32x4t)(0.0f), (f32x4t)(0.0f)};
+                rt16_run_ops<4, 5>(a2, dZ1, [&](int k) { return dZ2[k >> 2][k & 3]; });
+#pragma unroll
+                for (int t = 0; t < 4; t++) dZ1[t] *= D1[t];
+                RT_STAMP(2);
+                {
+#pragma unroll
+                    for (int Q = 0; Q < 13; Q++)
+                        if (Q < 12 || g < 2) sw[72 + 4 * Q] = dZ1[Q >> 2][Q & 3];
+#pragma unroll
+                    for (int Q2 = 0; Q2 < 5; Q2++) sw[124 + 4 * Q2] = dZ2[Q2 >> 2][Q2 & 3];
+                    float* s3 = stg + j * 180 + 144 + 4 * g - 1;                         // output o = face - 1
+#pragma unroll
+                    for (int v = 0; v < 2; v++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (!(v == 0 && r == 0 && g == 0)) s3[16 * v + r] = dO.t[v][r];
+                    // the wave's 16 x 176 floats leave as 11 float4 stores per lane (the element-wise form costs 52 scattered dword stores)
+#pragma unroll
+                    for (int i = 0; i < 11; i++) *reinterpret_cast<f32x4v*>(rec + rec_wr[i]) = *reinterpret_cast<const f32x4v*>(stg + stg_rd[i]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) gb1[t] += dZ1[t];
+#pragma unroll
+                for (int u = 0; u < 2; u++) { gb2[u] += dZ2[u]; gb3[u] += dO.t[u]; }
+                RT_STAMP(3);
+                // (5) this net's part of the state cotangent, W1_n^T δz1 (6 tiles x 13 k-steps), exchanged and summed in net order
+                f32x4v* eb = ex + buf * (3 * 6 * 64);
+#pragma unroll
+                for (int q = 0; q < 3; q++) {                                            // variable q: its two 16-level tiles together
+                    if (q < 2) rt16_fetch_ops<2, 13>(wl, a1[(q + 1) & 1], [&](int c, int k) { return b1T + 32 * (q + 1) + 16 * c + 4 * k * RT_LD1; });
+                    RT_SCHED_HARD();
+                    f32x4t c2[2] = {(f32x4t)(0.0f), (f32x4t)(0.0f)};
+                    rt16_run_ops<2, 13>(a1[q & 1], c2, [&](int k) { return dZ1[k >> 2][k & 3]; });
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) eb[(n * 6 + q * 2 + tau) * 64 + lane] = c2[tau];
+                    RT_SCHED_HARD();
+                }
+                RT_STAMP(4);
+                // (a bare barrier behind the LDS writes: __syncthreads() would also drain vmcnt — this stage's tape stores and the next
+                //  stage's prefetch)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) {
+                        const f32x4v c0 = eb[(0 * 6 + q * 2 + tau) * 64 + lane], c1 = eb[(1 * 6 + q * 2 + tau) * 64 + lane],
+                                     c2 = eb[(2 * 6 + q * 2 + tau) * 64 + lane];
+                        xb[q].t[tau] = xbp[q].t[tau] + ((c0 + c1) + c2);
+                        xbs[q].t[tau] += xb[q].t[tau];
+                    }
+                buf ^= 1;
+                RT_STAMP(5);
+            }
+            // λ_n = λ_{n+1} + x̄_1 + x̄_2 + x̄_3 + x̄_4
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) { lam[q].t[tau] += xbs[q].t[tau]; xbs[q].t[tau] = (f32x4t)(0.0f); }
+        }
+    }
+
+#ifndef COLNDE_STAMPS_FWD
+    RT_STAMP_FLUSH();
+#endif
+    // ---- the tile's slab row: bias gradients of net n (sums over the 16 columns = the lanes of a g-group) and the loss sums ----
+    float* out = slab + (size_t)tile * (m.n_params + 8);
+    auto colsum = [&](float v) {
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        return v;
+    };
+#pragma unroll
+    for (int Q = 0; Q < 13; Q++) {
+        const float v = colsum(gb1[Q >> 2][Q & 3]);
+        if (j == 0 && (Q < 12 || g < 2)) out[n * m.net_size + m.b_off[0] + 4 * Q + g] = v;
+    }
+#pragma unroll
+    for (int Q2 = 0; Q2 < 5; Q2++) {
+        const float v = colsum(gb2[Q2 >> 2][Q2 & 3]);
+        if (j == 0) out[n * m.net_size + m.b_off[1] + 4 * Q2 + g] = v;
+    }
+#pragma unroll
+    for (int v_ = 0; v_ < 2; v_++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = colsum(gb3[v_][r]);
+            const int face = 16 * v_ + 4 * g + r;
+            if (j == 0 && face >= 1) out[n * m.net_size + m.b_off[2] + face - 1] = v;
+        }
+    float sd = sum_d, sg = sum_g;
+    for (int off = 32; off > 0; off >>= 1) { sd += __shfl_down(sd, off); sg += __shfl_down(sg, off); }
+    if (lane == 0) {
+        out[m.n_params + n] = sd;
+        out[m.n_params + 3 + n] = sg;
+        if (n == 0) { out[m.n_params + 6] = 0.0f; out[m.n_params + 7] = 0.0f; }
     }
 }
 
@@ -1679,6 +2113,12 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_TANH>);
     RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU>);
     RT_SETATTR(rt_dw1_kernel);
+    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY>);
+    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_RELU>);
+    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_MISH>);
+    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_SWISH>);
+    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_TANH>);
+    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU>);
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -1762,6 +2202,28 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
         default: return hipErrorInvalidValue;
     }
 #undef RT_FWDS
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
+                                   const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
+                                   int n_col, float* dwtape, hipStream_t stream) {
+    // the record formats this kernel reads and writes are tile16's for exactly this shape
+    if (!rt_supported(m) || dwtape_row_floats(m) * CT != RT16S_REC || t16_ztape_col_floats(m) * CT != RT16S_ZREC || m.nst != 4)
+        return hipErrorInvalidValue;
+    const size_t lds = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + 2 * (3 * 6 * 64) * 16 + 3 * RT16S_STG * sizeof(float);
+    const dim3 grid((n_col + 15) / 16), block(192);
+#define RT_ADJS(A) hipLaunchKernelGGL(rt16s_adjoint_kernel<A>, grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape)
+    switch (m.acts[0]) {
+        case COLNDE_ACT_IDENTITY: RT_ADJS(COLNDE_ACT_IDENTITY); break;
+        case COLNDE_ACT_RELU: RT_ADJS(COLNDE_ACT_RELU); break;
+        case COLNDE_ACT_MISH: RT_ADJS(COLNDE_ACT_MISH); break;
+        case COLNDE_ACT_SWISH: RT_ADJS(COLNDE_ACT_SWISH); break;
+        case COLNDE_ACT_TANH: RT_ADJS(COLNDE_ACT_TANH); break;
+        case COLNDE_ACT_LEAKYRELU: RT_ADJS(COLNDE_ACT_LEAKYRELU); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RT_ADJS
     return hipGetLastError();
 }
 

@@ -24,7 +24,11 @@ for _ in range(12 if ncol >= 16384 else 1):        # back-to-back launches, so t
     nde.loss_grad(p.weights, [0, 0, 1, 0, 0, 0] if FC64 else [1, 1, 1, 5e-3, 5e-3, 5e-3])
 buf = (ctypes.c_ulonglong * 16)()
 _lib.check(L.colnde_debug_stamps(nde._h, buf))
-if nde.engine == 2 and FWD:
+SPLIT = nde.engine == 1 and not FC64 and os.environ.get("COLNDE_T16_FWD_SPLIT", "1") != "0" and os.environ.get("COLNDE_T16_ADJ_SPLIT", "1") != "0"
+if SPLIT:        # net-split kernels of the latency points (wave 0 = net 0)
+    names = ["prefetch issue + kbar + physics pullback", "activation pairs + x / a stores", "W3^T and W2^T chains", "delta stores + bias sums",
+             "W1^T chains + exchange write", "barrier + sum of the three parts"]
+elif nde.engine == 2 and FWD:
     names = ["X tape store + top flux", "layer 1 (10 chains, Z1 tape store, activation)", "layers 2, 3", "physics", "RK4 update"]
 elif nde.engine == 2:
     names = ["kbar + physics pullback + dO park", "dO reload + L1 chains (3 nets)", "X prefetch + L2 chain", "dW3 + W3^T + dZ2",
@@ -39,7 +43,7 @@ print("total %.0f cycles/stage" % (v.sum() / nstage))
 if FWD:
     print("whole kernel (workgroup 0, wave 0): %d s_memtime ticks in %.3f ms (s_memrealtime, 100 MHz) -> %.3f ticks/ns; stage loop share %.1f %%"
           % (buf[6], buf[7] / 1e5, buf[6] / (buf[7] * 10.0), 100.0 * v.sum() / buf[6]))
-if nde.engine == 2:
+if nde.engine == 2 or SPLIT:
     # clock the stamped kernel ran at (MI355X_MICROARCH 'DVFS give-back' item 6); meaningful on launches of >= 10 ms (pass e.g. 32768 289)
     if buf[9]:
         print("whole kernel (workgroup 0, wave 0): %d shader ticks in %.3f ms of the 100 MHz reference -> in-kernel clock %.3f GHz"
