@@ -1169,6 +1169,7 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
         info[2] = h->t16_dwtape == 1 ? h->t16_nblocks : 0;
         info[4] = h->t16_dwtape == 1 ? 1 : 0;
         info[5] = h->t16_dwtape == 1 ? h->dw_slices : 0;
+        info[6] = (h->fwd_split ? 1 : 0) | ((h->adj_split && h->t16_dwtape == 1 && h->d_t16_ztape) ? 2 : 0);
     }
     return 0;
 }

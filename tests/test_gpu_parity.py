@@ -363,6 +363,61 @@ def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
     assert _rel(grad_g, g) < GRAD_REL
 
 
+# ---- the net-split kernels of the latency points (engine AUTO below 4,096 columns of the regtile shape) -----------------
+@pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "diurnal", "conv_adj_branch", "swish", "raw", "dRi_small", "relu",
+                                  "tanh", "leakyrelu"])
+def test_split_kernels_against_oracle_and_tile16(name, monkeypatch):
+    """rt16s_forward_kernel + rt16s_adjoint_kernel (three wavefronts per 16-column tile, one per flux net) on 40 columns (two
+    full tiles and a ragged one): against the float64 oracle at the usual tolerances, against pure tile16 (the same tapes and
+    dW GEMM behind a different adjoint kernel) an order tighter, and bit-identical from one call to the next."""
+    p = synthetic.wind_mixing_problem(40, n_frames=9, weight_divisor=1e2, **VARIANTS[name])
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_s = nde.forward(p.weights)
+        tot_s, terms_s, grad_s = nde.loss_grad(p.weights, sc)
+        tot_2, terms_2, grad_2 = nde.loss_grad(p.weights, sc)
+        plan = nde.plan()
+    assert plan["split_forward"] and plan["split_adjoint"] and plan["dw_taped"]
+    monkeypatch.setenv("COLNDE_T16_FWD_SPLIT", "0")
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_t = nde.forward(p.weights)
+        tot_t, terms_t, grad_t = nde.loss_grad(p.weights, sc)
+        plan_t = nde.plan()
+    assert not plan_t["split_forward"] and not plan_t["split_adjoint"]
+    _record("test_split_kernels/" + str(name), sol_abs=np.abs(sol_s - sol).max(), loss_rel=abs(tot_s - tot) / abs(tot), grad_rel=_rel(grad_s, g),
+            grad_rel_vs_tile16=_rel(grad_s, grad_t.astype(np.float64)), sol_abs_vs_tile16=np.abs(sol_s - sol_t).max())
+    assert np.abs(sol_s - sol).max() < SOL_ATOL
+    # (a term four orders below the total — the temperature terms of the convective-adjustment variant — is float32 cancellation:
+    #  it gets the absolute slack of 1e-3 of the total's tolerance)
+    np.testing.assert_allclose(terms_s, terms, rtol=LOSS_RTOL, atol=1e-3 * LOSS_RTOL * float(np.sum(terms)))
+    assert np.isclose(tot_s, tot, rtol=LOSS_RTOL)
+    assert _rel(grad_s, g) < GRAD_REL
+    assert np.array_equal(grad_s, grad_2) and tot_s == tot_2
+    assert np.abs(sol_s - sol_t).max() < 0.25 * SOL_ATOL
+    assert _rel(grad_s, grad_t.astype(np.float64)) < 0.25 * GRAD_REL
+
+
+def test_split_adjoint_behind_tile16_forward(monkeypatch):
+    """COLNDE_T16_ADJ_SPLIT=0 keeps tile16's adjoint behind the split forward (the round-2 intermediate); both gradient paths read
+    the same tapes, so they agree far inside the oracle tolerance."""
+    p = synthetic.wind_mixing_problem(24, n_frames=9, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    grads = []
+    for adj in ("1", "0"):
+        monkeypatch.setenv("COLNDE_T16_ADJ_SPLIT", adj)
+        with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+            nde.set_problem(p.x0, p.bcs, truth)
+            grads.append(nde.loss_grad(p.weights, sc))
+            assert nde.plan()["split_forward"] and nde.plan()["split_adjoint"] == (adj == "1")
+    assert np.isclose(grads[0][0], grads[1][0], rtol=1e-6)
+    assert _rel(grads[0][2], grads[1][2].astype(np.float64)) < 0.25 * GRAD_REL
+
+
 # ---- edge cases: ragged/minimal shapes, non-uniform time axis, odd sub-step counts, both engines ---------------------
 @pytest.mark.parametrize("engine", [1, 2])
 @pytest.mark.parametrize("n_col", [1, 31, 33])
