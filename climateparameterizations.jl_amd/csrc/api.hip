@@ -375,14 +375,16 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         if (e == hipSuccess) e = rt_set_attributes();
         if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); }
     }
-    // AUTO: regtile where it applies, except for small problems (< 4,096 columns), which are latency points — one wavefront per
-    // SIMD at most — where tile16's eight cooperating waves per 16-column tile finish a gradient sooner (8 columns x 576 steps:
-    // 66 vs 83 ms per iteration)
+    // AUTO: regtile where it applies, except for problems of at most 8,192 columns (two rounds of one 16-column tile per CU).  Those
+    // are latency points for regtile — 32 columns per wavefront leave most SIMDs without a wave — and go to the net-split kernels
+    // (three wavefronts per 16-column tile, below) with tile16's tapes and dW GEMM: 4,096 columns x 64 steps 3.98 vs 9.72 ms per
+    // iteration, 8,192: 8.03 vs 10.07, 16,384: 15.0 vs 10.9 (tools/crossover.py)
     h->use_rt = rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine != COLNDE_ENGINE_GENERIC &&
-                (cfg->engine == COLNDE_ENGINE_MFMA || cfg->n_columns >= 4096 || !h->geo_ok);
+                (cfg->engine == COLNDE_ENGINE_MFMA || cfg->n_columns > 8192 || !h->geo_ok);
     h->rt_fwd32 = h->use_rt && rt_forward_is32();
-    // AUTO on a regtile-shaped problem too small for regtile (a latency point): tile16 takes the gradient, the three-wave split kernel the
-    // forward solves (8 simulations: 19.8 -> 10.6 ms).  An explicit engine = tile16 stays pure tile16; COLNDE_T16_FWD_SPLIT=0|1 overrides.
+    // AUTO on a regtile-shaped problem too small for regtile (a latency point): the three-wave net-split kernels take the forward solves and
+    // the adjoint (8 simulations: forward 19.8 -> 8.5 ms, adjoint 25.0 -> 14.6 ms), tile16 the tapes' formats, the dW GEMM and the reduction.
+    // An explicit engine = tile16 stays pure tile16; COLNDE_T16_FWD_SPLIT=0|1 and COLNDE_T16_ADJ_SPLIT=0 override.
     h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine == COLNDE_ENGINE_AUTO;
     {
         const char* es = getenv("COLNDE_T16_FWD_SPLIT");

@@ -32,7 +32,7 @@ enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_t
 enum { COLNDE_ACT_IDENTITY = 0, COLNDE_ACT_RELU = 1, COLNDE_ACT_MISH = 2, COLNDE_ACT_SWISH = 3,
        COLNDE_ACT_TANH = 4, COLNDE_ACT_LEAKYRELU = 5 };
 
-enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it is built for and there are >= 4,096 columns, else tile16 */
+enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it is built for and there are > 8,192 columns, else tile16 (with the net-split kernels where the shape is regtile's) */
        COLNDE_ENGINE_GENERIC = 1,   /* tile16: 16-column MFMA tiles staged through LDS, any layer sizes / model */
        COLNDE_ENGINE_MFMA = 2 };    /* regtile: 32 columns per wavefront resident in registers (static 96-50-20-31 wind-mixing
                                        shape; colnde_create fails if the configuration is not covered) */

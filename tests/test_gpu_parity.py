@@ -301,7 +301,7 @@ def test_engine_selection_and_cross_check():
     res = {}
     for eng in (ENGINE_TILE16, ENGINE_REGTILE, ENGINE_AUTO):
         with colnde.ColumnNDE(p.cfg, p.n_columns, engine=eng) as nde:
-            # AUTO sends small problems (< 4,096 columns: latency points) to tile16 and everything else regtile covers to regtile
+            # AUTO sends small problems (<= 8,192 columns: latency points) to tile16 and everything else regtile covers to regtile
             assert nde.engine == (ENGINE_REGTILE if eng == ENGINE_REGTILE else ENGINE_TILE16)
             nde.set_problem(p.x0, p.bcs)
             truth = nde.forward(p.weights_truth)
@@ -312,7 +312,9 @@ def test_engine_selection_and_cross_check():
     a, b = res[ENGINE_TILE16][1], res[ENGINE_REGTILE][1]
     assert np.isclose(a[0], b[0], rtol=1e-4)
     assert _rel(a[2], b[2].astype(np.float64)) < 1e-4
-    with colnde.ColumnNDE(p.cfg, 4096) as nde:
+    with colnde.ColumnNDE(p.cfg, 8192) as nde:
+        assert nde.engine == ENGINE_TILE16
+    with colnde.ColumnNDE(p.cfg, 8208) as nde:
         assert nde.engine == ENGINE_REGTILE
     # smoothing is outside the regtile engine's coverage: AUTO falls back, an explicit request fails loudly
     ps = synthetic.wind_mixing_problem(8, n_frames=3, smooth_NN=True)
@@ -363,7 +365,7 @@ def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
     assert _rel(grad_g, g) < GRAD_REL
 
 
-# ---- the net-split kernels of the latency points (engine AUTO below 4,096 columns of the regtile shape) -----------------
+# ---- the net-split kernels of the latency points (engine AUTO up to 8,192 columns of the regtile shape) -----------------
 @pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "diurnal", "conv_adj_branch", "swish", "raw", "dRi_small", "relu",
                                   "tanh", "leakyrelu"])
 def test_split_kernels_against_oracle_and_tile16(name, monkeypatch):
