@@ -403,6 +403,26 @@ def test_split_kernels_against_oracle_and_tile16(name, monkeypatch):
     assert _rel(grad_s, grad_t.astype(np.float64)) < 0.25 * GRAD_REL
 
 
+def test_split_kernels_column_blocked(monkeypatch):
+    """The column-blocked gradient path (tapes that hold one block: what a problem larger than the free HBM takes) through the net-split
+    kernels: 40 columns as blocks of 16 + 16 + 8 give the gradient of the unblocked run (same kernels, same reduction order per row)."""
+    p = synthetic.wind_mixing_problem(40, n_frames=9, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    res = []
+    for blk in (None, "16"):
+        if blk:
+            monkeypatch.setenv("COLNDE_T16_BLOCK", blk)
+        with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+            nde.set_problem(p.x0, p.bcs, truth)
+            res.append(nde.loss_grad(p.weights, sc))
+            plan = nde.plan()
+            assert plan["split_adjoint"] and plan["n_blocks"] == (3 if blk else 1)
+    assert _rel(res[1][2], g) < GRAD_REL and np.isclose(res[1][0], tot, rtol=LOSS_RTOL)
+    assert _rel(res[1][2], res[0][2].astype(np.float64)) < 1e-6
+
+
 def test_split_adjoint_behind_tile16_forward(monkeypatch):
     """COLNDE_T16_ADJ_SPLIT=0 keeps tile16's adjoint behind the split forward (the round-2 intermediate); both gradient paths read
     the same tapes, so they agree far inside the oracle tolerance."""
