@@ -53,6 +53,7 @@ struct colnde_handle {
     size_t lds_fwd = 0, lds_adj = 0, lds_fwd_solve = 0;
     int fwd_threads = 256;
     bool fwd_wlds = false;
+    bool split_rich = false;        // ... with the rich tape (activations, derivatives, physics coefficients) in place of the pre-activation tape
     bool adj_split = false;         // ... and the gradient by rt16s_adjoint_kernel + tile16's dW GEMM
     bool fwd_split = false;         // forward solves by rt16s_forward_kernel (three waves per tile) beside the tile16 adjoint
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
@@ -673,7 +674,7 @@ static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_
         if (es == hipSuccess)
             es = rt_launch_forward_split(h->m, h->d_wimg, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
                                          h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
-                                         with_tape ? h->d_tape : nullptr, with_tape ? h->d_t16_ztape : nullptr, nc, h->stream);
+                                         with_tape ? h->d_tape : nullptr, with_tape ? h->d_t16_ztape : nullptr, nc, with_tape && h->split_rich, h->stream);
         if (es != hipSuccess) return fail("split forward launch failed: %s", hipGetErrorString(es));
         return 0;
     }
@@ -854,6 +855,17 @@ static int t16_plan_dwtape(colnde_handle* h) {
         }
     }
     const char* ezt = getenv("COLNDE_T16_ZTAPE");
+    // net-split kernels on a small block (<= 2,048 columns: tape bytes cost nothing there): the rich tape in place of the pre-activations
+    {
+        const char* er = getenv("COLNDE_T16_SPLIT_RICH");
+        const bool want_rich = h->adj_split && !(ezt && atoi(ezt) == 0) && (er ? atoi(er) != 0 : tiles_b <= 128);
+        if (want_rich && hipMalloc((void**)&h->d_t16_ztape, n_rec * rt_split_rich_record_floats() * sizeof(float)) == hipSuccess) {
+            h->split_rich = true;
+            return 0;
+        }
+        (void)hipGetLastError();
+        h->d_t16_ztape = nullptr;
+    }
     if (!(ezt && atoi(ezt) == 0) && hipMalloc((void**)&h->d_t16_ztape, n_rec * CT * t16_ztape_col_floats(m) * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         h->d_t16_ztape = nullptr;
@@ -933,7 +945,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                     // the companion of the split forward: three wavefronts per tile, one per flux net, writing tile16's delta tape
                     e = rt_launch_adjoint_split(h->m, h->d_wimg, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                                 h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
-                                                h->d_t16_ztape, lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, h->d_dwtape, h->stream);
+                                                h->d_t16_ztape, lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, h->d_dwtape, h->split_rich, h->stream);
                 else
                 e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
                                               h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
@@ -1171,7 +1183,7 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
         info[2] = h->t16_dwtape == 1 ? h->t16_nblocks : 0;
         info[4] = h->t16_dwtape == 1 ? 1 : 0;
         info[5] = h->t16_dwtape == 1 ? h->dw_slices : 0;
-        info[6] = (h->fwd_split ? 1 : 0) | ((h->adj_split && h->t16_dwtape == 1 && h->d_t16_ztape) ? 2 : 0);
+        info[6] = (h->fwd_split ? 1 : 0) | ((h->adj_split && h->t16_dwtape == 1 && h->d_t16_ztape) ? 2 : 0) | (h->split_rich ? 4 : 0);
     }
     return 0;
 }

@@ -28,10 +28,11 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
                              const float* save_times, int n_save, int substeps, float* sol, float* tape, float* tapez,
                              int n_col, bool fwd32, hipStream_t stream);
 hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const float* x0, const float* bcs, const float* save_times,
-                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, hipStream_t stream);
+                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, hipStream_t stream);
+size_t rt_split_rich_record_floats();   // floats per (tile, step, stage) of the net-split kernels' rich tape (which then takes the place of t16_ztape)
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
-                                   int n_col, float* dwtape, hipStream_t stream);
+                                   int n_col, float* dwtape, bool rich, hipStream_t stream);
 bool rt_forward_is32();   // COLNDE_RT_FWD=32 in the environment (read when a handle is created)
 size_t rt_adjoint_lds_bytes();
 size_t rt_tape_floats(int n_col, int n_steps);

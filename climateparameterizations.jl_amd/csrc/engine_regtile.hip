@@ -1414,7 +1414,23 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
 // arithmetic, layouts and chains as rt16_forward_kernel.  The tapes are written in tile16's formats, because at these sizes the gradient
 // is taken by tile16's taped adjoint: stage inputs [tile][step][stage][column][3 Nz], hidden pre-activations [tile][step][stage][column][net][72].
 // ------------------------------------------------------------------------------------------------
+// value and derivative of the activation on a four-element tile
 template <int ACT>
+__device__ __forceinline__ void rt16_act_pair(const f32x4t z, f32x4t& a, f32x4t& d) {
+    const f32x2v z0 = {z[0], z[1]}, z1 = {z[2], z[3]};
+    f32x2v a0, d0, a1, d1;
+    rt_act_pair4<ACT>(z0, z1, a0, d0, a1, d1);
+    a = (f32x4t){a0.x, a0.y, a1.x, a1.y};
+    d = (f32x4t){d0.x, d0.y, d1.x, d1.y};
+}
+
+// RICH (small problems, where tape bytes cost nothing): instead of the hidden pre-activations in tile16's format, the forward kernel tapes what the
+// net-split adjoint would otherwise recompute on its critical path, as register images (1-KB coalesced stores):
+//   [tile][step][stage][ net 0..2: a1 (4 tiles) | act'(z1) (4) | a2 (2) | act'(z2) (2) ][ physics pullback coefficients dn_k, nu_k, c_k (k = 0..2) x 2 tiles ][64 lanes][4]
+// — the activation derivatives with the padding slots already zeroed, and the nine per-level coefficients of rt16_physics_apply (everything in the
+// Richardson-number closure that depends on the stage input alone: all the transcendental work of the pullback).
+#define RT16S_RREC ((3 * 12 + 18) * 256)    // floats per rich tape record
+template <int ACT, bool RICH>
 __global__ void __launch_bounds__(192)
 rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
                      const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
@@ -1468,7 +1484,8 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
         for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
     const int n_steps = (n_save - 1) * substeps;
     float* tp = t16_tape ? t16_tape + (size_t)tile * n_steps * 4 * 1536 + j * 96 + n * 32 + 4 * g : nullptr;
-    float* tz = t16_ztape ? t16_ztape + (size_t)tile * n_steps * 4 * (16 * 216) + j * 216 + n * 72 + g : nullptr;
+    float* tz = (t16_ztape && !RICH) ? t16_ztape + (size_t)tile * n_steps * 4 * (16 * 216) + j * 216 + n * 72 + g : nullptr;
+    float* tr = (t16_ztape && RICH) ? t16_ztape + (size_t)tile * n_steps * 4 * RT16S_RREC + lane * 4 : nullptr;
     const float Nz = 32.0f;
     const float L2E = 1.4426950408889634f;
     const float cU = m.sig_u * Nz, sU = m.sig_u * m.eps, cV = m.sig_v * Nz, sV = m.sig_v * m.eps, cB = m.B * Nz, sB = m.B * m.eps;
@@ -1477,6 +1494,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
     const float fn = n == 0 ? -m.cs[0] * Nz : (n == 1 ? -m.cs[1] * Nz : -m.cs[2] * m.inv_Pr * Nz);
     const float s0n = n == 0 ? m.s0[0] : (n == 1 ? m.s0[1] : m.s0[2]);
     const float An = n == 0 ? m.A[0] : (n == 1 ? m.A[1] : m.A[2]);
+    const float rmn = n == 0 ? -m.cs[0] : (n == 1 ? -m.cs[1] : -m.cs[2] * m.inv_Pr);                 // m_n of rt16_physics_apply's coefficients
     int step = 0, buf = 0;
     for (int iv = 0; iv < n_save - 1; iv++) {
         const float t0 = save_times[iv];
@@ -1500,6 +1518,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                     for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(o + 16 * tau) = Xme.t[tau];
                 }
                 float* oz = tz ? tz + ((size_t)step * 4 + st) * (16 * 216) : nullptr;
+                float* orr = tr ? tr + ((size_t)step * 4 + st) * RT16S_RREC : nullptr;
                 const float top_raw = n == 2 ? rt_top_flux(m, bc5, ts + ca * dt) : bct;
                 // ---- net n ----------------------------------------------------------------------------------------------
                 f32x4t A1[4];
@@ -1521,7 +1540,14 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                             if (Q < 13 && (Q < 12 || g < 2)) oz[4 * Q] = acc[r];             // feature 4 Q + g of layer 1
                         }
                     }
-                    A1[t] = rt_act4<ACT>(acc);
+                    if (RICH && orr) {
+                        f32x4t dd;
+                        rt16_act_pair<ACT>(acc, A1[t], dd);
+                        if (t == 3) { dd[1] = 0.0f; dd[2] = 0.0f; dd[3] = 0.0f; if (g >= 2) dd[0] = 0.0f; }   // padding: quads >= 13, features 50, 51
+                        *reinterpret_cast<f32x4v*>(orr + (n * 12 + t) * 256) = A1[t];
+                        *reinterpret_cast<f32x4v*>(orr + (n * 12 + 4 + t) * 256) = dd;
+                    } else
+                        A1[t] = rt_act4<ACT>(acc);
                 }
                 f32x4t A2[2];
 #pragma unroll
@@ -1537,7 +1563,14 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                         for (int r = 0; r < 4; r++)
                             if (4 * u + r < 5) oz[52 + 4 * (4 * u + r)] = acc[r];            // feature 4 Q2 + g of layer 2
                     }
-                    A2[u] = rt_act4<ACT>(acc);
+                    if (RICH && orr) {
+                        f32x4t dd;
+                        rt16_act_pair<ACT>(acc, A2[u], dd);
+                        if (u == 1) { dd[1] = 0.0f; dd[2] = 0.0f; dd[3] = 0.0f; }                             // padding: quads >= 5
+                        *reinterpret_cast<f32x4v*>(orr + (n * 12 + 8 + u) * 256) = A2[u];
+                        *reinterpret_cast<f32x4v*>(orr + (n * 12 + 10 + u) * 256) = dd;
+                    } else
+                        A2[u] = rt_act4<ACT>(acc);
                 }
                 V16 O;
 #pragma unroll
@@ -1549,7 +1582,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                     O.t[v] = rt16_chain<5, 5>(wl, acc, [=](int k) { return base + 4 * k; }, [&](int k) { return A2[k >> 2][k & 3]; });
                 }
                 // ---- physics: face flux and tendency of variable n (predict_flux / predict_NDE) -----------------------------
-                V16 F;
+                V16 F, Pd, Pn, Pc;
                 {
                     V16 Ud, Vd, Td;
                     if (m.mpp || m.ca) {
@@ -1576,13 +1609,25 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                                 f32x2v rc;
                                 rc.x = __builtin_amdgcn_rcpf(e1.x);
                                 rc.y = __builtin_amdgcn_rcpf(e1.y);
-                                const f32x2v nu = (rc * -2.0f + 1.0f) * nA + nB;
+                                const f32x2v th = rc * -2.0f + 1.0f;
+                                const f32x2v nu = th * nA + nB;
                                 const f32x2v dn = n == 0 ? dU : (n == 1 ? dV : dT);
                                 const f32x2v on = {O.t[tau][r], O.t[tau][r + 1]};
                                 const f32x2v f = (nu * dn) * fn + on;
                                 F.t[tau][r] = f.x; F.t[tau][r + 1] = f.y;
+                                if (RICH && orr) {
+                                    // this wave's three of the nine pullback coefficients (rt16_physics_apply): dn_n, nu_n, c_n
+                                    const f32x2v wf = (1.0f - th * th) * rS;                 // (1 - tanh²) / S2
+                                    const f32x2v wR = wf * ((dT * cB + sB) * rS);            // ... times Ri
+                                    const f32x2v cn = n == 0 ? wR * (a1 * (-2.0f * m.sig_u)) : (n == 1 ? wR * (a2 * (-2.0f * m.sig_v)) : wf * m.B);
+                                    const f32x2v pd = dn * (rmn * (Nz * m.c_rib)), pn = nu * rmn;
+                                    Pd.t[tau][r] = pd.x; Pd.t[tau][r + 1] = pd.y;
+                                    Pn.t[tau][r] = pn.x; Pn.t[tau][r + 1] = pn.y;
+                                    Pc.t[tau][r] = cn.x; Pc.t[tau][r + 1] = cn.y;
+                                }
                             }
                         if (g == 0) F.t[0][0] = m.zero_w ? bcb - s0n : bcb;                 // face 0: the bottom boundary
+                        if (RICH && g == 0) { Pn.t[0][0] = 0.0f; Pc.t[0][0] = 0.0f; }       // ... carries no diffusive flux
                     } else {
 #pragma unroll
                         for (int tau = 0; tau < 2; tau++)
@@ -1590,12 +1635,22 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                             for (int r = 0; r < 4; r++) {
                                 const bool in = !(tau == 0 && r == 0 && g == 0);
                                 float f = in ? O.t[tau][r] : (m.zero_w ? 0.0f : bcb);
+                                if (RICH) { Pd.t[tau][r] = 0.0f; Pn.t[tau][r] = 0.0f; Pc.t[tau][r] = 0.0f; }
                                 if (m.ca && in && n == 2) {
                                     const float gT = (Xs[2].t[tau][r] - Td.t[tau][r]) * Nz;
                                     f -= m.cs[2] * m.kappa * fminf(0.0f, gT);
+                                    if (RICH && gT < 0.0f) Pn.t[tau][r] = -m.cs[2] * m.kappa;
                                 }
                                 F.t[tau][r] = f;
                             }
+                    }
+                }
+                if (RICH && orr && (m.mpp || m.ca)) {
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) {
+                        *reinterpret_cast<f32x4v*>(orr + (36 + (0 * 3 + n) * 2 + tau) * 256) = Pd.t[tau];
+                        *reinterpret_cast<f32x4v*>(orr + (36 + (1 * 3 + n) * 2 + tau) * 256) = Pn.t[tau];
+                        *reinterpret_cast<f32x4v*>(orr + (36 + (2 * 3 + n) * 2 + tau) * 256) = Pc.t[tau];
                     }
                 }
                 {
@@ -1761,17 +1816,55 @@ __device__ __forceinline__ void rt16_physics_vjp(const DevModel& m, const V16 (&
     }
 }
 
-// value and derivative of the activation on a four-element tile
-template <int ACT>
-__device__ __forceinline__ void rt16_act_pair(const f32x4t z, f32x4t& a, f32x4t& d) {
-    const f32x2v z0 = {z[0], z[1]}, z1 = {z[2], z[3]};
-    f32x2v a0, d0, a1, d1;
-    rt_act_pair4<ACT>(z0, z1, a0, d0, a1, d1);
-    a = (f32x4t){a0.x, a0.y, a1.x, a1.y};
-    d = (f32x4t){d0.x, d0.y, d1.x, d1.y};
+// The coupled (transcendental) half of the pullback read from the RICH tape instead of recomputed: nine coefficients per level,
+//   face cotangent D_k = A_k (k̄_k[i] - k̄_k[i-1]);  g_k = nub c_k + D_k nu_k with nub = Σ_k D_k dn_k;  x̄_k += Nz (g_k[i] - g_k[i+1])
+// (rt16_physics_vjp's arithmetic with the uniform factors and the level mask folded into the coefficients by the forward kernel).
+// On entry kd holds k̄; on exit dO, and xb the physics part of the state cotangent.
+struct PhysC { V16 dn0, dn1, dn2, nu0, nu1, nu2, c0, c1, c2; };
+
+__device__ __forceinline__ void rt16_physics_apply(const DevModel& m, const PhysC& P, V16 (&kd)[3], int lane, V16 (&xb)[3]) {
+    const float Nz = 32.0f;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            xb[0].t[tau][r] = -m.cor_v * m.sig_u * kd[1].t[tau][r];
+            xb[1].t[tau][r] = m.cor_u * m.sig_v * kd[0].t[tau][r];
+            xb[2].t[tau][r] = 0.0f;
+        }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const V16 dn = shift_down16(kd[k], lane, 0.0f);
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                kd[k].t[tau][r] = (tau == 0 && r == 0 && g == 0) ? 0.0f : m.A[k] * (kd[k].t[tau][r] - dn.t[tau][r]);
+    }
+    if (!m.mpp && !m.ca) return;
+    V16 gb[3];
+#pragma unroll
+    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float k0 = kd[0].t[tau][r], k1 = kd[1].t[tau][r], k2 = kd[2].t[tau][r];
+            const float nub = fmaf(k2, P.dn2.t[tau][r], fmaf(k1, P.dn1.t[tau][r], k0 * P.dn0.t[tau][r]));
+            gb[0].t[tau][r] = fmaf(nub, P.c0.t[tau][r], k0 * P.nu0.t[tau][r]);
+            gb[1].t[tau][r] = fmaf(nub, P.c1.t[tau][r], k1 * P.nu1.t[tau][r]);
+            gb[2].t[tau][r] = fmaf(nub, P.c2.t[tau][r], k2 * P.nu2.t[tau][r]);
+        }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const V16 gu_ = shift_up16(gb[k], lane, 0.0f);
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) xb[k].t[tau][r] += (gb[k].t[tau][r] - gu_.t[tau][r]) * Nz;
+    }
 }
 
-template <int ACT>
+template <int ACT, bool RICH>
 __global__ void __launch_bounds__(192)
 rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ save_times, int n_save, int substeps,
                      const float* __restrict__ sol, const float* __restrict__ truth, const float* __restrict__ t16_tape,
@@ -1824,7 +1917,9 @@ rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 
     const int n_steps = (n_save - 1) * substeps;
     const float* tp = t16_tape + (size_t)tile * n_steps * 4 * 1536 + j * 96 + 4 * g;
-    const float* tz = t16_ztape + (size_t)tile * n_steps * 4 * RT16S_ZREC + j * 216 + n * 72 + g;
+    const float* tz = RICH ? t16_ztape + (size_t)tile * n_steps * 4 * RT16S_RREC + lane * 4      // the rich tape (see rt16s_forward_kernel)
+                           : t16_ztape + (size_t)tile * n_steps * 4 * RT16S_ZREC + j * 216 + n * 72 + g;
+    const bool phys = m.mpp || m.ca;
     float* rec0 = dwtape + (size_t)tile * n_steps * 4 * RT16S_REC;
     // the record's 11 float4 pieces this lane copies from the staging area each stage: piece e = 64 i + lane = column e / 44, float4 e % 44
     // of that column's 72 a-floats and 104 δ-floats
@@ -1874,11 +1969,36 @@ rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __
     };
     inject(0, false);
 
-    // stage inputs and hidden pre-activations, fetched one stage ahead of their use
+    // stage inputs and hidden pre-activations (RICH: variable n of the stage input, this net's activations and derivatives, the nine
+    // physics coefficients), fetched one stage ahead of their use
     V16 Xp[3];
     float z1p[13], z2p[5];
-    auto prefetch = [&](int qs) {
+    f32x4t adp[12];
+    PhysC Pp;
+    auto prefetch = [&](int qs) __attribute__((always_inline)) {
         const float* sx = tp + (size_t)qs * 1536;
+        if (RICH) {
+#pragma unroll
+            for (int tau = 0; tau < 2; tau++) Xp[0].t[tau] = *reinterpret_cast<const f32x4v*>(sx + n * 32 + 16 * tau);
+            const float* sr = tz + (size_t)qs * RT16S_RREC;
+#pragma unroll
+            for (int e = 0; e < 12; e++) adp[e] = *reinterpret_cast<const f32x4v*>(sr + (n * 12 + e) * 256);
+            if (phys) {
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) {
+                    Pp.dn0.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 0 + tau) * 256);
+                    Pp.dn1.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 2 + tau) * 256);
+                    Pp.dn2.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 4 + tau) * 256);
+                    Pp.nu0.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 6 + tau) * 256);
+                    Pp.nu1.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 8 + tau) * 256);
+                    Pp.nu2.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 10 + tau) * 256);
+                    Pp.c0.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 12 + tau) * 256);
+                    Pp.c1.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 14 + tau) * 256);
+                    Pp.c2.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 16 + tau) * 256);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -1905,24 +2025,35 @@ rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                 RT_STAMP_BEGIN();
                 V16 X[3];
                 f32x4t Z1[4], Z2[2];
-#pragma unroll
-                for (int q = 0; q < 3; q++) X[q] = Xp[q];
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) Z1[t][r] = (4 * t + r < 13) ? z1p[(4 * t + r) < 13 ? 4 * t + r : 0] : 0.0f;
-#pragma unroll
-                for (int u = 0; u < 2; u++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) Z2[u][r] = (4 * u + r < 5) ? z2p[(4 * u + r) < 5 ? 4 * u + r : 0] : 0.0f;
-                if (qs > 0) prefetch(qs - 1);
-                // (1) stage cotangent k̄ = cwl λ + cwx x̄ (x̄: the state cotangent of the stage handled before), then the physics pullback
+                f32x4t A1[4], D1[4], A2[2], D2[2];
                 V16 kb[3], xbp[3];
+                // (1) stage cotangent k̄ = cwl λ + cwx x̄ (x̄: the state cotangent of the stage handled before), then the physics pullback
 #pragma unroll
                 for (int q = 0; q < 3; q++)
 #pragma unroll
                     for (int tau = 0; tau < 2; tau++) kb[q].t[tau] = cwl * lam[q].t[tau] + cwx * xb[q].t[tau];
-                rt16_physics_vjp(m, X, kb, lane, xbp);                                   // kb now holds dO
+                if (RICH) {
+                    X[0] = Xp[0];                                                        // variable n only
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { A1[t] = adp[t]; D1[t] = adp[4 + t]; }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) { A2[u] = adp[8 + u]; D2[u] = adp[10 + u]; }
+                    rt16_physics_apply(m, Pp, kb, lane, xbp);                            // kb now holds dO
+                    if (qs > 0) prefetch(qs - 1);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) X[q] = Xp[q];
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) Z1[t][r] = (4 * t + r < 13) ? z1p[(4 * t + r) < 13 ? 4 * t + r : 0] : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) Z2[u][r] = (4 * u + r < 5) ? z2p[(4 * u + r) < 5 ? 4 * u + r : 0] : 0.0f;
+                    if (qs > 0) prefetch(qs - 1);
+                    rt16_physics_vjp(m, X, kb, lane, xbp);                               // kb now holds dO
+                }
                 RT_STAMP(0);
                 V16 dO;                 // (element-wise selects on the wave-uniform n: a select between the aggregates becomes a scratch array)
 #pragma unroll
@@ -1934,24 +2065,25 @@ rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                 rt16_fetch_ops<2, 8>(wl, a3, [&](int u, int k) { return b3T[u] + (16 * (k >> 2) + (k & 3)) * RT_LD3; });
                 rt16_fetch_ops<4, 5>(wl, a2, [&](int t, int k) { return b2T[t] + 4 * k * RT_LD2; });
                 RT_SCHED_HARD();
-                // (2) activations and their derivatives from the taped pre-activations
-                f32x4t A1[4], D1[4], A2[2], D2[2];
+                // (2) activations and their derivatives from the taped pre-activations (RICH: taped as such)
+                if (!RICH) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) rt16_act_pair<ACT>(Z1[t], A1[t], D1[t]);
+                    for (int t = 0; t < 4; t++) rt16_act_pair<ACT>(Z1[t], A1[t], D1[t]);
 #pragma unroll
-                for (int u = 0; u < 2; u++) rt16_act_pair<ACT>(Z2[u], A2[u], D2[u]);
+                    for (int u = 0; u < 2; u++) rt16_act_pair<ACT>(Z2[u], A2[u], D2[u]);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (r > 0) { D1[3][r] = 0.0f; D2[1][r] = 0.0f; }                 // padding quads: Q >= 13, Q2 >= 5
+                    for (int r = 0; r < 4; r++) {
+                        if (r > 0) { D1[3][r] = 0.0f; D2[1][r] = 0.0f; }             // padding quads: Q >= 13, Q2 >= 5
+                    }
+                    if (g >= 2) D1[3][0] = 0.0f;                                         // features 50, 51 of quad 12
                 }
-                if (g >= 2) D1[3][0] = 0.0f;                                             // features 50, 51 of quad 12
                 float* rec = rec0 + (size_t)qs * RT16S_REC;
                 {
 #pragma unroll
                     for (int tau = 0; tau < 2; tau++) {
                         f32x4v xv;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) xv[r] = n == 0 ? X[0].t[tau][r] : (n == 1 ? X[1].t[tau][r] : X[2].t[tau][r]);
+                        for (int r = 0; r < 4; r++) xv[r] = (RICH || n == 0) ? X[0].t[tau][r] : (n == 1 ? X[1].t[tau][r] : X[2].t[tau][r]);
                         *reinterpret_cast<f32x4v*>(rec + j * 720 + n * 32 + 16 * tau + 4 * g) = xv;
                     }
 #pragma unroll
@@ -2082,6 +2214,7 @@ size_t rt_forward_lds_bytes() { return (size_t)RT_IMG_FLOATS * sizeof(float); }
 size_t rt_adjoint_lds_bytes() { return ((size_t)RT_IMG_FLOATS + RT_WAVES * (3072 + 1056)) * sizeof(float); }
 size_t rt_tape_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * 3072; }
 size_t rt_tape2_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * RT_TAPE2; }
+size_t rt_split_rich_record_floats() { return RT16S_RREC; }
 size_t rt_tapez_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * RT_TAPEZ; }
 int rt_n_wtiles(int n_col) { return (n_col + RT_COLS - 1) / RT_COLS; }
 int rt_dw1_waves(int n_col, int n_steps) {
@@ -2106,19 +2239,31 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_SWISH>);
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_TANH>);
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_LEAKYRELU>);
-    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_IDENTITY>);
-    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_RELU>);
-    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_MISH>);
-    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_SWISH>);
-    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_TANH>);
-    RT_SETATTR(rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU>);
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_IDENTITY, false>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, false>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, false>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, false>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, false>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
+    RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR(rt_dw1_kernel);
-    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY>);
-    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_RELU>);
-    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_MISH>);
-    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_SWISH>);
-    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_TANH>);
-    RT_SETATTR(rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU>);
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, false>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, false>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, false>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, false>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
+    RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -2188,10 +2333,14 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
 
 // the three-wavefronts-per-tile forward solve of the latency points; tapes (optional) in tile16's formats
 hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const float* x0, const float* bcs, const float* save_times,
-                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, hipStream_t stream) {
+                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, hipStream_t stream) {
     const size_t lds = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + 2 * 384 * 16;
     const dim3 grid((n_col + 15) / 16), block(192);
-#define RT_FWDS(A) hipLaunchKernelGGL(rt16s_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col)
+#define RT_FWDS(A)                                                                                                                              \
+    do {                                                                                                                                        \
+        if (rich) hipLaunchKernelGGL((rt16s_forward_kernel<A, true>), grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else hipLaunchKernelGGL((rt16s_forward_kernel<A, false>), grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+    } while (0)
     switch (m.acts[0]) {
         case COLNDE_ACT_IDENTITY: RT_FWDS(COLNDE_ACT_IDENTITY); break;
         case COLNDE_ACT_RELU: RT_FWDS(COLNDE_ACT_RELU); break;
@@ -2207,13 +2356,17 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
 
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
-                                   int n_col, float* dwtape, hipStream_t stream) {
+                                   int n_col, float* dwtape, bool rich, hipStream_t stream) {
     // the record formats this kernel reads and writes are tile16's for exactly this shape
     if (!rt_supported(m) || dwtape_row_floats(m) * CT != RT16S_REC || t16_ztape_col_floats(m) * CT != RT16S_ZREC || m.nst != 4)
         return hipErrorInvalidValue;
     const size_t lds = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + 2 * (3 * 6 * 64) * 16 + 3 * RT16S_STG * sizeof(float);
     const dim3 grid((n_col + 15) / 16), block(192);
-#define RT_ADJS(A) hipLaunchKernelGGL(rt16s_adjoint_kernel<A>, grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape)
+#define RT_ADJS(A)                                                                                                                              \
+    do {                                                                                                                                        \
+        if (rich) hipLaunchKernelGGL((rt16s_adjoint_kernel<A, true>), grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else hipLaunchKernelGGL((rt16s_adjoint_kernel<A, false>), grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+    } while (0)
     switch (m.acts[0]) {
         case COLNDE_ACT_IDENTITY: RT_ADJS(COLNDE_ACT_IDENTITY); break;
         case COLNDE_ACT_RELU: RT_ADJS(COLNDE_ACT_RELU); break;

@@ -382,7 +382,7 @@ def test_split_kernels_against_oracle_and_tile16(name, monkeypatch):
         tot_s, terms_s, grad_s = nde.loss_grad(p.weights, sc)
         tot_2, terms_2, grad_2 = nde.loss_grad(p.weights, sc)
         plan = nde.plan()
-    assert plan["split_forward"] and plan["split_adjoint"] and plan["dw_taped"]
+    assert plan["split_forward"] and plan["split_adjoint"] and plan["dw_taped"] and plan["split_rich_tape"]
     monkeypatch.setenv("COLNDE_T16_FWD_SPLIT", "0")
     with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
         nde.set_problem(p.x0, p.bcs, truth)
@@ -401,6 +401,27 @@ def test_split_kernels_against_oracle_and_tile16(name, monkeypatch):
     assert np.array_equal(grad_s, grad_2) and tot_s == tot_2
     assert np.abs(sol_s - sol_t).max() < 0.25 * SOL_ATOL
     assert _rel(grad_s, grad_t.astype(np.float64)) < 0.25 * GRAD_REL
+
+
+@pytest.mark.parametrize("name", ["mpp_zero_weights", "conv_adj_branch", "raw", "relu"])
+def test_split_kernels_plain_tape(name, monkeypatch):
+    """COLNDE_T16_SPLIT_RICH=0: the net-split adjoint recomputes activation pairs and the physics closure from the pre-activation and stage
+    tapes (what blocks above 2,048 columns take) instead of reading them from the rich tape; same oracle tolerances, and the two agree."""
+    p = synthetic.wind_mixing_problem(40, n_frames=9, weight_divisor=1e2, **VARIANTS[name])
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    res = {}
+    for rich in ("1", "0"):
+        monkeypatch.setenv("COLNDE_T16_SPLIT_RICH", rich)
+        with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+            nde.set_problem(p.x0, p.bcs, truth)
+            res[rich] = nde.loss_grad(p.weights, sc)
+            plan = nde.plan()
+            assert plan["split_adjoint"] and plan["split_rich_tape"] == (rich == "1")
+        assert np.isclose(res[rich][0], tot, rtol=LOSS_RTOL)
+        assert _rel(res[rich][2], g) < GRAD_REL
+    assert _rel(res["1"][2], res["0"][2].astype(np.float64)) < 0.25 * GRAD_REL
 
 
 def test_split_kernels_column_blocked(monkeypatch):
