@@ -28,7 +28,7 @@ for short, sub in KEYS.items():
     out["per_kernel"][short] = {"fetch_KB_raw": fr, "write_KB": wr, "hbm_bytes": (2.0 * fr + wr) * 1024.0}
 out["adjoint_hbm_bytes_per_launch"] = out["per_kernel"]["rt_adjoint"]["hbm_bytes"]
 out["correction"] = ("gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section); cross-check on known byte counts: rt16_forward WRITE_SIZE = stage "
-                     "tape 28.99 GB + Z1 tape + sol 3.64 GB; rt_dw1 2*FETCH_SIZE = stage tape 28.99 GB + delta tape 50.73 GB")
+                     "tape 28.99 GB + Z1 tape + sol 3.64 GB; rt_dw1 2*FETCH_SIZE = stage tape 28.99 GB + delta tape 48.32 GB (20 groups since r02b)")
 out["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline (%s)" % tag
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for k, v in out["per_kernel"].items():
