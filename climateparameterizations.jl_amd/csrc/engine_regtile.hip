@@ -816,6 +816,10 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     if (ZT) {
                         if (n == 0) {
                             load_z1(step, st, 0, A1);
+#ifdef COLNDE_STAMPS
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            RT_STAMP(7);            // diagnostic build only: the exposed latency of net 0's Z1 loads
+#endif
 #pragma unroll
                             for (int G = 0; G < 24; G += 4) rt_act_pair4_at<ACT>(A1, D1, G);
                             rt_act_pair_at<ACT>(A1, D1, 24);

@@ -31,8 +31,9 @@ if SPLIT:        # net-split kernels of the latency points (wave 0 = net 0)
 elif nde.engine == 2 and FWD:
     names = ["X tape store + top flux", "layer 1 (10 chains, Z1 tape store, activation)", "layers 2, 3", "physics", "RK4 update"]
 elif nde.engine == 2:
-    names = ["kbar + physics pullback + dO park", "dO reload + L1 chains (3 nets)", "X prefetch + L2 chain", "dW3 + W3^T + dZ2",
-             "dW2 (transposes + outer)", "W2^T + dZ1 + tape2 store", "W1^T chains"]
+    # (stamp 6 sits behind the net loop: the W1^T chains of nets 0 and 1 are charged to the next net's stamp 1)
+    names = ["kbar + physics pullback + dO park", "net 0 activation pairs + W1^T chains of nets 0, 1", "L2 chain (3 nets)", "dW3 + W3^T + dZ2",
+             "dW2 (transposes + outer)", "W2^T + dZ1 + tape2 store", "W1^T chains of net 2", "(net 0's Z1 loads: issue -> landed)"]
 else:
     names = ["tape load + kbar", "mlp_forward", "physics_vjp", "mlp_backward", "dW tiles", "bias + xbar sum + barrier"]
 v = np.array(list(buf)[:len(names)], dtype=np.float64)
