@@ -636,14 +636,18 @@ __device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (
     }
 }
 
-// LDS transposition buffer (one 32 x 33 float tile per wave): a D-layout tile (lane = column) becomes the MFMA operand of
+#define RT_TB (32 * 36)   // floats of a wave's transposition tile
+// LDS transposition buffer (one 32 x 36 float tile per wave): a D-layout tile (lane = column) becomes the MFMA operand of
 // a product contracted over the 32 columns (lane = row, k-step s = columns 2s, 2s+1)
 __device__ __forceinline__ f32x16 rt_transpose(float* tb, const f32x16 T, int wbase, int rbase) {
+    // tile stored [column][row] with a 36-float column stride: the four registers 4a .. 4a+3 of a lane are rows 8a + 4h .. + 3 of its column —
+    // one 16-byte write each; the operand of k-step s, lane (row m, kh), is tile[(2 s + kh)][m]
 #pragma unroll
-    for (int r = 0; r < 16; r++) tb[wbase + RHO0(r) * 33] = T[r];
+    for (int a = 0; a < 4; a++)
+        *reinterpret_cast<f32x4v*>(tb + wbase + 8 * a) = (f32x4v){T[4 * a], T[4 * a + 1], T[4 * a + 2], T[4 * a + 3]};
     f32x16 o;
 #pragma unroll
-    for (int s = 0; s < 16; s++) o[s] = tb[rbase + 2 * s];
+    for (int s = 0; s < 16; s++) o[s] = tb[rbase + 72 * s];
     return o;
 }
 
@@ -683,8 +687,8 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     const int j = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x * RT_WAVES + wave;
     if (tile * RT_COLS >= n_col) return;
-    float* lam = rt_smem + RT_IMG_FLOATS + wave * (3072 + 1056);      // λ: [48][64] floats, wave-private
-    float* tb = lam + 3072;                                            // transposition tile [32][33]
+    float* lam = rt_smem + ((RT_IMG_FLOATS + 3) & ~3) + wave * (3072 + RT_TB);   // λ: [48][64] floats, wave-private (16-byte aligned base)
+    float* tb = lam + 3072;                                            // transposition tile [32 columns][36]
     const int col = tile * RT_COLS + j;
     const bool valid = col < n_col;
     const int i_ = lane & 31, r_i = (i_ & 3) + 4 * (i_ >> 3), h_i = (i_ >> 2) & 1;
@@ -700,7 +704,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
     for (int t = 0; t < 2; t++) b2T[t] = RT_W2C + h * RT_LD2 + ((t * 16 + r_i < 25) ? 2 * (t * 16 + r_i) + h_i : 50);   // 50 = zero column
     const int b1T = RT_W1C + h * RT_LD1 + i_;
-    const int wbase = 4 * h * 33 + j, rbase = i_ * 33 + h;
+    const int wbase = j * 36 + 4 * h, rbase = h * 36 + i_;
 
     f32x16 gW3[3], gW2[3][2];
 #pragma unroll
@@ -2215,7 +2219,7 @@ bool rt_supported(const DevModel& m) {
 }
 
 size_t rt_forward_lds_bytes() { return (size_t)RT_IMG_FLOATS * sizeof(float); }
-size_t rt_adjoint_lds_bytes() { return ((size_t)RT_IMG_FLOATS + RT_WAVES * (3072 + 1056)) * sizeof(float); }
+size_t rt_adjoint_lds_bytes() { return ((size_t)((RT_IMG_FLOATS + 3) & ~3) + RT_WAVES * (3072 + RT_TB)) * sizeof(float); }
 size_t rt_tape_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * 3072; }
 size_t rt_tape2_floats(int n_col, int n_steps) { return (size_t)((n_col + RT_COLS - 1) / RT_COLS) * n_steps * 4 * RT_TAPE2; }
 size_t rt_split_rich_record_floats() { return RT16S_RREC; }
