@@ -637,6 +637,8 @@ __device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (
 }
 
 #define RT_TB (32 * 36)   // floats of a wave's transposition tile
+// λ in LDS, wave-private: element e of a lane at [e / 4][lane][e % 4] — four consecutive elements are one 16-byte access
+#define RT_LAM(e, lane) ((((e) >> 2) * 64 + (lane)) * 4 + ((e) & 3))
 // LDS transposition buffer (one 32 x 36 float tile per wave): a D-layout tile (lane = column) becomes the MFMA operand of
 // a product contracted over the 32 columns (lane = row, k-step s = columns 2s, 2s+1)
 __device__ __forceinline__ f32x16 rt_transpose(float* tb, const f32x16 T, int wbase, int rbase) {
@@ -719,7 +721,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
     for (int q = 0; q < 3; q++) xbs[q] = (f32x16)(0.0f);
 #pragma unroll
-    for (int e = 0; e < 48; e++) lam[e * 64 + lane] = 0.0f;
+    for (int e = 0; e < 48; e++) lam[RT_LAM(e, lane)] = 0.0f;
 
     const int n_steps = (n_save - 1) * substeps;
     const float* tp = tape + (size_t)tile * n_steps * 4 * 3072 + lane * 4;
@@ -751,7 +753,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 const f32x16 gu_ = shift_up(gg, h, 0.0f);
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    lam[(q * 16 + r) * 64 + lane] += 2.0f * lw.w[q] * d[r] + 2.0f * lw.w[3 + q] * 32.0f * (gg[r] - gu_[r]);
+                    lam[RT_LAM(q * 16 + r, lane)] += 2.0f * lw.w[q] * d[r] + 2.0f * lw.w[3 + q] * 32.0f * (gg[r] - gu_[r]);
             }
         }
     };
@@ -803,7 +805,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                     for (int q = 0; q < 3; q++)
 #pragma unroll
-                        for (int r = 0; r < 16; r++) kb[q][r] = cwl * lam[(q * 16 + r) * 64 + lane] + cwx * xb[q][r];
+                        for (int r = 0; r < 16; r++) kb[q][r] = cwl * lam[RT_LAM(q * 16 + r, lane)] + cwx * xb[q][r];
                     rt_physics_vjp(m, X, kb, h, xb);       // kb now holds dO
 #pragma unroll
                     for (int q = 0; q < 3; q++) dOk[q] = kb[q];
@@ -948,7 +950,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
             for (int q = 0; q < 3; q++) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) lam[(q * 16 + r) * 64 + lane] += xbs[q][r];
+                for (int r = 0; r < 16; r++) lam[RT_LAM(q * 16 + r, lane)] += xbs[q][r];
                 xbs[q] = (f32x16)(0.0f);
             }
         }
