@@ -1506,6 +1506,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
     const float An = n == 0 ? m.A[0] : (n == 1 ? m.A[1] : m.A[2]);
     const float rmn = n == 0 ? -m.cs[0] : (n == 1 ? -m.cs[1] : -m.cs[2] * m.inv_Pr);                 // m_n of rt16_physics_apply's coefficients
     int step = 0, buf = 0;
+    RT_STAMP_DECL;
     for (int iv = 0; iv < n_save - 1; iv++) {
         const float t0 = save_times[iv];
         const float dt = (save_times[iv + 1] - t0) / (float)substeps;
@@ -1517,6 +1518,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
             for (int st = 0; st < 4; st++) {
                 const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);
                 const float cb = (st == 0 || st == 3) ? 1.0f / 6.0f : 1.0f / 3.0f;
+                RT_STAMP_BEGIN();
                 V16 Xme;               // (element-wise selects on the wave-uniform n: a select between the aggregates becomes a scratch array)
 #pragma unroll
                 for (int tau = 0; tau < 2; tau++)
@@ -1530,6 +1532,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                 float* oz = tz ? tz + ((size_t)step * 4 + st) * (16 * 216) : nullptr;
                 float* orr = tr ? tr + ((size_t)step * 4 + st) * RT16S_RREC : nullptr;
                 const float top_raw = n == 2 ? rt_top_flux(m, bc5, ts + ca * dt) : bct;
+                RT_STAMP(0);
                 // ---- net n ----------------------------------------------------------------------------------------------
                 f32x4t A1[4];
 #pragma unroll
@@ -1559,6 +1562,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                     } else
                         A1[t] = rt_act4<ACT>(acc);
                 }
+                RT_STAMP(1);
                 f32x4t A2[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
@@ -1591,6 +1595,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                     const int base = a3b[v];
                     O.t[v] = rt16_chain<5, 5>(wl, acc, [=](int k) { return base + 4 * k; }, [&](int k) { return A2[k >> 2][k & 3]; });
                 }
+                RT_STAMP(2);
                 // ---- physics: face flux and tendency of variable n (predict_flux / predict_NDE) -----------------------------
                 V16 F, Pd, Pn, Pc;
                 {
@@ -1676,6 +1681,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
                             F.t[tau][r] = v;                                                // F now holds the tendency of variable n
                         }
                 }
+                RT_STAMP(3);
                 // ---- RK4 bookkeeping for variable n; the next stage input (or, after stage 3, the new state) is exchanged -------------
                 V16 Xnext;
 #pragma unroll
@@ -1699,6 +1705,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 #pragma unroll
                     for (int tau = 0; tau < 2; tau++) Xs[q].t[tau] = eb[(q * 2 + tau) * 64 + lane];
                 buf ^= 1;
+                RT_STAMP(4);
             }
             if (s == substeps - 1 && sol && valid) {
 #pragma unroll
@@ -1707,6 +1714,9 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
             }
         }
     }
+#ifdef COLNDE_STAMPS_FWD
+    RT_STAMP_FLUSH();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -25,7 +25,10 @@ for _ in range(12 if ncol >= 16384 else 1):        # back-to-back launches, so t
 buf = (ctypes.c_ulonglong * 16)()
 _lib.check(L.colnde_debug_stamps(nde._h, buf))
 SPLIT = nde.engine == 1 and not FC64 and os.environ.get("COLNDE_T16_FWD_SPLIT", "1") != "0" and os.environ.get("COLNDE_T16_ADJ_SPLIT", "1") != "0"
-if SPLIT:        # net-split kernels of the latency points (wave 0 = net 0)
+if SPLIT and FWD:
+    names = ["x tape store + top flux", "layer 1 (4 chains, activation, tape stores)", "layers 2, 3", "physics (flux, tendency, coefficients)",
+             "RK4 bookkeeping + exchange + barrier"]
+elif SPLIT:        # net-split kernels of the latency points (wave 0 = net 0)
     names = ["prefetch issue + kbar + physics pullback", "activation pairs + x / a stores", "W3^T and W2^T chains", "delta stores + bias sums",
              "W1^T chains + exchange write", "barrier + sum of the three parts"]
 elif nde.engine == 2 and FWD:
@@ -41,7 +44,7 @@ nstage = p.cfg.n_steps * 4
 for n, x in zip(names, v):
     print("%-28s %10.0f cycles/stage  %5.1f %%" % (n, x / nstage, 100 * x / v.sum()))
 print("total %.0f cycles/stage" % (v.sum() / nstage))
-if FWD:
+if FWD and not SPLIT:
     print("whole kernel (workgroup 0, wave 0): %d s_memtime ticks in %.3f ms (s_memrealtime, 100 MHz) -> %.3f ticks/ns; stage loop share %.1f %%"
           % (buf[6], buf[7] / 1e5, buf[6] / (buf[7] * 10.0), 100.0 * v.sum() / buf[6]))
 if nde.engine == 2 or SPLIT:
