@@ -221,6 +221,29 @@ def test_regtile_long_horizon_against_oracle(n_col, divisor):
     assert _rel(grad_g, g) < LONG_GRAD_REL[divisor]
 
 
+@pytest.mark.parametrize("engine", [0, 2])
+def test_eight_day_suite_horizon(engine):
+    """The reference's long training suites (wind_mixing 8DaySuite: 1,153 frames; two RK4 sub-steps per frame = 2,304 steps, four times
+    the bench horizon) on 8 simulations: engine AUTO (the net-split kernels) and regtile named explicitly, against the float64 oracle.
+    Round-off accumulates over 9,216 stage evaluations: measured sol 1.7e-5, loss 1.2e-6 / 5.2e-6, gradient 2.0e-6 / 2.4e-6
+    (weights/1e2); the tolerances below are about 10x that."""
+    p = synthetic.wind_mixing_problem(8, n_frames=1153, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(p.cfg)
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=engine) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+        plan = nde.plan()
+    assert plan["split_adjoint"] == (engine == 0)
+    _record("eight_day/%d" % engine, sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot,
+            terms_rel=np.abs(terms_g / terms - 1).max(), grad_rel=_rel(grad_g, g))
+    assert np.abs(sol_g - sol).max() < 1.7e-4
+    assert np.isclose(tot_g, tot, rtol=5e-5, atol=0)
+    assert _rel(grad_g, g) < 2.5e-5
+
+
 def test_config1_shape_one_column_ten_frames():
     """BASELINE config 1 (`test_nonmutating_NDE.jl:49-58`): 1 simulation, 32 levels, MPP + zero_weights, nu0 = 1e-4, nu_minus = 0.1,
     dRi = 1, Ric = 0.25, Pr = 1, `tsteps = 1:1:10` of the 1,153-frame 8-day record (tau = 691,200 s, dt = 1/1152), both engines."""
