@@ -485,8 +485,8 @@ def test_split_adjoint_behind_tile16_forward(monkeypatch):
 
 
 # ---- edge cases: ragged/minimal shapes, non-uniform time axis, odd sub-step counts, both engines ---------------------
-@pytest.mark.parametrize("engine", [1, 2])
-@pytest.mark.parametrize("n_col", [1, 31, 33])
+@pytest.mark.parametrize("engine", [0, 1, 2])          # 0 = AUTO: the net-split kernels at these sizes
+@pytest.mark.parametrize("n_col", [1, 15, 31, 33])
 def test_edge_columns_nonuniform_times(engine, n_col):
     p = synthetic.wind_mixing_problem(n_col, n_frames=5, weight_divisor=1e2)
     # non-uniform save times and 3 sub-steps per interval (train_tranges such as 1:20:200 give uniform spacing; the ABI
@@ -506,7 +506,7 @@ def test_edge_columns_nonuniform_times(engine, n_col):
     assert _rel(grad_g, g) < GRAD_REL
 
 
-@pytest.mark.parametrize("engine", [1, 2])
+@pytest.mark.parametrize("engine", [0, 1, 2])
 def test_zero_weights_give_zero_weight_gradient_blocks(engine):
     """With all weights zero every hidden activation of a mish net is 0, so dW2, dW3 vanish identically while db3 and
     (through mish'(0) = 0.6) the other gradients do not: checks the per-layer block placement in Flux.destructure order."""
