@@ -819,6 +819,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                 }
                 RT_STAMP(0);
                 float* dst = tp2 + ((size_t)step * 4 + st) * RT_TAPE2;
+                float carry[2] = {0.0f, 0.0f};
                 // the nets are handled one after the other so that only one net's hidden state is live at a time
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
@@ -913,8 +914,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                         for (int r = 0; r < 16; r++) D1[t][r] = da[r] * D1[t][r];     // dZ1 in place of act'(z1)
                     }
-                    // delta tape: register g of net n is stacked register G = 25 n + g, element G & 3 of 16-byte group G >> 2
-                    // (whole groups with one store, the registers at a net boundary one by one)
+                    // delta tape: register g of net n is stacked register G = 25 n + g, element G & 3 of 16-byte group G >> 2.  Whole groups
+                    // leave with one store; the groups that straddle a net boundary (6: G 24 | 25..27, 12: G 48, 49 | 50, 51) wait in
+                    // `carry` for the next net's first registers, so a stage writes 19 16-byte stores and no scattered dwords
 #pragma unroll
                     for (int g = 0; g < 25; g++) {
                         const int G = 25 * n + g;
@@ -922,9 +924,17 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                             const f32x4v v = {D1[g >> 4][g & 15], D1[(g + 1) >> 4][(g + 1) & 15], D1[(g + 2) >> 4][(g + 2) & 15],
                                               D1[(g + 3) >> 4][(g + 3) & 15]};
                             RT_NT_STORE4(dst + (G >> 2) * 256, v);
-                        } else if (g < (G & 3) || g - (G & 3) + 3 >= 25) {
-                            RT_NT_STORE1(dst + (G >> 2) * 256 + (G & 3), D1[g >> 4][g & 15]);
                         }
+                    }
+                    if (n == 0) carry[0] = D1[1][8];                                                   // G 24
+                    if (n == 1) {
+                        RT_NT_STORE4(dst + 6 * 256, ((f32x4v){carry[0], D1[0][0], D1[0][1], D1[0][2]}));   // G 24 | 25, 26, 27
+                        carry[0] = D1[1][7];                                                           // G 48
+                        carry[1] = D1[1][8];                                                           // G 49
+                    }
+                    if (n == 2) {
+                        RT_NT_STORE4(dst + 12 * 256, ((f32x4v){carry[0], carry[1], D1[0][0], D1[0][1]})); // G 48, 49 | 50, 51
+                        RT_NT_STORE4(dst + 18 * 256, ((f32x4v){D1[1][6], D1[1][7], D1[1][8], 0.0f}));     // G 72, 73, 74, pad
                     }
                     RT_STAMP(5);
                     // (6) x̄ += W1_n^T dZ1_n
