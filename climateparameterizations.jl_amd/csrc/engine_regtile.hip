@@ -1755,8 +1755,9 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 #define RT16S_ZREC (16 * 216)      // floats per pre-activation tape record: 16 columns x 3 nets x 72
 #define RT16S_STG (16 * 180)       // floats of one wave's record staging area in LDS
 
-// NC independent chains of N k-steps advanced together, k-major (consecutive MFMAs belong to different accumulators: no dependent-issue
-// bubble), their A operands fetched as one group — early enough, by the caller, that the LDS latency is covered by other work
+// NC independent chains of N k-steps advanced together, k-major, their A operands fetched as one group — early enough, by the caller, that the
+// LDS latency is covered by other work.  (The grouping is for the operand fetch: a dependent fp32 MFMA chain issues at the full rate anyway,
+// tools/probe/mfma_rate.hip.)
 template <int NC, int N, class AF>
 __device__ __forceinline__ void rt16_fetch_ops(const float* wl, float (&a)[NC][N], AF aidx) {
 #pragma unroll
