@@ -28,7 +28,7 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
                              const float* save_times, int n_save, int substeps, float* sol, float* tape, float* tapez,
                              int n_col, bool fwd32, hipStream_t stream);
 hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const float* x0, const float* bcs, const float* save_times,
-                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, hipStream_t stream);
+                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, bool use_helper, hipStream_t stream);
 size_t rt_split_rich_record_floats();   // floats per (tile, step, stage) of the net-split kernels' rich tape (which then takes the place of t16_ztape)
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,

@@ -1736,6 +1736,296 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 #endif
 }
 
+// The same solve with a FOURTH wavefront (the workgroup's idle SIMD) as helper: it evaluates the Richardson-number closure of all three variables
+// once per stage — the diffusive face fluxes go to LDS, the rich tape's nine pullback coefficients to HBM — while the three net waves run their
+// chains; a second bare barrier per stage (B) hands the fluxes over.  Every wave executes exactly the barriers (B) and (A) in every stage.
+template <int ACT, bool RICH>
+__global__ void __launch_bounds__(256)
+rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
+                     const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
+                     float* __restrict__ t16_tape, float* __restrict__ t16_ztape, int n_col) {
+    float* wl = rt_smem;
+    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += 256) wl[e] = wimg[e];
+    f32x4v* ex = reinterpret_cast<f32x4v*>(rt_smem + ((RT_IMG_FLOATS + 3) & ~3));          // [2 buffers][3 variables][2 tiles][64 lanes]
+    f32x4v* cl = ex + 2 * 384;                                                             // the helper wave's closure fluxes [3 variables][2 tiles][64 lanes]
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                     // 0..2: net = variable; 3: the helper (fourth SIMD)
+    const bool helper = role == 3;
+    const int n = helper ? 2 : role;
+    const int j = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x;
+    const int col = tile * 16 + j;
+    const bool valid = col < n_col;
+    const int colc = min(col, n_col - 1);
+    const int i_ = lane & 15, g_i = i_ >> 2, r_i = i_ & 3;
+    int a1b[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int Q = 4 * t + r_i, f = 4 * Q + g_i;
+        a1b[t] = RT_W1C + (n * 50 + ((Q < 13 && f < 50) ? f : 0)) * RT_LD1 + 4 * g;       // padding rows read a valid row; never consumed
+    }
+    int a2b[2], a2l[2], a3b[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int Q2 = 4 * u + r_i;
+        const int row2 = n * 20 + (Q2 < 5 ? 4 * Q2 + g_i : 0);
+        a2b[u] = RT_W2C + row2 * RT_LD2 + g;
+        a2l[u] = RT_W2C + row2 * RT_LD2 + (g < 2 ? 48 + g : 50);
+        a3b[u] = RT_W3C + (n * 31 + 16 * u + i_ - 1) * RT_LD3 + g;
+    }
+    float bcb, bct, bc5;
+    {
+        const float* bp = bcs + (size_t)colc * 6;
+        bcb = bp[2 * n];
+        bct = bp[2 * n + 1];
+        bc5 = bp[5];
+    }
+    V16 Xs[3], Xn, Kacc;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++) Xs[q].t[tau] = *reinterpret_cast<const f32x4v*>(x0 + (size_t)colc * 96 + q * 32 + 16 * tau + 4 * g);
+    // (wave-uniform n: a select, not a dynamic register index)
+#pragma unroll
+    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Xn.t[tau][r] = n == 0 ? Xs[0].t[tau][r] : (n == 1 ? Xs[1].t[tau][r] : Xs[2].t[tau][r]);
+    if (sol && valid && !helper)
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
+    const int n_steps = (n_save - 1) * substeps;
+    float* tp = t16_tape ? t16_tape + (size_t)tile * n_steps * 4 * 1536 + j * 96 + n * 32 + 4 * g : nullptr;
+    float* tz = (t16_ztape && !RICH) ? t16_ztape + (size_t)tile * n_steps * 4 * (16 * 216) + j * 216 + n * 72 + g : nullptr;
+    float* tr = (t16_ztape && RICH) ? t16_ztape + (size_t)tile * n_steps * 4 * RT16S_RREC + lane * 4 : nullptr;
+    const float Nz = 32.0f;
+    const float L2E = 1.4426950408889634f;
+    const float cU = m.sig_u * Nz, sU = m.sig_u * m.eps, cV = m.sig_v * Nz, sV = m.sig_v * m.eps, cB = m.B * Nz, sB = m.B * m.eps;
+    const float kE = 2.0f * m.inv_dRi * L2E, oE = -2.0f * m.Ric * m.inv_dRi * L2E, cE = 30.0f * L2E;
+    const float nA = -0.5f * m.nu_minus, nB = m.nu0 + 0.5f * m.nu_minus;
+    const float s0n = n == 0 ? m.s0[0] : (n == 1 ? m.s0[1] : m.s0[2]);
+    const float An = n == 0 ? m.A[0] : (n == 1 ? m.A[1] : m.A[2]);
+    int step = 0, buf = 0;
+    RT_STAMP_DECL;
+    for (int iv = 0; iv < n_save - 1; iv++) {
+        const float t0 = save_times[iv];
+        const float dt = (save_times[iv + 1] - t0) / (float)substeps;
+        for (int s = 0; s < substeps; s++, step++) {
+            const float ts = t0 + (float)s * dt;
+            Kacc.t[0] = (f32x4t)(0.0f);
+            Kacc.t[1] = (f32x4t)(0.0f);
+#pragma nounroll
+            for (int st = 0; st < 4; st++) {
+                const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);
+                const float cb = (st == 0 || st == 3) ? 1.0f / 6.0f : 1.0f / 3.0f;
+                RT_STAMP_BEGIN();
+                f32x4v* eb = ex + buf * 384;
+                if (helper) {
+                    // ---- the Richardson-number closure of all three variables (predict_flux), once, on the fourth SIMD, while the net waves run
+                    //      their chains: diffusive face fluxes to LDS, and (RICH) the nine pullback coefficients to the tape
+                    float* orr = tr ? tr + ((size_t)step * 4 + st) * RT16S_RREC : nullptr;
+                    V16 C[3];
+                    if (m.mpp) {
+                        const V16 Ud = shift_down16(Xs[0], lane, 0.0f), Vd = shift_down16(Xs[1], lane, 0.0f), Td = shift_down16(Xs[2], lane, 0.0f);
+                        const float f0 = -m.cs[0] * Nz, f1 = -m.cs[1] * Nz, f2 = -m.cs[2] * m.inv_Pr * Nz;
+                        const float m0 = -m.cs[0], m1 = -m.cs[1], m2 = -m.cs[2] * m.inv_Pr, nr = Nz * m.c_rib;
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                            for (int r = 0; r < 4; r += 2) {
+                                const f32x2v dU = {Xs[0].t[tau][r] - Ud.t[tau][r], Xs[0].t[tau][r + 1] - Ud.t[tau][r + 1]};
+                                const f32x2v dV = {Xs[1].t[tau][r] - Vd.t[tau][r], Xs[1].t[tau][r + 1] - Vd.t[tau][r + 1]};
+                                const f32x2v dT = {Xs[2].t[tau][r] - Td.t[tau][r], Xs[2].t[tau][r + 1] - Td.t[tau][r + 1]};
+                                const f32x2v a1 = dU * cU + sU, a2 = dV * cV + sV;
+                                const f32x2v s2 = a2 * a2 + a1 * a1;
+                                f32x2v rS;
+                                rS.x = __builtin_amdgcn_rcpf(s2.x);
+                                rS.y = __builtin_amdgcn_rcpf(s2.y);
+                                const f32x2v Ri = (dT * cB + sB) * rS;
+                                const f32x2v arg = Ri * kE + oE;
+                                f32x2v e;
+                                e.x = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(arg.x, -cE, cE));
+                                e.y = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(arg.y, -cE, cE));
+                                const f32x2v e1 = e + 1.0f;
+                                f32x2v rc;
+                                rc.x = __builtin_amdgcn_rcpf(e1.x);
+                                rc.y = __builtin_amdgcn_rcpf(e1.y);
+                                const f32x2v th = rc * -2.0f + 1.0f;
+                                const f32x2v nu = th * nA + nB;
+                                const f32x2v c0 = (nu * dU) * f0, c1 = (nu * dV) * f1, c2 = (nu * dT) * f2;
+                                C[0].t[tau][r] = c0.x; C[0].t[tau][r + 1] = c0.y;
+                                C[1].t[tau][r] = c1.x; C[1].t[tau][r + 1] = c1.y;
+                                C[2].t[tau][r] = c2.x; C[2].t[tau][r + 1] = c2.y;
+                                if (RICH && orr) {
+                                    const bool z0 = tau == 0 && r == 0 && g == 0;            // face 0 carries no diffusive flux
+                                    const f32x2v wf = (1.0f - th * th) * rS, wR = wf * Ri;
+                                    f32x2v pn = nu, pc0 = wR * (a1 * (-2.0f * m.sig_u)), pc1 = wR * (a2 * (-2.0f * m.sig_v)), pc2 = wf * m.B;
+                                    if (z0) { pn.x = 0.0f; pc0.x = 0.0f; pc1.x = 0.0f; pc2.x = 0.0f; }
+                                    float* o2 = orr + (36 + tau) * 256 + r;
+                                    const f32x2v d0 = dU * (m0 * nr), d1 = dV * (m1 * nr), d2 = dT * (m2 * nr), q0 = pn * m0, q1 = pn * m1, q2 = pn * m2;
+                                    *reinterpret_cast<f32x2v*>(o2 + 0 * 512) = d0;  *reinterpret_cast<f32x2v*>(o2 + 1 * 512) = d1;  *reinterpret_cast<f32x2v*>(o2 + 2 * 512) = d2;
+                                    *reinterpret_cast<f32x2v*>(o2 + 3 * 512) = q0;  *reinterpret_cast<f32x2v*>(o2 + 4 * 512) = q1;  *reinterpret_cast<f32x2v*>(o2 + 5 * 512) = q2;
+                                    *reinterpret_cast<f32x2v*>(o2 + 6 * 512) = pc0; *reinterpret_cast<f32x2v*>(o2 + 7 * 512) = pc1; *reinterpret_cast<f32x2v*>(o2 + 8 * 512) = pc2;
+                                }
+                            }
+                    } else {
+                        const V16 Td = shift_down16(Xs[2], lane, 0.0f);
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const bool in = !(tau == 0 && r == 0 && g == 0);
+                                const float gT = (Xs[2].t[tau][r] - Td.t[tau][r]) * Nz;
+                                C[0].t[tau][r] = 0.0f;
+                                C[1].t[tau][r] = 0.0f;
+                                C[2].t[tau][r] = (m.ca && in) ? -m.cs[2] * m.kappa * fminf(0.0f, gT) : 0.0f;
+                                if (RICH && orr && m.ca) {
+                                    float* o2 = orr + (36 + tau) * 256 + r;
+#pragma unroll
+                                    for (int a9 = 0; a9 < 9; a9++) o2[a9 * 512] = (a9 == 5 && in && gT < 0.0f) ? -m.cs[2] * m.kappa : 0.0f;
+                                }
+                            }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++) cl[(k * 2 + tau) * 64 + lane] = C[k].t[tau];
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (B) the closure is in LDS
+                } else {
+                V16 Xme;               // (element-wise selects on the wave-uniform n: a select between the aggregates becomes a scratch array)
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Xme.t[tau][r] = n == 0 ? Xs[0].t[tau][r] : (n == 1 ? Xs[1].t[tau][r] : Xs[2].t[tau][r]);
+                if (tp) {
+                    float* o = tp + ((size_t)step * 4 + st) * 1536;
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(o + 16 * tau) = Xme.t[tau];
+                }
+                float* oz = tz ? tz + ((size_t)step * 4 + st) * (16 * 216) : nullptr;
+                float* orr = tr ? tr + ((size_t)step * 4 + st) * RT16S_RREC : nullptr;
+                const float top_raw = n == 2 ? rt_top_flux(m, bc5, ts + ca * dt) : bct;
+                RT_STAMP(0);
+                // ---- net n ----------------------------------------------------------------------------------------------
+                f32x4t A1[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    f32x4t acc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int Q = 4 * t + r;
+                        acc[r] = Q < 13 ? wl[RT_B1C + n * 50 + min(4 * Q + g, 49)] : 0.0f;
+                    }
+                    const int base = a1b[t];
+                    acc = rt16_chain<24, 8>(wl, acc, [=](int k) { return base + (k >> 3) * 32 + ((k >> 2) & 1) * 16 + (k & 3); },
+                                            [&](int k) { return Xs[k >> 3].t[(k >> 2) & 1][k & 3]; });
+                    if (oz) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int Q = 4 * t + r;
+                            if (Q < 13 && (Q < 12 || g < 2)) oz[4 * Q] = acc[r];             // feature 4 Q + g of layer 1
+                        }
+                    }
+                    if (RICH && orr) {
+                        f32x4t dd;
+                        rt16_act_pair<ACT>(acc, A1[t], dd);
+                        if (t == 3) { dd[1] = 0.0f; dd[2] = 0.0f; dd[3] = 0.0f; if (g >= 2) dd[0] = 0.0f; }   // padding: quads >= 13, features 50, 51
+                        *reinterpret_cast<f32x4v*>(orr + (n * 12 + t) * 256) = A1[t];
+                        *reinterpret_cast<f32x4v*>(orr + (n * 12 + 4 + t) * 256) = dd;
+                    } else
+                        A1[t] = rt_act4<ACT>(acc);
+                }
+                RT_STAMP(1);
+                f32x4t A2[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    f32x4t acc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[r] = (4 * u + r < 5) ? wl[RT_B2C + n * 20 + 4 * (4 * u + r) + g] : 0.0f;
+                    const int base = a2b[u], basel = a2l[u];
+                    acc = rt16_chain<13, 13>(wl, acc, [=](int k) { return k < 12 ? base + 4 * k : basel; },
+                                             [&](int k) { return A1[k >> 2][k & 3]; });
+                    if (oz) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (4 * u + r < 5) oz[52 + 4 * (4 * u + r)] = acc[r];            // feature 4 Q2 + g of layer 2
+                    }
+                    if (RICH && orr) {
+                        f32x4t dd;
+                        rt16_act_pair<ACT>(acc, A2[u], dd);
+                        if (u == 1) { dd[1] = 0.0f; dd[2] = 0.0f; dd[3] = 0.0f; }                             // padding: quads >= 5
+                        *reinterpret_cast<f32x4v*>(orr + (n * 12 + 8 + u) * 256) = A2[u];
+                        *reinterpret_cast<f32x4v*>(orr + (n * 12 + 10 + u) * 256) = dd;
+                    } else
+                        A2[u] = rt_act4<ACT>(acc);
+                }
+                V16 O;
+#pragma unroll
+                for (int v = 0; v < 2; v++) {
+                    f32x4t acc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[r] = wl[RT_B3C + n * 32 + 16 * v + 4 * g + r];
+                    const int base = a3b[v];
+                    O.t[v] = rt16_chain<5, 5>(wl, acc, [=](int k) { return base + 4 * k; }, [&](int k) { return A2[k >> 2][k & 3]; });
+                }
+                RT_STAMP(2);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // (B) the helper's closure fluxes are in LDS
+                // ---- physics: face flux = NN flux + closure flux, tendency of variable n (predict_flux / predict_NDE) ---------
+                V16 F;
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) F.t[tau] = O.t[tau] + cl[(n * 2 + tau) * 64 + lane];
+                if (g == 0) F.t[0][0] = m.mpp ? (m.zero_w ? bcb - s0n : bcb) : (m.zero_w ? 0.0f : bcb);      // face 0: the bottom boundary
+                {
+                    const float top = m.zero_w ? top_raw - s0n : top_raw;
+                    const V16 Fu = shift_up16(F, lane, top);
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float v = -An * (Fu.t[tau][r] - F.t[tau][r]);
+                            if (n == 0) v += m.cor_u * (m.sig_v * Xs[1].t[tau][r] + m.mu_v);
+                            if (n == 1) v -= m.cor_v * (m.sig_u * Xs[0].t[tau][r] + m.mu_u);
+                            F.t[tau][r] = v;                                                // F now holds the tendency of variable n
+                        }
+                }
+                RT_STAMP(3);
+                // ---- RK4 bookkeeping for variable n; the next stage input (or, after stage 3, the new state) is exchanged -------------
+                V16 Xnext;
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) {
+                    Kacc.t[tau] += cb * F.t[tau];
+                    if (st < 3) {
+                        const float can = st == 2 ? 1.0f : 0.5f;
+                        Xnext.t[tau] = Xn.t[tau] + (can * dt) * F.t[tau];
+                    } else {
+                        Xn.t[tau] += dt * Kacc.t[tau];
+                        Xnext.t[tau] = Xn.t[tau];
+                    }
+                }
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) eb[(n * 2 + tau) * 64 + lane] = Xnext.t[tau];
+                }
+                // (a bare barrier behind the LDS writes: __syncthreads() would also drain vmcnt, i.e. wait for this stage's tape stores)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) Xs[q].t[tau] = eb[(q * 2 + tau) * 64 + lane];
+                buf ^= 1;
+                RT_STAMP(4);
+            }
+            if (s == substeps - 1 && sol && valid && !helper) {
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++)
+                    *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save + iv + 1) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
+            }
+        }
+    }
+#ifdef COLNDE_STAMPS_FWD
+    RT_STAMP_FLUSH();
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // discrete adjoint of ONE 16-column tile by THREE wavefronts (the companion of rt16s_forward_kernel at the latency points).
 //
@@ -2279,16 +2569,28 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_LEAKYRELU>);
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR(rt_dw1_kernel);
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
@@ -2371,12 +2673,16 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
 
 // the three-wavefronts-per-tile forward solve of the latency points; tapes (optional) in tile16's formats
 hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const float* x0, const float* bcs, const float* save_times,
-                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, hipStream_t stream) {
+                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, bool use_helper, hipStream_t stream) {
     const size_t lds = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + 2 * 384 * 16;
     const dim3 grid((n_col + 15) / 16), block(192);
+    const size_t ldsh = lds + 384 * 16;
+    const dim3 blockh(256);
 #define RT_FWDS(A)                                                                                                                              \
     do {                                                                                                                                        \
-        if (rich) hipLaunchKernelGGL((rt16s_forward_kernel<A, true>), grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        if (use_helper && rich) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else if (use_helper) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else if (rich) hipLaunchKernelGGL((rt16s_forward_kernel<A, true>), grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else hipLaunchKernelGGL((rt16s_forward_kernel<A, false>), grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
     } while (0)
     switch (m.acts[0]) {

@@ -447,6 +447,23 @@ def test_split_kernels_plain_tape(name, monkeypatch):
     assert _rel(res["1"][2], res["0"][2].astype(np.float64)) < 0.25 * GRAD_REL
 
 
+def test_split_forward_without_helper_wave(monkeypatch):
+    """COLNDE_T16_FWD_HELPER=0: the three-wave forward kernel (every net wave evaluates the Richardson-number closure itself) gives the
+    trajectory and gradient of the default four-wave one (a helper wave on the fourth SIMD hands the closure fluxes over through LDS)."""
+    for name in ("mpp_zero_weights", "conv_adj_branch", "raw", "diurnal"):
+        p = synthetic.wind_mixing_problem(40, n_frames=9, weight_divisor=1e2, **VARIANTS[name])
+        truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+        sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+        res = {}
+        for hw in ("1", "0"):
+            monkeypatch.setenv("COLNDE_T16_FWD_HELPER", hw)
+            with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+                nde.set_problem(p.x0, p.bcs, truth)
+                res[hw] = (nde.forward(p.weights), nde.loss_grad(p.weights, sc))
+        assert np.abs(res["1"][0] - res["0"][0]).max() < 0.25 * SOL_ATOL, name
+        assert _rel(res["1"][1][2], res["0"][1][2].astype(np.float64)) < 0.25 * GRAD_REL, name
+
+
 def test_split_kernels_column_blocked(monkeypatch):
     """The column-blocked gradient path (tapes that hold one block: what a problem larger than the free HBM takes) through the net-split
     kernels: 40 columns as blocks of 16 + 16 + 8 give the gradient of the unblocked run (same kernels, same reduction order per row)."""
