@@ -53,6 +53,7 @@ struct colnde_handle {
     size_t lds_fwd = 0, lds_adj = 0, lds_fwd_solve = 0;
     int fwd_threads = 256;
     bool fwd_wlds = false;
+    bool adj_helper = true;         // ... and in the adjoint: a helper wave carries λ, x̄ and the physics pullback for the three net waves
     bool fwd_helper = true;         // ... four waves per tile: a helper wave evaluates the Richardson-number closure for the three net waves
     bool split_rich = false;        // ... with the rich tape (activations, derivatives, physics coefficients) in place of the pre-activation tape
     bool adj_split = false;         // ... and the gradient by rt16s_adjoint_kernel + tile16's dW GEMM
@@ -394,6 +395,8 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         // the gradient behind a split forward: rt16s_adjoint_kernel (same decomposition) when the taped mode with both tapes is planned
         const char* eh = getenv("COLNDE_T16_FWD_HELPER");      // 0: the three-wave forward (8 simulations 9.8 vs 8.3 ms, 4,096 columns 8.27 vs 7.65 ms)
         h->fwd_helper = !(eh && atoi(eh) == 0);
+        const char* eah = getenv("COLNDE_T16_ADJ_HELPER");     // 0: the three-wave adjoint (8 simulations 11.3 vs 8.2 ms)
+        h->adj_helper = !(eah && atoi(eah) == 0);
         const char* ea = getenv("COLNDE_T16_ADJ_SPLIT");
         h->adj_split = h->fwd_split && !(ea && atoi(ea) == 0);
     }
@@ -948,7 +951,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                     // the companion of the split forward: three wavefronts per tile, one per flux net, writing tile16's delta tape
                     e = rt_launch_adjoint_split(h->m, h->d_wimg, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                                 h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
-                                                h->d_t16_ztape, lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, h->d_dwtape, h->split_rich, h->stream);
+                                                h->d_t16_ztape, lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, h->d_dwtape, h->split_rich, h->adj_helper, h->stream);
                 else
                 e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
                                               h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,

@@ -32,7 +32,7 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
 size_t rt_split_rich_record_floats();   // floats per (tile, step, stage) of the net-split kernels' rich tape (which then takes the place of t16_ztape)
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
-                                   int n_col, float* dwtape, bool rich, hipStream_t stream);
+                                   int n_col, float* dwtape, bool rich, bool use_helper, hipStream_t stream);
 bool rt_forward_is32();   // COLNDE_RT_FWD=32 in the environment (read when a handle is created)
 size_t rt_adjoint_lds_bytes();
 size_t rt_tape_floats(int n_col, int n_steps);

@@ -2530,6 +2530,345 @@ rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// The net-split adjoint with a FOURTH wavefront.  In rt16s_adjoint_kernel every net wave carries the whole state of the adjoint — λ, x̄, the
+// stage cotangent, the physics pullback — in three bit-identical copies.  Here ONE wave (the helper, on the workgroup's fourth SIMD) carries
+// it: per stage it forms k̄ = cwl λ + cwx x̄, runs the physics pullback once and hands the three dO over through LDS (barrier B); the net waves
+// back-propagate their nets from dO_n, write the delta-tape record and their W1_n^T δz1_n parts to LDS (barrier A); the helper sums the
+// parts into x̄.  While the helper works (between A and B) the net waves do what depends on the tapes alone: next stage's prefetch, this
+// stage's activations, the record's x and a parts.  Every wave executes exactly the barriers B and A in every stage.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, bool RICH>
+__global__ void __launch_bounds__(256)
+rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ save_times, int n_save, int substeps,
+                      const float* __restrict__ sol, const float* __restrict__ truth, const float* __restrict__ t16_tape,
+                      const float* __restrict__ t16_ztape, LossWeights lw, float* __restrict__ slab, int n_col,
+                      float* __restrict__ dwtape) {
+    float* wl = rt_smem;
+    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += 256) wl[e] = wimg[e];
+    float* lbase = rt_smem + ((RT_IMG_FLOATS + 3) & ~3);
+    f32x4v* ex = reinterpret_cast<f32x4v*>(lbase);                    // the nets' parts of x̄: [3 nets][6 tiles][64 lanes]
+    f32x4v* dOl = ex + 3 * 6 * 64;                                     // the helper's dO: [3 variables][2 tiles][64 lanes]
+    float* stg_all = lbase + (3 * 6 * 64 + 3 * 2 * 64) * 4;           // record staging: see rt16s_adjoint_kernel
+    for (int e = threadIdx.x; e < 3 * RT16S_STG; e += 256) stg_all[e] = 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool helper = role == 3;
+    const int n = helper ? 0 : role;                                    // the net of a net wave
+    const int j = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x;
+    const int col = tile * 16 + j;
+    const bool valid = col < n_col;
+    const int colc = min(col, n_col - 1);
+    const int n_steps = (n_save - 1) * substeps;
+    const float* tp = t16_tape + (size_t)tile * n_steps * 4 * 1536 + j * 96 + 4 * g;
+    const bool phys = m.mpp || m.ca;
+    float* out = slab + (size_t)tile * (m.n_params + 8);
+
+    if (helper) {
+        // ================================================= the helper wave: λ, x̄, loss injection, physics pullback ======================
+        const float* tzr = t16_ztape + (size_t)tile * n_steps * 4 * RT16S_RREC + lane * 4;             // RICH: the rich tape
+        V16 lam[3], xb[3], xbs[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int tau = 0; tau < 2; tau++) { lam[q].t[tau] = (f32x4t)(0.0f); xb[q].t[tau] = (f32x4t)(0.0f); xbs[q].t[tau] = (f32x4t)(0.0f); }
+        float sum_d[3] = {0.0f, 0.0f, 0.0f}, sum_g[3] = {0.0f, 0.0f, 0.0f};
+        auto inject = [&](int sv, bool add) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                V16 d;
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) {
+                    const size_t o = ((size_t)colc * n_save + sv) * 96 + q * 32 + 16 * tau + 4 * g;
+                    const f32x4v a = *reinterpret_cast<const f32x4v*>(sol + o);
+                    const f32x4v b = *reinterpret_cast<const f32x4v*>(truth + o);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) d.t[tau][e] = valid ? a[e] - b[e] : 0.0f;
+                }
+                const V16 dd = shift_down16(d, lane, 0.0f);
+                V16 gg;
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        gg.t[tau][r] = (tau == 0 && r == 0 && g == 0) ? 0.0f : (d.t[tau][r] - dd.t[tau][r]) * 32.0f;
+                        sum_d[q] += d.t[tau][r] * d.t[tau][r];
+                        sum_g[q] += gg.t[tau][r] * gg.t[tau][r];
+                    }
+                if (add) {
+                    const V16 gu_ = shift_up16(gg, lane, 0.0f);
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            lam[q].t[tau][r] += 2.0f * lw.w[q] * d.t[tau][r] + 2.0f * lw.w[3 + q] * 32.0f * (gg.t[tau][r] - gu_.t[tau][r]);
+                }
+            }
+        };
+        // what the pullback reads from the tapes, one stage ahead: RICH the nine coefficients, otherwise the stage input
+        PhysC Pp;
+        V16 Xp[3];
+        auto prefetch = [&](int qs) __attribute__((always_inline)) {
+            if (RICH) {
+                if (phys) {
+                    const float* sr = tzr + (size_t)qs * RT16S_RREC;
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) {
+                        Pp.dn0.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 0 + tau) * 256);
+                        Pp.dn1.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 2 + tau) * 256);
+                        Pp.dn2.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 4 + tau) * 256);
+                        Pp.nu0.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 6 + tau) * 256);
+                        Pp.nu1.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 8 + tau) * 256);
+                        Pp.nu2.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 10 + tau) * 256);
+                        Pp.c0.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 12 + tau) * 256);
+                        Pp.c1.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 14 + tau) * 256);
+                        Pp.c2.t[tau] = *reinterpret_cast<const f32x4v*>(sr + (36 + 16 + tau) * 256);
+                    }
+                }
+            } else {
+                const float* sx = tp + (size_t)qs * 1536;
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) Xp[q].t[tau] = *reinterpret_cast<const f32x4v*>(sx + q * 32 + 16 * tau);
+            }
+        };
+        inject(0, false);
+        prefetch(n_steps * 4 - 1);
+        for (int iv = n_save - 2; iv >= 0; iv--) {
+            const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
+            inject(iv + 1, true);
+            for (int s = substeps - 1; s >= 0; s--) {
+                const int step = iv * substeps + s;
+#pragma nounroll
+                for (int st = 3; st >= 0; st--) {
+                    const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
+                    const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
+                    const int qs = step * 4 + st;
+                    V16 kb[3], xbp[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++) kb[q].t[tau] = cwl * lam[q].t[tau] + cwx * xb[q].t[tau];
+                    if (RICH) {
+                        rt16_physics_apply(m, Pp, kb, lane, xbp);                        // kb now holds dO
+                        if (qs > 0) prefetch(qs - 1);
+                    } else {
+                        V16 X[3];
+#pragma unroll
+                        for (int q = 0; q < 3; q++) X[q] = Xp[q];
+                        if (qs > 0) prefetch(qs - 1);
+                        rt16_physics_vjp(m, X, kb, lane, xbp);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++) dOl[(q * 2 + tau) * 64 + lane] = kb[q].t[tau];
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (B) dO is in LDS
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (A) the nets' parts of x̄ are in LDS
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+#pragma unroll
+                        for (int tau = 0; tau < 2; tau++) {
+                            const f32x4v c0 = ex[(0 * 6 + q * 2 + tau) * 64 + lane], c1 = ex[(1 * 6 + q * 2 + tau) * 64 + lane],
+                                         c2 = ex[(2 * 6 + q * 2 + tau) * 64 + lane];
+                            xb[q].t[tau] = xbp[q].t[tau] + ((c0 + c1) + c2);
+                            xbs[q].t[tau] += xb[q].t[tau];
+                        }
+                }
+                // λ_n = λ_{n+1} + x̄_1 + x̄_2 + x̄_3 + x̄_4
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) { lam[q].t[tau] += xbs[q].t[tau]; xbs[q].t[tau] = (f32x4t)(0.0f); }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            float sd = sum_d[q], sg = sum_g[q];
+            for (int off = 32; off > 0; off >>= 1) { sd += __shfl_down(sd, off); sg += __shfl_down(sg, off); }
+            if (lane == 0) { out[m.n_params + q] = sd; out[m.n_params + 3 + q] = sg; }
+        }
+        if (lane == 0) { out[m.n_params + 6] = 0.0f; out[m.n_params + 7] = 0.0f; }
+        return;
+    }
+
+    // ===================================================== the three net waves ========================================================
+    float* stg = stg_all + n * RT16S_STG;
+    const int i_ = lane & 15, g_i = i_ >> 2, r_i = i_ & 3;
+    int b3T[2], b2T[4];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int Q2 = 4 * u + r_i;
+        b3T[u] = RT_W3C + (n * 31 + 4 * g - 1) * RT_LD3 + (Q2 < 5 ? 4 * Q2 + g_i : 20);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int Q = 4 * t + r_i, f = 4 * Q + g_i;
+        b2T[t] = RT_W2C + (n * 20 + g) * RT_LD2 + ((Q < 13 && f < 50) ? f : 50);
+    }
+    const int b1T = RT_W1C + (n * 50 + g) * RT_LD1 + i_;
+    f32x4t gb1[4], gb2[2], gb3[2];                         // bias gradients: this lane's column of every delta, summed over the stages
+#pragma unroll
+    for (int t = 0; t < 4; t++) gb1[t] = (f32x4t)(0.0f);
+#pragma unroll
+    for (int u = 0; u < 2; u++) { gb2[u] = (f32x4t)(0.0f); gb3[u] = (f32x4t)(0.0f); }
+    const float* tz = RICH ? t16_ztape + (size_t)tile * n_steps * 4 * RT16S_RREC + lane * 4
+                           : t16_ztape + (size_t)tile * n_steps * 4 * RT16S_ZREC + j * 216 + n * 72 + g;
+    float* rec0 = dwtape + (size_t)tile * n_steps * 4 * RT16S_REC;
+    int stg_rd[11], rec_wr[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+        const int e = 64 * i + lane, c = e / 44, f4 = e - 44 * c;
+        stg_rd[i] = c * 180 + 4 * f4;
+        rec_wr[i] = c * 720 + 96 + (f4 < 18 ? n * 104 + 4 * f4 : (3 + n) * 104 + 4 * (f4 - 18));
+    }
+    float* sw = stg + j * 180 + g;
+    // this net's tape data, one stage ahead: variable n of the stage input, and the activations with their derivatives (RICH) or the
+    // pre-activations they are evaluated from
+    V16 Xnp;
+    float z1p[13], z2p[5];
+    f32x4t adp[12];
+    auto prefetch = [&](int qs) __attribute__((always_inline)) {
+        const float* sx = tp + (size_t)qs * 1536;
+#pragma unroll
+        for (int tau = 0; tau < 2; tau++) Xnp.t[tau] = *reinterpret_cast<const f32x4v*>(sx + n * 32 + 16 * tau);
+        if (RICH) {
+            const float* sr = tz + (size_t)qs * RT16S_RREC;
+#pragma unroll
+            for (int e = 0; e < 12; e++) adp[e] = *reinterpret_cast<const f32x4v*>(sr + (n * 12 + e) * 256);
+        } else {
+            const float* sz = tz + (size_t)qs * RT16S_ZREC;
+#pragma unroll
+            for (int Q = 0; Q < 13; Q++) z1p[Q] = (Q < 12 || g < 2) ? sz[4 * Q] : 0.0f;
+#pragma unroll
+            for (int Q2 = 0; Q2 < 5; Q2++) z2p[Q2] = sz[52 + 4 * Q2];
+        }
+    };
+    prefetch(n_steps * 4 - 1);
+    for (int iv = n_save - 2; iv >= 0; iv--) {
+        for (int s = substeps - 1; s >= 0; s--) {
+            const int step = iv * substeps + s;
+#pragma nounroll
+            for (int st = 3; st >= 0; st--) {
+                const int qs = step * 4 + st;
+                // ---- before (B), beside the helper's pullback: everything that depends on the tapes alone ----
+                f32x4t A1[4], D1[4], A2[2], D2[2];
+                const V16 Xme = Xnp;
+                if (RICH) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { A1[t] = adp[t]; D1[t] = adp[4 + t]; }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) { A2[u] = adp[8 + u]; D2[u] = adp[10 + u]; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        f32x4t z;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) z[r] = (4 * t + r < 13) ? z1p[(4 * t + r) < 13 ? 4 * t + r : 0] : 0.0f;
+                        rt16_act_pair<ACT>(z, A1[t], D1[t]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        f32x4t z;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) z[r] = (4 * u + r < 5) ? z2p[(4 * u + r) < 5 ? 4 * u + r : 0] : 0.0f;
+                        rt16_act_pair<ACT>(z, A2[u], D2[u]);
+                    }
+#pragma unroll
+                    for (int r = 1; r < 4; r++) { D1[3][r] = 0.0f; D2[1][r] = 0.0f; }   // padding quads: Q >= 13, Q2 >= 5
+                    if (g >= 2) D1[3][0] = 0.0f;                                         // features 50, 51 of quad 12
+                }
+                if (qs > 0) prefetch(qs - 1);
+                float a3[2][8], a2[4][5];
+                rt16_fetch_ops<2, 8>(wl, a3, [&](int u, int k) { return b3T[u] + (16 * (k >> 2) + (k & 3)) * RT_LD3; });
+                rt16_fetch_ops<4, 5>(wl, a2, [&](int t, int k) { return b2T[t] + 4 * k * RT_LD2; });
+                float* rec = rec0 + (size_t)qs * RT16S_REC;
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(rec + j * 720 + n * 32 + 16 * tau + 4 * g) = Xme.t[tau];
+#pragma unroll
+                for (int Q = 0; Q < 13; Q++)
+                    if (Q < 12 || g < 2) sw[4 * Q] = A1[Q >> 2][Q & 3];
+#pragma unroll
+                for (int Q2 = 0; Q2 < 5; Q2++) sw[52 + 4 * Q2] = A2[Q2 >> 2][Q2 & 3];
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // (B) the helper's dO is in LDS
+                V16 dO;
+#pragma unroll
+                for (int tau = 0; tau < 2; tau++) dO.t[tau] = dOl[(n * 2 + tau) * 64 + lane];
+                // (3) δz2 = (W3^T dO) ∘ act'(z2)
+                f32x4t dZ2[2] = {(f32x4t)(0.0f), (f32x4t)(0.0f)};
+                rt16_run_ops<2, 8>(a3, dZ2, [&](int k) { return dO.t[k >> 2][k & 3]; });
+#pragma unroll
+                for (int u = 0; u < 2; u++) dZ2[u] *= D2[u];
+                float a1[2][2][13];
+                rt16_fetch_ops<2, 13>(wl, a1[0], [&](int c, int k) { return b1T + 16 * c + 4 * k * RT_LD1; });
+                RT_SCHED_HARD();
+                // (4) δz1 = (W2^T δz2) ∘ act'(z1)
+                f32x4t dZ1[4] = {(f32x4t)(0.0f), (f32x4t)(0.0f), (f32x4t)(0.0f), (f32x4t)(0.0f)};
+                rt16_run_ops<4, 5>(a2, dZ1, [&](int k) { return dZ2[k >> 2][k & 3]; });
+#pragma unroll
+                for (int t = 0; t < 4; t++) dZ1[t] *= D1[t];
+                {
+#pragma unroll
+                    for (int Q = 0; Q < 13; Q++)
+                        if (Q < 12 || g < 2) sw[72 + 4 * Q] = dZ1[Q >> 2][Q & 3];
+#pragma unroll
+                    for (int Q2 = 0; Q2 < 5; Q2++) sw[124 + 4 * Q2] = dZ2[Q2 >> 2][Q2 & 3];
+                    float* s3 = stg + j * 180 + 144 + 4 * g - 1;                         // output o = face - 1
+#pragma unroll
+                    for (int v = 0; v < 2; v++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (!(v == 0 && r == 0 && g == 0)) s3[16 * v + r] = dO.t[v][r];
+#pragma unroll
+                    for (int i = 0; i < 11; i++) *reinterpret_cast<f32x4v*>(rec + rec_wr[i]) = *reinterpret_cast<const f32x4v*>(stg + stg_rd[i]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) gb1[t] += dZ1[t];
+#pragma unroll
+                for (int u = 0; u < 2; u++) { gb2[u] += dZ2[u]; gb3[u] += dO.t[u]; }
+                // (5) this net's part of the state cotangent, W1_n^T δz1 (6 tiles x 13 k-steps)
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    if (q < 2) rt16_fetch_ops<2, 13>(wl, a1[(q + 1) & 1], [&](int c, int k) { return b1T + 32 * (q + 1) + 16 * c + 4 * k * RT_LD1; });
+                    RT_SCHED_HARD();
+                    f32x4t c2[2] = {(f32x4t)(0.0f), (f32x4t)(0.0f)};
+                    rt16_run_ops<2, 13>(a1[q & 1], c2, [&](int k) { return dZ1[k >> 2][k & 3]; });
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) ex[(n * 6 + q * 2 + tau) * 64 + lane] = c2[tau];
+                    RT_SCHED_HARD();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // (A) this net's part of x̄ is in LDS
+            }
+        }
+    }
+    // ---- the tile's slab row: bias gradients of net n (sums over the 16 columns = the lanes of a g-group); the loss sums are the helper's ----
+    auto colsum = [&](float v) {
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        return v;
+    };
+#pragma unroll
+    for (int Q = 0; Q < 13; Q++) {
+        const float v = colsum(gb1[Q >> 2][Q & 3]);
+        if (j == 0 && (Q < 12 || g < 2)) out[n * m.net_size + m.b_off[0] + 4 * Q + g] = v;
+    }
+#pragma unroll
+    for (int Q2 = 0; Q2 < 5; Q2++) {
+        const float v = colsum(gb2[Q2 >> 2][Q2 & 3]);
+        if (j == 0) out[n * m.net_size + m.b_off[1] + 4 * Q2 + g] = v;
+    }
+#pragma unroll
+    for (int v_ = 0; v_ < 2; v_++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = colsum(gb3[v_][r]);
+            const int face = 16 * v_ + 4 * g + r;
+            if (j == 0 && face >= 1) out[n * m.net_size + m.b_off[2] + face - 1] = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 bool rt_supported(const DevModel& m) {
@@ -2594,16 +2933,28 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt_dw1_kernel);
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -2700,15 +3051,19 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
 
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
-                                   int n_col, float* dwtape, bool rich, hipStream_t stream) {
+                                   int n_col, float* dwtape, bool rich, bool use_helper, hipStream_t stream) {
     // the record formats this kernel reads and writes are tile16's for exactly this shape
     if (!rt_supported(m) || dwtape_row_floats(m) * CT != RT16S_REC || t16_ztape_col_floats(m) * CT != RT16S_ZREC || m.nst != 4)
         return hipErrorInvalidValue;
     const size_t lds = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + 2 * (3 * 6 * 64) * 16 + 3 * RT16S_STG * sizeof(float);
     const dim3 grid((n_col + 15) / 16), block(192);
+    const size_t ldsh = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + (3 * 6 * 64 + 3 * 2 * 64) * 16 + 3 * RT16S_STG * sizeof(float);
+    const dim3 blockh(256);
 #define RT_ADJS(A)                                                                                                                              \
     do {                                                                                                                                        \
-        if (rich) hipLaunchKernelGGL((rt16s_adjoint_kernel<A, true>), grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        if (use_helper && rich) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else if (use_helper) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else if (rich) hipLaunchKernelGGL((rt16s_adjoint_kernel<A, true>), grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else hipLaunchKernelGGL((rt16s_adjoint_kernel<A, false>), grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
     } while (0)
     switch (m.acts[0]) {

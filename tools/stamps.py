@@ -6,6 +6,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import colnde
 from colnde import _lib, synthetic
+# (the net-split kernels' stamps live in the three-wave variants: the four-wave ones carry none)
+os.environ.setdefault("COLNDE_T16_FWD_HELPER", "0")
+os.environ.setdefault("COLNDE_T16_ADJ_HELPER", "0")
 FWD = "--fwd" in sys.argv      # forward-kernel stamps: build with -DCOLNDE_STAMPS -DCOLNDE_STAMPS_FWD into libcolnde_stamps_fwd.so
 if FWD: sys.argv.remove("--fwd")
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcolnde_stamps_fwd.so" if FWD else "libcolnde_stamps.so")
