@@ -2747,12 +2747,14 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
         }
     };
     prefetch(n_steps * 4 - 1);
+    RT_STAMP_DECL;
     for (int iv = n_save - 2; iv >= 0; iv--) {
         for (int s = substeps - 1; s >= 0; s--) {
             const int step = iv * substeps + s;
 #pragma nounroll
             for (int st = 3; st >= 0; st--) {
                 const int qs = step * 4 + st;
+                RT_STAMP_BEGIN();
                 // ---- before (B), beside the helper's pullback: everything that depends on the tapes alone ----
                 f32x4t A1[4], D1[4], A2[2], D2[2];
                 const V16 Xme = Xnp;
@@ -2792,7 +2794,9 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                     if (Q < 12 || g < 2) sw[4 * Q] = A1[Q >> 2][Q & 3];
 #pragma unroll
                 for (int Q2 = 0; Q2 < 5; Q2++) sw[52 + 4 * Q2] = A2[Q2 >> 2][Q2 & 3];
+                RT_STAMP(0);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // (B) the helper's dO is in LDS
+                RT_STAMP(1);
                 V16 dO;
 #pragma unroll
                 for (int tau = 0; tau < 2; tau++) dO.t[tau] = dOl[(n * 2 + tau) * 64 + lane];
@@ -2809,6 +2813,7 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                 rt16_run_ops<4, 5>(a2, dZ1, [&](int k) { return dZ2[k >> 2][k & 3]; });
 #pragma unroll
                 for (int t = 0; t < 4; t++) dZ1[t] *= D1[t];
+                RT_STAMP(2);
                 {
 #pragma unroll
                     for (int Q = 0; Q < 13; Q++)
@@ -2828,6 +2833,7 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                 for (int t = 0; t < 4; t++) gb1[t] += dZ1[t];
 #pragma unroll
                 for (int u = 0; u < 2; u++) { gb2[u] += dZ2[u]; gb3[u] += dO.t[u]; }
+                RT_STAMP(3);
                 // (5) this net's part of the state cotangent, W1_n^T δz1 (6 tiles x 13 k-steps)
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
@@ -2839,10 +2845,15 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                     for (int tau = 0; tau < 2; tau++) ex[(n * 6 + q * 2 + tau) * 64 + lane] = c2[tau];
                     RT_SCHED_HARD();
                 }
+                RT_STAMP(4);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // (A) this net's part of x̄ is in LDS
+                RT_STAMP(5);
             }
         }
     }
+#ifndef COLNDE_STAMPS_FWD
+    RT_STAMP_FLUSH();
+#endif
     // ---- the tile's slab row: bias gradients of net n (sums over the 16 columns = the lanes of a g-group); the loss sums are the helper's ----
     auto colsum = [&](float v) {
         v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);

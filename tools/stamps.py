@@ -8,7 +8,6 @@ import colnde
 from colnde import _lib, synthetic
 # (the net-split kernels' stamps live in the three-wave variants: the four-wave ones carry none)
 os.environ.setdefault("COLNDE_T16_FWD_HELPER", "0")
-os.environ.setdefault("COLNDE_T16_ADJ_HELPER", "0")
 FWD = "--fwd" in sys.argv      # forward-kernel stamps: build with -DCOLNDE_STAMPS -DCOLNDE_STAMPS_FWD into libcolnde_stamps_fwd.so
 if FWD: sys.argv.remove("--fwd")
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcolnde_stamps_fwd.so" if FWD else "libcolnde_stamps.so")
@@ -31,6 +30,9 @@ SPLIT = nde.engine == 1 and not FC64 and os.environ.get("COLNDE_T16_FWD_SPLIT", 
 if SPLIT and FWD:
     names = ["x tape store + top flux", "layer 1 (4 chains, activation, tape stores)", "layers 2, 3", "physics (flux, tendency, coefficients)",
              "RK4 bookkeeping + exchange + barrier"]
+elif SPLIT and os.environ.get("COLNDE_T16_ADJ_HELPER", "1") != "0":        # the four-wave adjoint: net wave 0's segments
+    names = ["tape-only work before (B): activations, x / a parts, operand fetch", "wait at (B) for the helper's dO", "W3^T and W2^T chains",
+             "delta stores + bias sums", "W1^T chains + part write", "wait at (A)"]
 elif SPLIT:        # net-split kernels of the latency points (wave 0 = net 0)
     names = ["prefetch issue + kbar + physics pullback", "activation pairs + x / a stores", "W3^T and W2^T chains", "delta stores + bias sums",
              "W1^T chains + exchange write", "barrier + sum of the three parts"]
