@@ -861,10 +861,11 @@ static int t16_plan_dwtape(colnde_handle* h) {
         }
     }
     const char* ezt = getenv("COLNDE_T16_ZTAPE");
-    // net-split kernels on a small block (<= 1,024 columns, where it pays: 64-step iteration 2.91 vs 3.01 ms at 1,024 columns, 3.28 vs 3.29 at 2,048, 4.05 vs 3.96 at 4,096): the rich tape in place of the pre-activations
+    // net-split kernels on a small block (<= 2,048 columns, where it pays: 64-step iteration with the four-wave kernels 2.36 vs 2.48 ms at 1,024
+    // columns, 2.69 vs 2.77 at 2,048, 3.99 vs 3.53 at 4,096): the rich tape in place of the pre-activations
     {
         const char* er = getenv("COLNDE_T16_SPLIT_RICH");
-        const bool want_rich = h->adj_split && !(ezt && atoi(ezt) == 0) && (er ? atoi(er) != 0 : tiles_b <= 64);
+        const bool want_rich = h->adj_split && !(ezt && atoi(ezt) == 0) && (er ? atoi(er) != 0 : tiles_b <= 128);
         if (want_rich && hipMalloc((void**)&h->d_t16_ztape, n_rec * rt_split_rich_record_floats() * sizeof(float)) == hipSuccess) {
             h->split_rich = true;
             return 0;

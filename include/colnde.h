@@ -207,7 +207,7 @@ int  colnde_allreduce_result_dev(colnde_handle* h, colnde_comm* comm, float* d_o
  * pre-activations taped (1) or recomputed (0), [4] tile16: weight gradients taped (1) or accumulated in registers (0),
  * [5] tile16 taped mode: K-slices of the dW GEMM, [6] net-split kernels of the latency points (three wavefronts per 16-column tile,
  * one per flux net): bit 0 = forward solve, bit 1 = adjoint, bit 2 = with the rich tape (activations, their derivatives and the physics-pullback
- * coefficients taped by the forward kernel: blocks of at most 1,024 columns), [7] reserved (0). */
+ * coefficients taped by the forward kernel: blocks of at most 2,048 columns), [7] reserved (0). */
 int colnde_plan(const colnde_handle* h, int info[8]);
 
 /* ---- measurement: HIP-event timing of the handle's kernels on its stream.

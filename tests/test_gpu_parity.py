@@ -429,7 +429,7 @@ def test_split_kernels_against_oracle_and_tile16(name, monkeypatch):
 @pytest.mark.parametrize("name", ["mpp_zero_weights", "conv_adj_branch", "raw", "relu"])
 def test_split_kernels_plain_tape(name, monkeypatch):
     """COLNDE_T16_SPLIT_RICH=0: the net-split adjoint recomputes activation pairs and the physics closure from the pre-activation and stage
-    tapes (what blocks above 1,024 columns take) instead of reading them from the rich tape; same oracle tolerances, and the two agree."""
+    tapes (what blocks above 2,048 columns take) instead of reading them from the rich tape; same oracle tolerances, and the two agree."""
     p = synthetic.wind_mixing_problem(40, n_frames=9, weight_divisor=1e2, **VARIANTS[name])
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
     sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
