@@ -57,7 +57,7 @@ struct colnde_handle {
     bool fwd_helper = true;         // ... four waves per tile: a helper wave evaluates the Richardson-number closure for the three net waves
     bool split_rich = false;        // ... with the rich tape (activations, derivatives, physics coefficients) in place of the pre-activation tape
     bool adj_split = false;         // ... and the gradient by rt16s_adjoint_kernel + tile16's dW GEMM
-    bool fwd_split = false;         // forward solves by rt16s_forward_kernel (three waves per tile) beside the tile16 adjoint
+    bool fwd_split = false;         // forward solves by the net-split kernels (rt16sh_forward_kernel: three net waves + a helper wave per tile)
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
     float* d_wimg = nullptr;
     float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_tapez = nullptr;
@@ -380,12 +380,12 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     }
     // AUTO: regtile where it applies, except for problems of at most 8,192 columns (two rounds of one 16-column tile per CU).  Those
     // are latency points for regtile — 32 columns per wavefront leave most SIMDs without a wave — and go to the net-split kernels
-    // (three wavefronts per 16-column tile, below) with tile16's tapes and dW GEMM: 4,096 columns x 64 steps 3.98 vs 9.72 ms per
-    // iteration, 8,192: 8.03 vs 10.07, 16,384: 15.0 vs 10.9 (tools/crossover.py)
+    // (one wavefront per flux net plus a helper wavefront per 16-column tile, below) with tile16's tapes and dW GEMM: 4,096 columns x 64 steps
+    // 3.55 vs 9.48 ms per iteration, 8,192: 6.99 vs 9.84, 16,384: 12.8 vs 10.7 (tools/crossover.py)
     h->use_rt = rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine != COLNDE_ENGINE_GENERIC &&
                 (cfg->engine == COLNDE_ENGINE_MFMA || cfg->n_columns > 8192 || !h->geo_ok);
     h->rt_fwd32 = h->use_rt && rt_forward_is32();
-    // AUTO on a regtile-shaped problem too small for regtile (a latency point): the three-wave net-split kernels take the forward solves and
+    // AUTO on a regtile-shaped problem too small for regtile (a latency point): the net-split kernels take the forward solves and
     // the adjoint (8 simulations: forward 19.8 -> 8.5 ms, adjoint 25.0 -> 14.6 ms), tile16 the tapes' formats, the dW GEMM and the reduction.
     // An explicit engine = tile16 stays pure tile16; COLNDE_T16_FWD_SPLIT=0|1 and COLNDE_T16_ADJ_SPLIT=0 override.
     h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine == COLNDE_ENGINE_AUTO;
@@ -674,7 +674,7 @@ static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_
     }
     Timed tm(h, K_FORWARD);
     if (h->fwd_split) {
-        // latency points of the wind-mixing shape: three wavefronts per 16-column tile, one per flux net (engine_regtile.hip); the tapes
+        // latency points of the wind-mixing shape: one wavefront per flux net (+ a helper) per 16-column tile (engine_regtile.hip); the tapes
         // come out in tile16's formats for its taped adjoint
         hipError_t es = rt_launch_pack(h->m, d_weights, h->d_wimg, h->stream);
         if (es == hipSuccess)
@@ -949,7 +949,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                 AdjointGeom g = {512, 1, 3, 0};
                 hipError_t e;
                 if (h->adj_split && h->d_t16_ztape)
-                    // the companion of the split forward: three wavefronts per tile, one per flux net, writing tile16's delta tape
+                    // the companion of the split forward: one wavefront per flux net (+ a helper) per tile, writing tile16's delta tape
                     e = rt_launch_adjoint_split(h->m, h->d_wimg, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                                 h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
                                                 h->d_t16_ztape, lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, h->d_dwtape, h->split_rich, h->adj_helper, h->stream);
