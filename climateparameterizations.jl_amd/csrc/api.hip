@@ -386,7 +386,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
                 (cfg->engine == COLNDE_ENGINE_MFMA || cfg->n_columns > 8192 || !h->geo_ok);
     h->rt_fwd32 = h->use_rt && rt_forward_is32();
     // AUTO on a regtile-shaped problem too small for regtile (a latency point): the net-split kernels take the forward solves and
-    // the adjoint (8 simulations: forward 19.8 -> 8.5 ms, adjoint 25.0 -> 14.6 ms), tile16 the tapes' formats, the dW GEMM and the reduction.
+    // the adjoint (8 simulations: forward 19.8 -> 8.3 ms, adjoint 25.0 -> 8.2 ms), tile16 the tapes' formats, the dW GEMM and the reduction.
     // An explicit engine = tile16 stays pure tile16; COLNDE_T16_FWD_SPLIT=0|1 and COLNDE_T16_ADJ_SPLIT=0 override.
     h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine == COLNDE_ENGINE_AUTO;
     {
