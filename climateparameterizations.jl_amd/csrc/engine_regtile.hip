@@ -1175,6 +1175,7 @@ __device__ __forceinline__ f32x4t rt16_chain(const float* wl, f32x4t acc, AF aid
     for (int u = 0; u < CH; u++)
         if (u < N) a[0][u] = wl[aidx(u)];
     RT_SCHED_FENCE();
+    __builtin_amdgcn_s_setprio(1);      // two waves share a SIMD in rt16_forward_kernel: the one inside a chain issues first (35.0 -> 34.3 ms)
 #pragma unroll
     for (int c = 0; c * CH < N; c++) {
 #pragma unroll
@@ -1185,6 +1186,7 @@ __device__ __forceinline__ f32x4t rt16_chain(const float* wl, f32x4t acc, AF aid
             if (c * CH + u < N) acc = mfma16t(a[c & 1][u], bval(c * CH + u), acc);
         RT_SCHED_FENCE();
     }
+    __builtin_amdgcn_s_setprio(0);
     return acc;
 }
 
