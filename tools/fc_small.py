@@ -1,7 +1,9 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, colnde
-from colnde import synthetic
+from colnde import synthetic, _lib
+if os.environ.get("COLNDE_LIB"):      # A/B aid: another build of the library
+    _lib.LIB_PATH = os.path.join(os.getcwd(), "climateparameterizations.jl_amd", os.environ["COLNDE_LIB"])
 for Nz in (32, 64):
   for ncol in (8, 64):
     p = synthetic.free_convection_problem(ncol, Nz=Nz)
