@@ -38,6 +38,8 @@ SYMBOLS = [
     ("colnde_infer_forcing_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
     ("colnde_convective_adjustment", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, ctypes.c_float, ctypes.c_float, _V, ctypes.c_int]),
     ("colnde_convective_adjustment_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, ctypes.c_float, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_implicit_diffusion", ctypes.c_int, [_V, _V, _V, _V, _V, ctypes.c_float, ctypes.c_float, _F, ctypes.c_int, _V, _V, _V, ctypes.c_int]),
+    ("colnde_implicit_diffusion_dev", ctypes.c_int, [_V, _V, _V, _V, _V, ctypes.c_float, ctypes.c_float, _F, ctypes.c_int, _V, _V, _V, ctypes.c_int]),
     ("colnde_adam_step_dev", ctypes.c_int, [_V, _V, _V, _V, _V] + [ctypes.c_float] * 6 + [ctypes.c_int]),
     ("colnde_pretrain_flux_dev", ctypes.c_int, [_V, ctypes.c_int, _V, _V, _V, _V, _V, _V, _V, ctypes.c_int] + [ctypes.c_float] * 5 +
      [ctypes.POINTER(ctypes.c_double), ctypes.c_int, _F]),

@@ -35,7 +35,7 @@ extern "C" int colnde_internal_set_error(const char* msg) { g_err = msg ? msg : 
         if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-enum { K_FORWARD = 0, K_ADJOINT = 1, K_REDUCE = 2, K_RHS = 3, K_INFER = 4, K_DW1 = 5, K_CONVADJ = 6, K_ADAM = 7, K_COUNT = 8 };
+enum { K_FORWARD = 0, K_ADJOINT = 1, K_REDUCE = 2, K_RHS = 3, K_INFER = 4, K_DW1 = 5, K_CONVADJ = 6, K_ADAM = 7, K_IMPLDIFF = 8, K_COUNT = 9 };
 
 struct PendingEvent { hipEvent_t a, b; int which; };
 
@@ -84,8 +84,8 @@ struct colnde_handle {
     int min_substeps = 1;           // least RK4 sub-steps per save interval inside the diffusive stability bound
     float* d_rkc = nullptr;         // RKC2 coefficient table (DevModel::rkc)
     std::vector<PendingEvent> pending;
-    double ms[K_COUNT] = {0, 0, 0, 0, 0, 0};
-    int launches[K_COUNT] = {0, 0, 0, 0, 0, 0};
+    double ms[K_COUNT] = {};
+    int launches[K_COUNT] = {};
 };
 
 extern "C" const char* colnde_last_error(void) { return g_err.c_str(); }
@@ -1090,6 +1090,60 @@ extern "C" int colnde_convective_adjustment(colnde_handle* h, const float* T, co
     HIPCHK(hipMemcpyAsync(out, h->d_tmp_c, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
+}
+
+// modified_pacanowski_philander! (wind_mixing/src/NDE_oceananigans.jl:61-101): one implicit diffusion step of u, v, T per column
+static int impl_diff_check(colnde_handle* h, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f,
+                           float dt, float dz, const float params[7], int n_columns) {
+    if (!h) return fail("null handle");
+    if (!a || !b || !c || !d || !e || !f || !params) return fail("null pointer argument");
+    if (n_columns < 1) return fail("n_columns must be >= 1");
+    if (!(dt > 0.0f) || !(dz > 0.0f)) return fail("dt > 0 and dz > 0 required");
+    if (!(params[0] >= 0.0f) || !(params[1] >= 0.0f)) return fail("nu0 >= 0 and nu_minus >= 0 required (the tridiagonal must stay diagonally dominant)");
+    if (!(params[2] != 0.0f) || !(params[4] > 0.0f)) return fail("dRi != 0 and Pr > 0 required");
+    if (h->m.Nz < 2 || h->m.Nz > 128) return fail("implicit diffusion supports 2 <= Nz <= 128 (Nz = %d)", h->m.Nz);
+    return 0;
+}
+
+extern "C" int colnde_implicit_diffusion_dev(colnde_handle* h, const float* d_u, const float* d_v, const float* d_T,
+                                             const float* d_halo_bottom, float dt, float dz, const float params[7],
+                                             int convective_adjustment, float* d_u_out, float* d_v_out, float* d_T_out, int n_columns) {
+    if (impl_diff_check(h, d_u, d_v, d_T, d_u_out, d_v_out, d_T_out, dt, dz, params, n_columns)) return 1;
+    HIPCHK(hipSetDevice(h->device));
+    Timed tm(h, K_IMPLDIFF);
+    hipError_t e = launch_mpp_diffusion(d_u, d_v, d_T, d_halo_bottom, dt, dz, params, convective_adjustment, d_u_out, d_v_out, d_T_out,
+                                        h->m.Nz, n_columns, h->stream);
+    if (e != hipSuccess) return fail("implicit diffusion launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_implicit_diffusion(colnde_handle* h, const float* u, const float* v, const float* T, const float* halo_bottom,
+                                         float dt, float dz, const float params[7], int convective_adjustment, float* u_out,
+                                         float* v_out, float* T_out, int n_columns) {
+    if (impl_diff_check(h, u, v, T, u_out, v_out, T_out, dt, dz, params, n_columns)) return 1;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t nf = (size_t)n_columns * h->m.Nz, nh = (size_t)n_columns;
+    float* d = nullptr;       // [u | v | T | halo(3 n_col)]: a scratch of its own — the handle's are sized for its own state vector
+    HIPCHK(hipMalloc((void**)&d, (3 * nf + 3 * nh) * sizeof(float)));
+    int rc = 1;
+    do {
+        const float* srcs[3] = {u, v, T};
+        bool ok = true;
+        for (int f = 0; f < 3 && ok; f++)
+            ok = hipMemcpyAsync(d + f * nf, srcs[f], nf * sizeof(float), hipMemcpyHostToDevice, h->stream) == hipSuccess;
+        if (ok && halo_bottom) ok = hipMemcpyAsync(d + 3 * nf, halo_bottom, 3 * nh * sizeof(float), hipMemcpyHostToDevice, h->stream) == hipSuccess;
+        if (!ok) { fail("implicit diffusion: host-to-device copy failed"); break; }
+        if (colnde_implicit_diffusion_dev(h, d, d + nf, d + 2 * nf, halo_bottom ? d + 3 * nf : nullptr, dt, dz, params,
+                                          convective_adjustment, d, d + nf, d + 2 * nf, n_columns)) break;
+        float* dsts[3] = {u_out, v_out, T_out};
+        for (int f = 0; f < 3 && ok; f++)
+            ok = hipMemcpyAsync(dsts[f], d + f * nf, nf * sizeof(float), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+        if (!ok || hipStreamSynchronize(h->stream) != hipSuccess) { fail("implicit diffusion: device-to-host copy failed"); break; }
+        rc = 0;
+    } while (0);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    return rc;
 }
 
 extern "C" int colnde_adam_step_dev(colnde_handle* h, float* d_weights, const float* d_grad, float* d_m, float* d_v, float eta,

@@ -6,6 +6,11 @@
 // T, out: [n_col][Nz] float32 (in place allowed), halo_bottom / halo_top: [n_col] or null.  2 <= Nz <= 128.
 hipError_t launch_convective_adjustment(const float* T, const float* halo_bottom, const float* halo_top, float dt_over_dz2, float K,
                                         float* out, int Nz, int n_col, hipStream_t stream);
+// modified_pacanowski_philander! (wind_mixing/src/NDE_oceananigans.jl:61-101): u, v, T and the outputs [n_col][Nz] (in place allowed field by
+// field), halo_bottom [3][n_col] (u, v, T halo cells below k = 0) or null, params = {nu0, nu_minus, dRi, Ric, Pr, alpha, g}.  2 <= Nz <= 128.
+hipError_t launch_mpp_diffusion(const float* u, const float* v, const float* T, const float* halo_bottom, float dt, float dz,
+                                const float params[7], int convective_adjustment, float* uo, float* vo, float* To, int Nz, int n_col,
+                                hipStream_t stream);
 hipError_t launch_adam_step(float* w, const float* grad, float* m, float* v, float eta, float beta1, float beta2, float eps,
                             float beta1_t, float beta2_t, int n, hipStream_t stream);
 // data preparation: rows are profiles ([n_rows][N] -> [n_rows][n]); face = 0: block means, 1: linear interpolation keeping the end points

@@ -209,3 +209,220 @@ hipError_t launch_zscore_scale(const float* x, long count, const float* mu_sigma
     hipLaunchKernelGGL(zscore_scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, x, count, mu_sigma, out);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// modified_pacanowski_philander!(model, constants, Δt, p, convective_adjustment): wind_mixing/src/NDE_oceananigans.jl:61-101, with
+// the face diffusivities of modified_pacanowski_philander_diffusivity (:17-58).  Per column, one backward-Euler diffusion step of
+// u, v (shared matrix) and T:
+//     Ri_k = gα (T_k − T_{k−1}) Δz / ((u_k − u_{k−1})² + (v_k − v_{k−1})²)          (Oceanostics 0.3.2 richardson_number_ccf!, the
+//            (Center, Center, Face) ratio ∂z b / ((∂z u)² + (∂z v)²) with b = gαT; third-party, pinned in wind_mixing/Manifest.toml:1279)
+//     ν_k  = ν₀ + ν₋ tanh_step((Ri_k − Riᶜ)/ΔRi) on the interior faces, 0 on face 0 (:45-47);   tanh_step(x) = (1 − tanh x)/2
+//     νT_k = convective_adjustment ? (Ri_k > 0 ? ν_k/Pr : 1) : ν_k/Pr  on EVERY face (:49-55; face 0 sees the halo cells)
+//     lower_k = −c ν_k,  diag_k = 1 + c (ν_k + ν_{k+1}) (k < Nz−1),  diag_{Nz−1} = 1 + c ν_{Nz−1},  upper_k = −c ν_{k+1},  c = Δt/Δz²
+//     u′ = L_ν \ u,  v′ = L_ν \ v,  T′ = L_νT \ T,  then T′_0 = T_0 (`T′[1] = T_bottom`, :94).
+// The same strictly diagonally dominant tridiagonal as convadj_kernel: the Thomas recurrence is the reference's LU without pivoting.
+// tanh_step is evaluated as 1/(1 + e^{2x}) (one v_exp + one v_rcp; exact limits 0 / 1 at Ri = ±∞, NaN stays NaN as in the reference,
+// which a face with no shear AND no stratification produces: 0/0).
+//
+// HBM-bound: 2·3·4·Nz bytes per column (768 B at Nz = 32), ≈ 60 flop per level.  One WAVE per workgroup stages 64 columns of the three
+// fields through LDS (rows padded to NZ+1: conflict-free column walks; 25 KB at Nz = 32, so six workgroups share a CU and one's solve
+// hides under the others' float4 traffic); a lane solves one column in place in LDS with the elimination factors in registers.  The T
+// system goes first: its sweep forms the face diffusivities from the still-unmodified u, v and keeps c·ν for the velocity sweep.
+// ------------------------------------------------------------------------------------------------
+typedef float co_f32x4 __attribute__((ext_vector_type(4)));
+struct MppParams { float nu0, nu_minus, inv_dRi, Ric, inv_Pr, galpha_dz, c; int ca; };
+
+// c·ν and c·νT of face k (1 <= k < Nz) from the level differences across it (du, dv, dT = upper − lower)
+__device__ __forceinline__ void mpp_face(const MppParams& P, float du, float dv, float dT, float& kv, float& kT) {
+    const float Ri = P.galpha_dz * dT / (du * du + dv * dv);
+    const float x = (Ri - P.Ric) * P.inv_dRi;
+    const float nu = P.nu0 + P.nu_minus * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+    kv = P.c * nu;
+    kT = P.ca ? (Ri > 0.0f ? kv * P.inv_Pr : P.c) : kv * P.inv_Pr;
+}
+
+template <int NZ>
+__global__ void __launch_bounds__(64) mpp_diffusion_kernel(const float* u, const float* v, const float* T,
+                                                           const float* __restrict__ halo_bottom, MppParams P, float* uo, float* vo, float* To, int n_col) {
+    extern __shared__ float cs_smem[];
+    constexpr int LD = NZ + 1, Q = NZ / 4, FS = 64 * LD;
+    const int lane = threadIdx.x;
+    const int col0 = blockIdx.x * 64;
+    const int ncol = min(64, n_col - col0);
+    const float* srcs[3] = {u, v, T};
+    float* dsts[3] = {uo, vo, To};
+    if (ncol == 64) {
+        co_f32x4 r[3][Q];
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            const co_f32x4* s = reinterpret_cast<const co_f32x4*>(srcs[f] + (size_t)col0 * NZ);
+#pragma unroll
+            for (int i = 0; i < Q; i++) r[f][i] = __builtin_nontemporal_load(s + i * 64 + lane);
+        }
+#pragma unroll
+        for (int f = 0; f < 3; f++)
+#pragma unroll
+            for (int i = 0; i < Q; i++) {
+                const int e = i * 64 + lane, cl = e / Q, k = (e % Q) * 4;
+                float* d = cs_smem + f * FS + cl * LD + k;
+                d[0] = r[f][i].x; d[1] = r[f][i].y; d[2] = r[f][i].z; d[3] = r[f][i].w;
+            }
+    } else {
+        for (int f = 0; f < 3; f++) {
+            const float4* s = reinterpret_cast<const float4*>(srcs[f] + (size_t)col0 * NZ);
+            for (int e = lane; e < ncol * Q; e += 64) {
+                const float4 q = s[e];
+                const int cl = e / Q, k = (e % Q) * 4;
+                float* d = cs_smem + f * FS + cl * LD + k;
+                d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane < ncol) {
+        float* tu = cs_smem + lane * LD;
+        float* tv = tu + FS;
+        float* tT = tv + FS;
+        float kvs[NZ], cp[NZ];
+        // face 0: ν = 0; νT under convective adjustment from the Richardson number the halo cells give (absent: zero-gradient fill,
+        // 0/0 = NaN, `NaN > 0` false: νT = 1 — what the reference computes for a flux-bounded field)
+        float u_lo = tu[0], v_lo = tv[0], T_lo = tT[0];
+        const float T_bottom = T_lo;
+        float kT_k = 0.0f;
+        kvs[0] = 0.0f;
+        if (P.ca) {
+            const size_t c = (size_t)col0 + lane;
+            const float du = halo_bottom ? u_lo - halo_bottom[c] : 0.0f;
+            const float dv = halo_bottom ? v_lo - halo_bottom[(size_t)n_col + c] : 0.0f;
+            const float dT = halo_bottom ? T_lo - halo_bottom[2 * (size_t)n_col + c] : 0.0f;
+            const float Ri0 = P.galpha_dz * dT / (du * du + dv * dv);
+            kT_k = Ri0 > 0.0f ? 0.0f : P.c;
+        }
+        // ---- T system, forming the faces one ahead of the elimination
+        float xT = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+            float kT_n = 0.0f;
+            const float T_k = T_lo;
+            if (k + 1 < NZ) {
+                const float u_hi = tu[k + 1], v_hi = tv[k + 1], T_hi = tT[k + 1];
+                mpp_face(P, u_hi - u_lo, v_hi - v_lo, T_hi - T_lo, kvs[k + 1], kT_n);
+                u_lo = u_hi; v_lo = v_hi; T_lo = T_hi;
+            }
+            const float a = -kT_k, b = 1.0f + kT_k + kT_n;
+            const float inv = 1.0f / (k == 0 ? b : b - a * cp[k - 1]);
+            cp[k] = -kT_n * inv;
+            xT = (k == 0 ? T_k : T_k - a * xT) * inv;
+            tT[k] = xT;
+            kT_k = kT_n;
+        }
+#pragma unroll
+        for (int k = NZ - 2; k >= 0; k--) { xT = tT[k] - cp[k] * xT; tT[k] = xT; }
+        tT[0] = T_bottom;
+        // ---- velocity system, two right-hand sides
+        float xu = 0.0f, xv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+            const float kn = k + 1 < NZ ? kvs[k + 1] : 0.0f;
+            const float a = -kvs[k], b = 1.0f + kvs[k] + kn;
+            const float inv = 1.0f / (k == 0 ? b : b - a * cp[k - 1]);
+            cp[k] = -kn * inv;
+            xu = (k == 0 ? tu[k] : tu[k] - a * xu) * inv;
+            xv = (k == 0 ? tv[k] : tv[k] - a * xv) * inv;
+            tu[k] = xu; tv[k] = xv;
+        }
+#pragma unroll
+        for (int k = NZ - 2; k >= 0; k--) {
+            xu = tu[k] - cp[k] * xu; tu[k] = xu;
+            xv = tv[k] - cp[k] * xv; tv[k] = xv;
+        }
+    }
+    __syncthreads();
+    if (ncol == 64) {
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            co_f32x4* dd = reinterpret_cast<co_f32x4*>(dsts[f] + (size_t)col0 * NZ);
+#pragma unroll
+            for (int i = 0; i < Q; i++) {
+                const int e = i * 64 + lane, cl = e / Q, k = (e % Q) * 4;
+                const float* d = cs_smem + f * FS + cl * LD + k;
+                const co_f32x4 q = {d[0], d[1], d[2], d[3]};
+                __builtin_nontemporal_store(q, dd + e);
+            }
+        }
+    } else {
+        for (int f = 0; f < 3; f++) {
+            float4* dd = reinterpret_cast<float4*>(dsts[f] + (size_t)col0 * NZ);
+            for (int e = lane; e < ncol * Q; e += 64) {
+                const int cl = e / Q, k = (e % Q) * 4;
+                const float* d = cs_smem + f * FS + cl * LD + k;
+                dd[e] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
+}
+
+// any 2 <= Nz <= 128 (not a multiple of 4, unaligned pointers, or none of the instantiated sizes): one thread per column from HBM
+__global__ void __launch_bounds__(64) mpp_diffusion_generic_kernel(const float* u, const float* v, const float* T, const float* __restrict__ halo_bottom,
+                                                                   MppParams P, float* uo, float* vo, float* To, int Nz, int n_col) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= n_col) return;
+    const float* pu = u + (size_t)col * Nz;
+    const float* pv = v + (size_t)col * Nz;
+    const float* pT = T + (size_t)col * Nz;
+    float kv[128], kT[128], cp[128], xa[128], xb[128];
+    kv[0] = 0.0f;
+    kT[0] = 0.0f;
+    if (P.ca) {
+        const float du = halo_bottom ? pu[0] - halo_bottom[col] : 0.0f;
+        const float dv = halo_bottom ? pv[0] - halo_bottom[(size_t)n_col + col] : 0.0f;
+        const float dT = halo_bottom ? pT[0] - halo_bottom[2 * (size_t)n_col + col] : 0.0f;
+        const float Ri0 = P.galpha_dz * dT / (du * du + dv * dv);
+        kT[0] = Ri0 > 0.0f ? 0.0f : P.c;
+    }
+    for (int k = 1; k < Nz; k++) mpp_face(P, pu[k] - pu[k - 1], pv[k] - pv[k - 1], pT[k] - pT[k - 1], kv[k], kT[k]);
+    const float T_bottom = pT[0];
+    // T
+    for (int k = 0; k < Nz; k++) {
+        const float kn = k + 1 < Nz ? kT[k + 1] : 0.0f;
+        const float a = -kT[k], b = 1.0f + kT[k] + kn;
+        const float inv = 1.0f / (k == 0 ? b : b - a * cp[k - 1]);
+        cp[k] = -kn * inv;
+        xa[k] = (k == 0 ? pT[k] : pT[k] - a * xa[k - 1]) * inv;
+    }
+    for (int k = Nz - 2; k >= 0; k--) xa[k] -= cp[k] * xa[k + 1];
+    xa[0] = T_bottom;
+    for (int k = 0; k < Nz; k++) To[(size_t)col * Nz + k] = xa[k];
+    // u, v
+    for (int k = 0; k < Nz; k++) {
+        const float kn = k + 1 < Nz ? kv[k + 1] : 0.0f;
+        const float a = -kv[k], b = 1.0f + kv[k] + kn;
+        const float inv = 1.0f / (k == 0 ? b : b - a * cp[k - 1]);
+        cp[k] = -kn * inv;
+        xa[k] = (k == 0 ? pu[k] : pu[k] - a * xa[k - 1]) * inv;
+        xb[k] = (k == 0 ? pv[k] : pv[k] - a * xb[k - 1]) * inv;
+    }
+    for (int k = Nz - 2; k >= 0; k--) { xa[k] -= cp[k] * xa[k + 1]; xb[k] -= cp[k] * xb[k + 1]; }
+    for (int k = 0; k < Nz; k++) { uo[(size_t)col * Nz + k] = xa[k]; vo[(size_t)col * Nz + k] = xb[k]; }
+}
+
+hipError_t launch_mpp_diffusion(const float* u, const float* v, const float* T, const float* halo_bottom, float dt, float dz,
+                                const float params[7], int convective_adjustment, float* uo, float* vo, float* To, int Nz, int n_col,
+                                hipStream_t stream) {
+    if (Nz < 2 || Nz > 128 || n_col < 1) return hipErrorInvalidValue;
+    MppParams P;
+    P.nu0 = params[0]; P.nu_minus = params[1]; P.inv_dRi = 1.0f / params[2]; P.Ric = params[3]; P.inv_Pr = 1.0f / params[4];
+    P.galpha_dz = params[5] * params[6] * dz;       // ∂z b / ((∂z u)² + (∂z v)²) = gα ΔT Δz / (Δu² + Δv²)
+    P.c = dt / (dz * dz);
+    P.ca = convective_adjustment ? 1 : 0;
+    const dim3 grid((n_col + 63) / 64), block(64);
+    const bool aligned = (((uintptr_t)u | (uintptr_t)v | (uintptr_t)T | (uintptr_t)uo | (uintptr_t)vo | (uintptr_t)To) & 15) == 0;
+    // in-place use is allowed field by field (uo == u etc.); any other overlap between the six arrays is the caller's error
+#define MPP_LAUNCH(N) hipLaunchKernelGGL(mpp_diffusion_kernel<N>, grid, block, 3 * 64 * (N + 1) * sizeof(float), stream, u, v, T, halo_bottom, P, uo, vo, To, n_col)
+    if (aligned && Nz == 16) MPP_LAUNCH(16);
+    else if (aligned && Nz == 32) MPP_LAUNCH(32);
+    else if (aligned && Nz == 64) MPP_LAUNCH(64);
+    else hipLaunchKernelGGL(mpp_diffusion_generic_kernel, grid, block, 0, stream, u, v, T, halo_bottom, P, uo, vo, To, Nz, n_col);
+#undef MPP_LAUNCH
+    return hipGetLastError();
+}

@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from .config import NDEConfig, to_c_config
 
-KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4, "dw1": 5, "convadj": 6, "adam": 7}
+KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4, "dw1": 5, "convadj": 6, "adam": 7, "impldiff": 8}
 ENGINE_AUTO, ENGINE_TILE16, ENGINE_REGTILE = 0, 1, 2
 
 
@@ -293,6 +293,37 @@ class ColumnNDE:
         res = np.empty_like(T)
         _lib.check(self._L.colnde_convective_adjustment(self._h, _ptr(T), _ptr(hb), _ptr(ht), float(dt), float(dz), float(K),
                                                         _ptr(res), n))
+        return res
+
+    def implicit_diffusion(self, u, v, T, dt: float, dz: float, params, convective_adjustment: bool = False, halo_bottom=None, out=None):
+        """`modified_pacanowski_philander!(model, constants, Δt, p, convective_adjustment)` (wind_mixing/src/NDE_oceananigans.jl:61-101)
+        on [n][Nz] columns of u, v, T.  params = (ν₀, ν₋, ΔRi, Riᶜ, Pr, α, g); halo_bottom [3][n] or None.  Returns (u′, v′, T′);
+        `out` = a triple of device tensors (each may be its own input: in place)."""
+        Nz = self.cfg.Nz
+        pr = (ctypes.c_float * 7)(*[float(x) for x in params])
+        if _is_torch(T):
+            import torch
+            n = T.shape[0]
+            for a in (u, v, T):
+                self._chk_dev(a, (n, Nz))
+            if halo_bottom is not None:
+                self._chk_dev(halo_bottom, (3, n))
+            if out is None:
+                out = tuple(torch.empty_like(T) for _ in range(3))
+            for a in out:
+                self._chk_dev(a, (n, Nz))
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_implicit_diffusion_dev(
+                self._h, u.data_ptr(), v.data_ptr(), T.data_ptr(), halo_bottom.data_ptr() if halo_bottom is not None else None,
+                float(dt), float(dz), pr, int(bool(convective_adjustment)), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), n))
+            return out
+        T = _f32(T)
+        n = T.shape[0]
+        u, v, T = _f32(u, (n, Nz)), _f32(v, (n, Nz)), _f32(T, (n, Nz))
+        hb = _f32(halo_bottom, (3, n)) if halo_bottom is not None else None
+        res = tuple(np.empty_like(T) for _ in range(3))
+        _lib.check(self._L.colnde_implicit_diffusion(self._h, _ptr(u), _ptr(v), _ptr(T), _ptr(hb), float(dt), float(dz), pr,
+                                                     int(bool(convective_adjustment)), _ptr(res[0]), _ptr(res[1]), _ptr(res[2]), n))
         return res
 
     def adam_step(self, weights, grad, m, v, eta: float, beta=(0.9, 0.999), eps: float = 1e-8, beta_t=None):

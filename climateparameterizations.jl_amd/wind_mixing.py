@@ -10,6 +10,8 @@ Same names, argument meaning and return shapes as the Julia closures this path r
     ∇loss  -> grad_loss(weights)      the pullback GalacticOptim obtains from Zygote (NDE_training.jl:327-333)
     calculate_loss_scalings, apply_loss_scalings                               wind_mixing/src/loss.jl:11-42
     train_NDE                                                                  NDE_training.jl:167-374 (optimiser loop :340-372)
+    modified_pacanowski_philander!(model, constants, Δt, p, convective_adjustment)   wind_mixing/src/NDE_oceananigans.jl:61-101
+        -> modified_pacanowski_philander_step   (implicit diffusion step of the 1-D ocean embedding)
 
 Data loading, JLD2 logging and plotting stay outside (out of scope).
 """
@@ -241,3 +243,27 @@ def train_NN(engine: ColumnNDE, NN_type: str, weights, profiles, BCs, fluxes, op
                 cb(total, theta)
         opt.m, opt.v = m.double().cpu().numpy(), v.double().cpu().numpy()
     return theta.cpu().numpy(), hist
+
+
+def modified_pacanowski_philander_step(engine: ColumnNDE, u, v, T, dt: float, dz: float, p: dict, constants, convective_adjustment: bool = False,
+                                       halo_bottom=None):
+    """`modified_pacanowski_philander!(model, constants, Δt, p, convective_adjustment)` (wind_mixing/src/NDE_oceananigans.jl:61-101;
+    diffusivities :17-58) on `interior(u)`, `interior(v)`, `interior(T)` as [n, Nz] (or [Nz]) arrays: returns (u′, v′, T′).
+    `p` is the reference's diffusivity dictionary (keys "ν₀", "ν₋", "ΔRi", "Riᶜ", "Pr"; ASCII "nu0", "nu_minus", "dRi", "Ric" accepted),
+    `constants` carries α and g (attributes or keys `alpha`/`α`, `g`).  halo_bottom [3, n]: the u, v, T halo cells below the deepest
+    cell (None: zero-gradient fill)."""
+    def get(d, *names):
+        for nm in names:
+            if isinstance(d, dict) and nm in d:
+                return float(d[nm])
+            if not isinstance(d, dict) and hasattr(d, nm):
+                return float(getattr(d, nm))
+        raise KeyError(names[0])
+    params = (get(p, "ν₀", "nu0"), get(p, "ν₋", "nu_minus"), get(p, "ΔRi", "dRi"), get(p, "Riᶜ", "Ric"), get(p, "Pr"),
+              get(constants, "α", "alpha"), get(constants, "g"))
+    u, v, T = (np.asarray(a, dtype=np.float32) for a in (u, v, T))
+    shape = T.shape
+    u2, v2, T2 = (a.reshape(-1, shape[-1]) for a in (u, v, T))
+    hb = None if halo_bottom is None else np.asarray(halo_bottom, np.float32).reshape(3, -1)
+    uo, vo, To = engine.implicit_diffusion(u2, v2, T2, dt, dz, params, convective_adjustment, hb)
+    return uo.reshape(shape), vo.reshape(shape), To.reshape(shape)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define COLNDE_VERSION 101
+#define COLNDE_VERSION 102
 #define COLNDE_MAX_LAYERS 8
 
 enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_training.jl:56-165 */
@@ -153,6 +153,24 @@ int colnde_convective_adjustment(colnde_handle* h, const float* T, const float* 
 int colnde_convective_adjustment_dev(colnde_handle* h, const float* d_T, const float* d_halo_bottom, const float* d_halo_top,
                                      float dt, float dz, float K, float* d_out, int n_columns);
 
+/* modified_pacanowski_philander!(model, constants, Δt, p, convective_adjustment) — wind_mixing/src/NDE_oceananigans.jl:61-101, the implicit
+ * diffusion step of the 1-D Oceananigans embedding of the wind-mixing NN (called every time step at :376,:402), with the face
+ * diffusivities of modified_pacanowski_philander_diffusivity (:17-58):
+ *   Ri_k  = ∂z b / ((∂z u)² + (∂z v)²) on faces, b = gαT (Oceanostics 0.3.2 richardson_number_ccf!, wind_mixing/Manifest.toml:1279)
+ *   ν_k   = ν₀ + ν₋ tanh_step((Ri_k − Riᶜ)/ΔRi) on interior faces, 0 on the bottom face;  ν_T = ν/Pr, or under convective_adjustment
+ *           Ri_k > 0 ? ν_k/Pr : 1 on every face (the bottom face sees the halo cells; NaN > 0 is false, as in Julia)
+ *   u′ = L_ν \ u, v′ = L_ν \ v, T′ = L_νT \ T (backward Euler, the Tridiagonal of :69-83, c = Δt/Δz²), then T′[bottom] = T[bottom] (:94).
+ * u, v, T and the outputs: [n_col][Nz] in the ocean model's units, k = 0 deepest; an output may alias its own input.  halo_bottom:
+ * [3][n_col] = the u, v, T halo cells below k = 0 as the ocean model filled them for the fields' boundary conditions (only the
+ * convective-adjustment switch of the bottom face reads them), or NULL for the zero-gradient fill.  params = {ν₀, ν₋, ΔRi, Riᶜ, Pr, α, g}
+ * (the reference's `p` dictionary and `constants`).  Nz is the handle's (any model kind). */
+int colnde_implicit_diffusion(colnde_handle* h, const float* u, const float* v, const float* T, const float* halo_bottom, float dt,
+                              float dz, const float params[7], int convective_adjustment, float* u_out, float* v_out, float* T_out,
+                              int n_columns);
+int colnde_implicit_diffusion_dev(colnde_handle* h, const float* d_u, const float* d_v, const float* d_T, const float* d_halo_bottom,
+                                  float dt, float dz, const float params[7], int convective_adjustment, float* d_u_out, float* d_v_out,
+                                  float* d_T_out, int n_columns);
+
 /* Flux.Optimise.ADAM apply! + update! (Flux 0.11.6 src/optimise/optimisers.jl; used at wind_mixing/src/NDE_training.jl:340-372,
  * free_convection/src/training.jl:71) on device vectors of n floats: m ← β₁m + (1-β₁)g, v ← β₂v + (1-β₂)g²,
  * w ← w - η·m/(1-β₁ᵗ)/(√(v/(1-β₂ᵗ)) + ϵ).  beta1_t / beta2_t are the running powers the optimiser state carries (β₁, β₂ on the
@@ -212,7 +230,7 @@ int colnde_plan(const colnde_handle* h, int info[8]);
 
 /* ---- measurement: HIP-event timing of the handle's kernels on its stream.
  * which: 0 = forward solve kernel, 1 = adjoint kernel, 2 = gradient reduce, 3 = rhs, 4 = inference,
- * 5 = streaming dW1 GEMM (regtile engine only), 6 = convective adjustment, 7 = ADAM step.
+ * 5 = streaming dW1 GEMM (regtile engine only), 6 = convective adjustment, 7 = ADAM step, 8 = implicit diffusion.
  * Returns accumulated milliseconds and launch count since the last reset (synchronises the stream). */
 int colnde_set_profiling(colnde_handle* h, int enabled);
 int colnde_kernel_time(colnde_handle* h, int which, float* ms_total, int* n_launches);

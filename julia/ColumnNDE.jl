@@ -226,6 +226,20 @@ function convective_adjustment!(h::Handle, T::Matrix{Float32}, Δt, Δz, K; halo
     T
 end
 
+"modified_pacanowski_philander!(model, constants, Δt, p, convective_adjustment) — wind_mixing/src/NDE_oceananigans.jl:61-101: u, v, T are
+`interior(model.velocities.u)[:]` … as (Nz, n_columns) column-major matrices (= C-order [column][level]), updated in place; `p` is the
+reference's diffusivity dictionary, `constants` its NamedTuple; halo_bottom (n_columns, 3) column-major = C-order [3][n_columns] or nothing"
+function modified_pacanowski_philander!(h::Handle, u::Matrix{Float32}, v::Matrix{Float32}, T::Matrix{Float32}, constants, Δt, Δz, p,
+                                        convective_adjustment; halo_bottom=nothing)
+    params = Float32[p["ν₀"], p["ν₋"], p["ΔRi"], p["Riᶜ"], p["Pr"], constants.α, constants.g]
+    hb = halo_bottom === nothing ? C_NULL : pointer(halo_bottom)
+    GC.@preserve halo_bottom check(ccall((:colnde_implicit_diffusion, libcolnde), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Cfloat, Ptr{Float32}, Cint,
+         Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cint),
+        h.ptr, u, v, T, hb, Δt, Δz, params, convective_adjustment ? 1 : 0, u, v, T, size(T, 2)))
+    nothing
+end
+
 "Flux.Optimise.ADAM apply!/update! on device pointers (θ, ∇, m, v resident on the GPU); βᵗ = running powers kept by the caller"
 function adam_step!(h::Handle, dθ::Ptr{Float32}, dg::Ptr{Float32}, dm::Ptr{Float32}, dv::Ptr{Float32}, η, β, ϵ, βᵗ, n)
     check(ccall((:colnde_adam_step_dev, libcolnde), Cint,

@@ -728,6 +728,54 @@ def convective_adjustment(T, dt, dz, K, halo_bottom=None, halo_top=None, dtype=n
     return out
 
 
+def modified_pacanowski_philander_step(u, v, T, dt, dz, nu0, nu_minus, dRi, Ric, Pr, alpha, g, convective_adjustment=False,
+                                       halo_bottom=None, dtype=np.float64):
+    """`modified_pacanowski_philander!(model, constants, Δt, p, convective_adjustment)` — wind_mixing/src/NDE_oceananigans.jl:61-101
+    with `modified_pacanowski_philander_diffusivity` (:17-58), restated literally for a batch of columns [n_col, Nz] (k = 0 deepest):
+    `Ri` on the Nz+1 faces = ∂z b / ((∂z u)² + (∂z v)²) with b = gαT (Oceanostics 0.3.2 `richardson_number_ccf!` on the
+    (Center, Center, Face) location of a 1x1 periodic column — third-party, pinned in wind_mixing/Manifest.toml:1279, absent from
+    /root/reference; its published kernel is that ratio of centred face differences), `ν[i] = ν₀ + ν₋ tanh_step((Ri[i] − Riᶜ)/ΔRi)`
+    for i in 2:Nz and 0 at both ends (:45-47), `ν_T = Ri > 0 ? ν/Pr : 1` under convective adjustment, `ν/Pr` otherwise (:49-55),
+    the three diagonals of :69-83 assembled DENSELY and solved with LAPACK (`Tridiagonal \\`, :88-90), then `T′[1] = T_bottom` (:94).
+    halo_bottom: (u, v, T) halo cells below the deepest cell [3, n_col] (they carry the ocean model's boundary conditions; only
+    Ri[1] — the ν_T switch of the bottom face — reads them) or None for the zero-gradient fill (Ri[1] = 0/0 = NaN, `NaN > 0` false)."""
+    u, v, T = (np.asarray(a, dtype) for a in (u, v, T))
+    n, Nz = T.shape
+    if halo_bottom is None:
+        hb = np.stack([u[:, 0], v[:, 0], T[:, 0]])
+    else:
+        hb = np.asarray(halo_bottom, dtype)
+    # top halo: zero-gradient; Ri[Nz+1] enters ν_T[Nz+1] only, which no diagonal reads
+    ext = lambda a, h: np.concatenate([h[:, None], a, a[:, -1:]], axis=1)
+    ue, ve, Te = ext(u, hb[0]), ext(v, hb[1]), ext(T, hb[2])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dudz, dvdz = np.diff(ue, axis=1) / dz, np.diff(ve, axis=1) / dz
+        dbdz = dtype(g) * dtype(alpha) * np.diff(Te, axis=1) / dz
+        Ri = dbdz / (dudz ** 2 + dvdz ** 2)                                     # [n, Nz+1]
+        nu = np.zeros((n, Nz + 1), dtype)
+        nu[:, 1:Nz] = nu0 + nu_minus * (1 - np.tanh((Ri[:, 1:Nz] - Ric) / dRi)) / 2
+        nu_T = np.where(Ri > 0, nu / Pr, dtype(1)) if convective_adjustment else nu / Pr
+    c = dtype(dt) / dtype(dz) ** 2
+    uo, vo, To = np.empty_like(u), np.empty_like(v), np.empty_like(T)
+
+    def tri(nuf):
+        L = np.zeros((Nz, Nz), dtype)
+        for r in range(1, Nz):
+            L[r, r - 1] = -c * nuf[r]                       # lower[i] = -Δt/Δz² ν[i], i in 2:Nz
+        for r in range(Nz - 1):
+            L[r, r + 1] = -c * nuf[r + 1]                   # upper[i] = -Δt/Δz² ν[i+1], i in 1:Nz-1
+            L[r, r] = 1 + c * (nuf[r] + nuf[r + 1])
+        L[Nz - 1, Nz - 1] = 1 + c * nuf[Nz - 1]
+        return L
+    for i in range(n):
+        Lv, LT = tri(nu[i]), tri(nu_T[i])
+        uo[i] = np.linalg.solve(Lv, u[i])
+        vo[i] = np.linalg.solve(Lv, v[i])
+        To[i] = np.linalg.solve(LT, T[i])
+        To[i, 0] = T[i, 0]
+    return uo, vo, To
+
+
 def adam_step(theta, grad, m, v, eta, beta, eps, beta_t):
     """Flux.Optimise.ADAM `apply!` + `update!` (Flux 0.11.6, src/optimise/optimisers.jl — third-party, pinned in
     wind_mixing/Manifest.toml; call sites NDE_training.jl:340-372, training.jl:71).  Returns (theta, m, v, beta_t) after

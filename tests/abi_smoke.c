@@ -91,6 +91,28 @@ int main(int argc, char** argv) {
     const int rc_bad = colnde_create(&bad, &hb);
     printf("abi_smoke: engine %d, max|sol - golden| = %.3e, rel loss err = %.3e, rel grad err = %.3e, sum(terms)/total = %.7f, bad config rc = %d (%s)\n",
            colnde_engine(h), esol, etot, egrad, tsum / total, rc_bad, rc_bad ? colnde_last_error() : "accepted?!");
+    /* the implicit diffusion step (modified_pacanowski_philander!, NDE_oceananigans.jl:61-101) on a known answer: constant diffusivity
+     * (Ric -> +inf: tanh_step = 1), one backward-Euler step damps the discrete cosine mode m by 1/(1 + c nu lambda_m) */
+    double ediff = 0.0;
+    {
+        enum { NC = 3 };
+        float u[NC * NZ], v[NC * NZ], T[NC * NZ];
+        const float prm[7] = {0.0f, 2e-2f, 1.0f, 1e30f, 1.0f, 1.67e-4f, 9.81f};
+        const double PI = 3.14159265358979323846, dt = 60.0, dz = 8.0, lam = 4.0 * pow(sin(PI * 3 / (2.0 * NZ)), 2);
+        for (int cidx = 0; cidx < NC; cidx++)
+            for (int k = 0; k < NZ; k++) {
+                u[cidx * NZ + k] = (float)(0.05 * (cidx + 1) * cos(PI * 3 * (k + 0.5) / NZ));
+                v[cidx * NZ + k] = 0.02f;
+                T[cidx * NZ + k] = 19.6f + 0.01f * k;
+            }
+        float u0[NC * NZ];
+        memcpy(u0, u, sizeof u);
+        CHECK(colnde_implicit_diffusion(h, u, v, T, NULL, (float)dt, (float)dz, prm, 0, u, v, T, NC));
+        for (int i = 0; i < NC * NZ; i++) ediff = fmax(ediff, fabs((double)u[i] - u0[i] / (1.0 + dt / (dz * dz) * 2e-2 * lam)));
+        for (int i = 0; i < NC * NZ; i++) ediff = fmax(ediff, fabs((double)v[i] - 0.02));
+    }
+    printf("abi_smoke: implicit diffusion, max error against the damped cosine mode = %.3e\n", ediff);
+    if (!(ediff < 5e-7)) return 1;
     colnde_destroy(h);
     /* tolerances of tests/test_gpu_parity.py (wind mixing, short horizon); the golden file stores float32 roundings of the float64 oracle */
     if (!(esol < 2e-5) || !(etot < 8e-5) || !(egrad < 2e-4) || fabs(tsum / total - 1.0) > 1e-5 || rc_bad == 0 || hb != NULL) return 1;

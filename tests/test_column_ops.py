@@ -171,3 +171,162 @@ def test_gpu_free_convection_device_training_follows_the_host_loop():
     np.testing.assert_allclose(hb, ha, rtol=2e-3)
     assert hb[-1] < hb[0]
     np.testing.assert_allclose(thb, tha, rtol=1e-3, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------- implicit MPP diffusion step
+# modified_pacanowski_philander! (wind_mixing/src/NDE_oceananigans.jl:61-101): the third cited site of SURVEY §8f rank 1
+MPP = dict(nu0=1e-4, nu_minus=1e-1, dRi=1.0, Ric=0.25, Pr=1.0, alpha=1.67e-4, g=9.81)        # test_nonmutating_NDE.jl:52-53
+
+
+def _uvT(n, Nz, rng, unstable=True):
+    """Ocean-like columns in model units: sheared velocities (m/s), a stratified T (deg C) with inverted patches."""
+    k = np.arange(Nz)[None, :]
+    A = rng.uniform(0.02, 0.1, (n, 1))
+    u = A * np.tanh((k - 0.75 * Nz) / (Nz / 8)) + 2e-3 * rng.standard_normal((n, Nz))
+    v = 0.5 * A * np.tanh((k - 0.6 * Nz) / (Nz / 6)) + 2e-3 * rng.standard_normal((n, Nz))
+    T = 19.6 + 0.4 * k / Nz + (0.02 if unstable else 0.0) * rng.standard_normal((n, Nz))
+    return u.astype(np.float32), v.astype(np.float32), T.astype(np.float32)
+
+
+def _mpp_thomas(u, v, T, dt, dz, P, ca, hb=None):
+    """Independent restatement: scalar loops over faces, Thomas elimination (no LAPACK, no vectorised np.where)."""
+    n, Nz = T.shape
+    c = dt / dz ** 2
+    outs = [np.empty((n, Nz)) for _ in range(3)]
+    for i in range(n):
+        nu, nuT = np.zeros(Nz + 1), np.zeros(Nz + 1)
+        for f in range(Nz + 1):
+            lo = lambda a, h: (a[i, f - 1] if f > 0 else (h if h is not None else a[i, 0]))
+            hi = lambda a: a[i, f] if f < Nz else a[i, Nz - 1]
+            du = hi(u) - lo(u, None if hb is None else hb[0][i])
+            dv = hi(v) - lo(v, None if hb is None else hb[1][i])
+            dT = hi(T) - lo(T, None if hb is None else hb[2][i])
+            den = (du / dz) ** 2 + (dv / dz) ** 2
+            num = P["g"] * P["alpha"] * dT / dz
+            Ri = num / den if den != 0 else (np.nan if num == 0 else np.copysign(np.inf, num))
+            if 1 <= f < Nz:
+                nu[f] = P["nu0"] + P["nu_minus"] * (1 - np.tanh((Ri - P["Ric"]) / P["dRi"])) / 2
+            nuT[f] = (nu[f] / P["Pr"] if Ri > 0 else 1.0) if ca else nu[f] / P["Pr"]
+        for o, (x, kf) in zip(outs, ((u[i], nu), (v[i], nu), (T[i], nuT))):
+            x = x.astype(np.float64).copy()
+            kk = c * kf
+            cp = np.zeros(Nz)
+            b0 = 1 + kk[0] + kk[1]
+            cp[0] = -kk[1] / b0
+            x[0] /= b0
+            for r in range(1, Nz):
+                a = -kk[r]
+                b = 1 + kk[r] + (kk[r + 1] if r < Nz - 1 else 0.0)
+                den = b - a * cp[r - 1]
+                cp[r] = (-kk[r + 1] if r < Nz - 1 else 0.0) / den
+                x[r] = (x[r] - a * x[r - 1]) / den
+            for r in range(Nz - 2, -1, -1):
+                x[r] -= cp[r] * x[r + 1]
+            o[i] = x
+        outs[2][i, 0] = T[i, 0]
+    return outs
+
+
+@pytest.mark.parametrize("ca", [False, True])
+def test_oracle_mpp_step_matches_scalar_thomas_restatement(ca):
+    rng = np.random.default_rng(7)
+    u, v, T = _uvT(12, 32, rng)
+    hb = np.stack([u[:, 0] - 1e-3, v[:, 0] + 2e-3, T[:, 0] + np.where(np.arange(12) % 2, 0.01, -0.01)]).astype(np.float32)
+    for halo in (None, hb):
+        got = orc.modified_pacanowski_philander_step(u, v, T, 60.0, 8.0, convective_adjustment=ca, halo_bottom=halo, **MPP)
+        want = _mpp_thomas(u.astype(np.float64), v.astype(np.float64), T.astype(np.float64), 60.0, 8.0, MPP, ca, halo)
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g, w, rtol=1e-11, atol=1e-13)
+
+
+def test_oracle_mpp_step_properties():
+    rng = np.random.default_rng(8)
+    u, v, T = _uvT(6, 32, rng)
+    dt, dz = 60.0, 8.0
+    uo, vo, To = orc.modified_pacanowski_philander_step(u, v, T, dt, dz, **MPP)
+    # `T′[1] = T_bottom` (:94), and the velocity operator conserves column momentum (zero-flux ends: column sums of L are 1)
+    assert np.array_equal(To[:, 0], T[:, 0].astype(np.float64))
+    np.testing.assert_allclose(uo.sum(1), u.astype(np.float64).sum(1), rtol=1e-12)
+    np.testing.assert_allclose(vo.sum(1), v.astype(np.float64).sum(1), rtol=1e-12)
+    # M-matrix with unit row sums: maximum principle
+    assert (uo.max(1) <= u.max(1) + 1e-12).all() and (uo.min(1) >= u.min(1) - 1e-12).all()
+    # ν₋ = ν₀ = 0: nothing diffuses
+    P0 = dict(MPP, nu0=0.0, nu_minus=0.0)
+    u0, v0, T0 = orc.modified_pacanowski_philander_step(u, v, T, dt, dz, **P0)
+    assert np.array_equal(u0, u.astype(np.float64)) and np.array_equal(T0, T.astype(np.float64))
+    # constant ν (Riᶜ → +∞ ⇒ tanh_step = 1): one backward-Euler step damps discrete cosine mode m by 1/(1 + c ν λ_m)
+    Nz = 32
+    Pc = dict(MPP, Ric=1e30, nu0=0.0, nu_minus=2e-2)
+    m = 3
+    mode = np.cos(np.pi * m * (np.arange(Nz) + 0.5) / Nz)
+    uu = np.tile(mode, (2, 1)) * 0.05
+    vv = 0.02 + 0 * uu
+    TT = np.tile(19.6 + 0.01 * np.arange(Nz), (2, 1))
+    u1, _, _ = orc.modified_pacanowski_philander_step(uu, vv, TT, dt, dz, **Pc)
+    lam = 4 * np.sin(np.pi * m / (2 * Nz)) ** 2
+    np.testing.assert_allclose(u1, uu / (1 + dt / dz ** 2 * 2e-2 * lam), rtol=1e-9, atol=1e-14)
+    # convective adjustment: an inverted layer (Ri < 0) is mixed with ν_T = 1 while a stable one keeps ν/Pr
+    Tinv = np.tile(19.6 + 0.01 * np.arange(Nz), (1, 1))
+    Tinv[0, 20:24] -= 0.05
+    ui = 0.05 * np.tanh((np.arange(Nz)[None, :] - 24) / 4.0)
+    _, _, Tca = orc.modified_pacanowski_philander_step(ui, 0 * ui, Tinv, dt, dz, convective_adjustment=True, **MPP)
+    _, _, Tno = orc.modified_pacanowski_philander_step(ui, 0 * ui, Tinv, dt, dz, convective_adjustment=False, **MPP)
+    assert np.abs(Tca - Tinv).max() > 3 * np.abs(Tno - Tinv).max()
+
+
+def _mpp_params():
+    return (MPP["nu0"], MPP["nu_minus"], MPP["dRi"], MPP["Ric"], MPP["Pr"], MPP["alpha"], MPP["g"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nz,n", [(32, 1), (32, 63), (32, 64), (32, 1000), (64, 257), (16, 300), (20, 77)])
+@pytest.mark.parametrize("ca", [False, True])
+def test_gpu_implicit_diffusion_matches_oracle(Nz, n, ca):
+    import colnde
+    rng = np.random.default_rng(100 + Nz + n)
+    cfg = synthetic.free_convection_problem(1, Nz=Nz, n_save=2).cfg          # any model kind: only Nz is the handle's
+    u, v, T = _uvT(n, Nz, rng)
+    dt, dz = 60.0, 256.0 / Nz
+    hb = np.stack([u[:, 0] - 1e-3, v[:, 0] + 2e-3, T[:, 0] + np.where(np.arange(n) % 2, 0.01, -0.01)]).astype(np.float32)
+    with colnde.ColumnNDE(cfg, 1) as nde:
+        for halo in (None, hb):
+            want = orc.modified_pacanowski_philander_step(u, v, T, dt, dz, convective_adjustment=ca, halo_bottom=halo, **MPP)
+            got = nde.implicit_diffusion(u, v, T, dt, dz, _mpp_params(), ca, halo)
+            # float32 Thomas vs float64 LAPACK: velocities to 2e-5 of their range, T (|T| ~ 20, changes ~ 1e-2) to 2e-6 relative
+            for g, w, tol in zip(got, want, (2e-5, 2e-5, 2e-6)):
+                assert np.isfinite(g).all()
+                assert np.abs(g - w).max() <= tol * np.abs(w).max(), (np.abs(g - w).max(), np.abs(w).max())
+            assert np.array_equal(got[2][:, 0], T[:, 0])                                         # T′[1] = T_bottom, bit for bit
+        # nothing to diffuse: bit-identical pass-through
+        z = nde.implicit_diffusion(u, v, T, dt, dz, (0.0, 0.0, 1.0, 0.25, 1.0, MPP["alpha"], MPP["g"]), False)
+        assert all(np.array_equal(a, b) for a, b in zip(z, (u, v, T)))
+
+
+@pytest.mark.gpu
+def test_gpu_implicit_diffusion_device_twin_in_place_mirror_and_bad_arguments():
+    import torch
+    import colnde
+    from colnde import wind_mixing
+    rng = np.random.default_rng(5)
+    p = synthetic.wind_mixing_problem(2, n_frames=3)                          # a wind-mixing handle this time
+    u, v, T = _uvT(8192 + 17, 32, rng)
+    dt, dz = 60.0, 8.0
+    want = orc.modified_pacanowski_philander_step(u[:256], v[:256], T[:256], dt, dz, convective_adjustment=True, **MPP)
+    with colnde.ColumnNDE(p.cfg, 2) as nde:
+        ud, vd, Td = (torch.from_numpy(a).cuda() for a in (u, v, T))
+        nde.implicit_diffusion(ud, vd, Td, dt, dz, _mpp_params(), True, out=(ud, vd, Td))      # in place
+        torch.cuda.synchronize()
+        host = nde.implicit_diffusion(u, v, T, dt, dz, _mpp_params(), True)
+        for d, hst, w, tol in zip((ud, vd, Td), host, want, (2e-5, 2e-5, 2e-6)):
+            assert np.array_equal(d.cpu().numpy(), hst)                                        # device twin == host entry point
+            assert np.abs(hst[:256] - w).max() <= tol * np.abs(w).max()
+        # the reference-named mirror, with the reference's dictionary keys and a 1-D column
+        pj = {"ν₀": MPP["nu0"], "ν₋": MPP["nu_minus"], "ΔRi": MPP["dRi"], "Riᶜ": MPP["Ric"], "Pr": MPP["Pr"]}
+        u1, v1, T1 = wind_mixing.modified_pacanowski_philander_step(nde, u[3], v[3], T[3], dt, dz, pj, {"α": MPP["alpha"], "g": MPP["g"]}, True)
+        assert u1.shape == (32,) and np.array_equal(T1, host[2][3]) and np.array_equal(u1, host[0][3])
+        with pytest.raises(colnde.ColndeError):
+            nde.implicit_diffusion(u, v, T, -1.0, dz, _mpp_params())
+        with pytest.raises(colnde.ColndeError):
+            nde.implicit_diffusion(u, v, T, dt, dz, (1e-4, 1e-1, 0.0, 0.25, 1.0, 1e-4, 9.81))   # ΔRi = 0
+        with pytest.raises(colnde.ColndeError):
+            nde.implicit_diffusion(u, v, T, dt, dz, (-1e-4, 1e-1, 1.0, 0.25, 1.0, 1e-4, 9.81))  # negative diffusivity
