@@ -76,6 +76,163 @@ def cpu_baseline(problem, scalings, budget_s=20.0):
     }
 
 
+def other_configs(dev, budget_s=120.0):
+    """The BASELINE configs other than the headline one, run AFTER the headline's timed region and after its handle has been closed
+    (config 4's tapes want most of the HBM): each a short timed loop of the same C-ABI calls, reported with ms per pass,
+    column-timesteps/s and its fraction of the roofline that bounds it.  Parity for each of these cases lives in tests/ (-m gpu)."""
+    import torch
+    import colnde
+    from colnde import synthetic
+    out = {}
+    t_start = time.perf_counter()
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    def kernel_ms(nde):
+        r = {}
+        for k in ("forward", "adjoint", "dw1", "reduce"):
+            ms, n = nde.kernel_time(k)
+            if n:
+                r[k] = ms / n
+        return r
+
+    def guarded(name, fn):
+        if time.perf_counter() - t_start > budget_s:
+            out[name] = {"skipped": "time budget of the configs block spent"}
+            return
+        try:
+            out[name] = fn()
+        except Exception as e:                                   # a failing side config must not take the headline line with it
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    def grad_case(p, ncol, sc, n_timed, flop_per_rhs, rhs_per_step, label):
+        nde = colnde.ColumnNDE(p.cfg, ncol)
+        try:
+            x0, bcs, w, wt = (torch.from_numpy(a).to(dev) for a in (p.x0, p.bcs, p.weights, p.weights_truth))
+            nde.set_problem(x0, bcs)
+            truth = nde.forward(wt)
+            nde.set_problem(x0, bcs, truth)
+            res = torch.empty(p.cfg.n_params + 8, device=dev)
+            nde.loss_grad(w, sc, out=res)                         # plans and allocates the tapes
+            nde.set_profiling(True)
+            nde.reset_kernel_times()
+            dt = timed(lambda: nde.loss_grad(w, sc, out=res), n_timed)
+            km = kernel_ms(nde)
+            cs = ncol * p.cfg.n_steps
+            flop = 3 * rhs_per_step * flop_per_rhs                # forward + adjoint (dX, dW) per column-timestep: SURVEY §8d "3x forward"
+            bx = 4 * p.cfg.n_state
+            r = {"workload": label, "columns": ncol, "steps": p.cfg.n_steps, "ms": dt * 1e3, "column_timesteps_per_s": cs / dt,
+                 "mfma": {"flop_per_column_timestep": flop, "achieved_TFLOPs": cs * flop / dt / 1e12,
+                          "frac": cs * flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                 "hbm": {"algorithmic_bytes_per_column_timestep": 3 * bx / p.cfg.substeps,
+                         "frac": cs * 3 * bx / p.cfg.substeps / dt / 1e9 / PEAK_HBM_GBPS},
+                 "kernel_ms": km, "plan": nde.plan(), "loss_total": float(res[p.cfg.n_params + 6].item())}
+            if not np.isfinite(r["loss_total"]):
+                r["error"] = "non-finite loss"
+            return r
+        finally:
+            nde.close()
+
+    def c2():       # BASELINE configs[1]: forward only, 4,096 columns x 32 levels, 288 frames x 2 RK4 sub-steps
+        p = synthetic.wind_mixing_problem(4096)
+        nde = colnde.ColumnNDE(p.cfg, 4096)
+        try:
+            x0, bcs, w = (torch.from_numpy(a).to(dev) for a in (p.x0, p.bcs, p.weights))
+            nde.set_problem(x0, bcs)
+            sol = nde.forward(w)
+            dt = timed(lambda: nde.forward(w, out=sol), 10)
+            cs = 4096 * p.cfg.n_steps
+            return {"workload": "configs[1]: NDE forward only, 4096 columns x 32 levels x 576 RK4 steps", "columns": 4096, "steps": p.cfg.n_steps,
+                    "ms": dt * 1e3, "column_timesteps_per_s": cs / dt,
+                    "mfma": {"flop_per_column_timestep": FWD_FLOP_PER_COLSTEP, "achieved_TFLOPs": cs * FWD_FLOP_PER_COLSTEP / dt / 1e12,
+                             "frac": cs * FWD_FLOP_PER_COLSTEP / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                    "hbm": {"algorithmic_bytes_per_column_timestep": 384 / p.cfg.substeps, "frac": cs * 384 / p.cfg.substeps / dt / 1e9 / PEAK_HBM_GBPS},
+                    "engine": nde.engine, "plan_after_forward": nde.plan()}
+        finally:
+            nde.close()
+
+    def c3():       # BASELINE configs[2] as the reference trains it: 8 simulations
+        p = synthetic.wind_mixing_problem(8)
+        return grad_case(p, 8, [1, 1, 1, 5e-3, 5e-3, 5e-3], 5, MLP_FLOP_PER_RHS, 4,
+                         "configs[2] as written: 8 simulations x 32 levels x 289 frames, fwd+adjoint (latency point)")
+
+    def fc(ncol, Nz, ca, n_timed, label):
+        p = synthetic.free_convection_problem(ncol, Nz=Nz, convective_adjustment=ca)
+        rhs_per_step = 4
+        if ca:      # ConvectiveAdjustmentNDE is stiff (K = 10): the stabilised RKC2 stepper, automatic stage count
+            p.cfg = p.cfg.with_(stepper="rkc2")
+            rhs_per_step = colnde.rkc_stages(p.cfg)
+        mlp = 2 * (Nz * 4 * Nz + 16 * Nz * Nz + 4 * Nz * (Nz - 1))
+        r = grad_case(p, ncol, [0, 0, 1, 0, 0, 0], n_timed, mlp, rhs_per_step, label)
+        r["rhs_evaluations_per_step"] = rhs_per_step
+        return r
+
+    def c5():       # BASELINE configs[4]: inference forcing, 256 x 256 columns x 32 levels (one GPU holds the whole grid here)
+        cfg, T, tf, w = synthetic.inference_problem(256, 256)
+        nde = colnde.ColumnNDE(cfg, 65536)
+        try:
+            Td, tfd, wd = (torch.from_numpy(a).to(dev) for a in (T, tf, w))
+            nde.set_profiling(True)
+            nde.infer_forcing(wd, Td, tfd, 1024.0)
+            nde.reset_kernel_times()
+            dt = timed(lambda: nde.infer_forcing(wd, Td, tfd, 1024.0), 20)
+            ms, n = nde.kernel_time("infer")
+            kt = ms / n * 1e-3
+            mlp = 2 * (32 * 128 + 128 * 128 + 128 * 31)
+            return {"workload": "configs[4]: double_gyre_nn forcing, 256x256 columns x 32 levels, 32-128-128-31", "columns": 65536,
+                    "ms": dt * 1e3, "kernel_ms": kt * 1e3, "columns_per_s": 65536 / kt,
+                    "mfma": {"flop_per_column": mlp, "achieved_TFLOPs": 65536 * mlp / kt / 1e12, "frac": 65536 * mlp / kt / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                    "hbm": {"algorithmic_bytes_per_column": 260, "achieved_GBps": 65536 * 260 / kt / 1e9, "frac": 65536 * 260 / kt / 1e9 / PEAK_HBM_GBPS}}
+        finally:
+            nde.close()
+
+    def impl():     # SURVEY §8f rank 1: the implicit steps either side of the NN forcing, HBM-bound, 4 M columns x 32 levels
+        cfg = synthetic.free_convection_problem(1, Nz=32, n_save=2).cfg
+        nde = colnde.ColumnNDE(cfg, 1)
+        try:
+            ncol = 4 * 1024 * 1024
+            g = torch.Generator(device="cpu").manual_seed(2)
+            k = torch.arange(32)[None, :]
+            u = (0.05 * torch.tanh((k - 24) / 4.0) + 2e-3 * torch.randn(ncol, 32, generator=g)).to(dev)
+            v = (0.02 * torch.tanh((k - 20) / 5.0) + 2e-3 * torch.randn(ncol, 32, generator=g)).to(dev)
+            T = (19.6 + 0.4 * k / 32 + 0.02 * torch.randn(ncol, 32, generator=g)).to(dev)
+            outs = tuple(torch.empty_like(T) for _ in range(3))
+            nde.set_profiling(True)
+            prm = (1e-4, 1e-1, 1.0, 0.25, 1.0, 1.67e-4, 9.81)
+            r = {"columns": ncol, "levels": 32}
+            for name, kid, nbytes, fn in (
+                    ("implicit_mpp_diffusion", "impldiff", 768, lambda: nde.implicit_diffusion(u, v, T, 60.0, 8.0, prm, True, out=outs)),
+                    ("convective_adjustment", "convadj", 256, lambda: nde.convective_adjustment(T, 1200.0, 62.5, 10.0, out=outs[2]))):
+                fn()
+                nde.reset_kernel_times()
+                timed(fn, 10)
+                ms, n = nde.kernel_time(kid)
+                kt = ms / n * 1e-3
+                r[name] = {"kernel_ms": kt * 1e3, "columns_per_s": ncol / kt, "algorithmic_bytes_per_column": nbytes,
+                           "hbm": {"achieved_GBps": ncol * nbytes / kt / 1e9, "frac": ncol * nbytes / kt / 1e9 / PEAK_HBM_GBPS}}
+            return r
+        finally:
+            nde.close()
+
+    guarded("config2_forward_4096", c2)
+    guarded("config3_8_simulations", c3)
+    guarded("config5_inference_65536", c5)
+    guarded("implicit_steps_4M_columns", impl)
+    guarded("free_convection_32_levels_16384", lambda: fc(16384, 32, False, 2, "free convection 32 levels (32-128-128-31 relu), 16384 columns x 512 RK4 steps, fwd+adjoint"))
+    guarded("config4_shard_16384x64", lambda: fc(16384, 64, False, 2, "configs[3] one GPU's shard: FreeConvectionNDE, 16384 columns x 64 levels x 512 RK4 steps, 64-256-256-63 relu, fwd+adjoint"))
+    guarded("config4_shard_16384x64_conv_adj_rkc2", lambda: fc(16384, 64, True, 1, "configs[3] one GPU's shard: ConvectiveAdjustmentNDE (K = 10), 16384 columns x 64 levels x 512 RKC2 steps, fwd+adjoint"))
+    return out
+
+
 def launcher_command(n_gpus, argv, port):
     """The command `python bench.py --gpus N ...` turns itself into: one rank per GPU under torch.distributed.run."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
@@ -108,6 +265,7 @@ def main():
     ap.add_argument("--frames", type=int, default=289, help="saved frames (2-day suite: 289)")
     ap.add_argument("--substeps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the block that times the other BASELINE configs after the headline (N = 1 only)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -295,8 +453,14 @@ def main():
             line["cpu_baseline"] = cpu_baseline(prob, scal)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
     nde.close()
+    if rank == 0:
+        if world == 1 and not args.no_configs:
+            # outside the headline's timed region, with the headline's tapes released
+            del truth, x0, bcs, out
+            torch.cuda.empty_cache()
+            line["configs"] = other_configs(dev)
+        print(json.dumps(line), flush=True)
     if comm is not None:
         barrier()
         comm.close()

@@ -1,5 +1,5 @@
 """Throughput of the BASELINE configs other than the headline one (parity-test cases; this is a diagnostic, not bench.py).
-usage: bench_configs.py [2|4|4ca|4s|5|ca|adam] ..."""
+usage: bench_configs.py [2|3|4|4ca|4s|4n32|5|ca|mpp|adam] ..."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -73,6 +73,25 @@ for c in which:
             kt = ms / nl * 1e-3
             print("convective adjustment: %d columns x 32 levels: kernel %.4f ms -> %.0f M columns/s, %.0f GB/s of 8000 (256 B/column algorithmic) = %.1f %% of HBM peak; wall %.4f ms"
                   % (ncol, kt * 1e3, ncol / kt / 1e6, ncol * 256 / kt / 1e9, ncol * 256 / kt / 1e9 / 80.0, dt * 1e3), flush=True)
+        nde.close()
+    if c == "mpp":    # implicit MPP diffusion step (NDE_oceananigans.jl:61-101): u, v, T of 32 levels, 768 B/column algorithmic
+        cfg = synthetic.free_convection_problem(1, Nz=32, n_save=2).cfg
+        nde = colnde.ColumnNDE(cfg, 1)
+        prm = (1e-4, 1e-1, 1.0, 0.25, 1.0, 1.67e-4, 9.81)
+        for ncol in (65536, 4 * 1024 * 1024):
+            g = torch.Generator(device="cpu").manual_seed(2)
+            k = torch.arange(32)[None, :]
+            u = (0.05 * torch.tanh((k - 24) / 4.0) + 2e-3 * torch.randn(ncol, 32, generator=g)).to(dev)
+            v = (0.02 * torch.tanh((k - 20) / 5.0) + 2e-3 * torch.randn(ncol, 32, generator=g)).to(dev)
+            T = (19.6 + 0.4 * k / 32 + 0.02 * torch.randn(ncol, 32, generator=g)).to(dev)
+            outs = tuple(torch.empty_like(T) for _ in range(3))
+            for ca in (False, True):
+                nde.set_profiling(True); nde.reset_kernel_times()
+                dt = timed(lambda: nde.implicit_diffusion(u, v, T, 60.0, 8.0, prm, ca, out=outs), n=20)
+                ms, nl = nde.kernel_time("impldiff")
+                kt = ms / nl * 1e-3
+                print("implicit MPP diffusion (ca=%d): %d columns x 32 levels: kernel %.4f ms -> %.0f M columns/s, %.0f GB/s of 8000 (768 B/column algorithmic) = %.1f %% of HBM peak; wall %.4f ms"
+                      % (ca, ncol, kt * 1e3, ncol / kt / 1e6, ncol * 768 / kt / 1e9, ncol * 768 / kt / 1e9 / 80.0, dt * 1e3), flush=True)
         nde.close()
     if c == "adam":   # fused ADAM update on the 19,563-parameter vector and on a large one
         p = synthetic.wind_mixing_problem(2, n_frames=3)

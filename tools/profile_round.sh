@@ -8,11 +8,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o ks -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o ks -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/ks.log 2>&1
 echo "kernel stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pf -o pf -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pf.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pf -o pf -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs > $OUT/pf.log 2>&1
 echo "FETCH_SIZE done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pw -o pw -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pw.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pw -o pw -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs > $OUT/pw.log 2>&1
 echo "WRITE_SIZE done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/oc -o oc -- python3 $R/tools/bench_configs.py 2 3 4 4n32 5 ca adam > $OUT/oc.log 2>&1
 echo "other configs done"
