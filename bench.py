@@ -233,27 +233,26 @@ def other_configs(dev, budget_s=120.0):
     return out
 
 
-def launcher_command(n_gpus, argv, port):
-    """The command `python bench.py --gpus N ...` turns itself into: one rank per GPU under torch.distributed.run."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+def launcher_command(n_gpus, argv):
+    """The command `python bench.py --gpus N ...` turns itself into: one rank per GPU under torch.distributed.run.  `--standalone`
+    lets the launcher bind its own rendezvous port (no probe-then-reuse race); `--local-addr 127.0.0.1` because the box's hostname
+    may not resolve."""
+    return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+            "--nproc-per-node", str(n_gpus), os.path.abspath(__file__)] + list(argv)
 
 
 def self_launch(n_gpus, argv):
-    """Spawn the N ranks as children, relay their output (rank 0 prints the JSON line) and return their exit status."""
-    import socket
+    """Spawn the N ranks as children, relay their output (rank 0 prints the JSON line) and return their exit status.  This process
+    never loads HIP or torch: GPUs are counted from the KFD topology in sysfs (colnde.distributed.visible_gpu_count)."""
     import subprocess
-    import torch
-    visible = torch.cuda.device_count()
-    if visible < n_gpus:
-        print("bench.py: --gpus %d but only %d HIP device(s) visible on this node" % (n_gpus, visible), file=sys.stderr)
+    from colnde.distributed import visible_gpu_count
+    visible = visible_gpu_count()
+    if visible is not None and visible < n_gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) visible on this node (KFD topology / *_VISIBLE_DEVICES)" % (n_gpus, visible), file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(launcher_command(n_gpus, argv, port), env=env)
+    return subprocess.call(launcher_command(n_gpus, argv), env=env)
 
 
 def main():
@@ -264,13 +263,15 @@ def main():
     ap.add_argument("--columns", type=int, default=32768, help="columns per GPU (weak scaling); 32768 = one 32-column wavefront per SIMD")
     ap.add_argument("--frames", type=int, default=289, help="saved frames (2-day suite: 289)")
     ap.add_argument("--substeps", type=int, default=2)
+    ap.add_argument("--global-columns", type=int, default=0, help="N > 1: a GLOBAL column count dealt over the ranks in contiguous, possibly "
+                    "ragged shards (colnde.distributed.shard_columns) instead of --columns per GPU: strong scaling, exercises uneven shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the block that times the other BASELINE configs after the headline (N = 1 only)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # invoked plainly with N > 1: become the launcher.  Nothing in this process has touched the GPU (device_count() does not
-        # initialise it on this image); the ranks are fresh children, never an exec of a process that holds a HIP context.
+        # invoked plainly with N > 1: become the launcher.  Nothing in this process touches HIP or imports torch;
+        # the ranks are fresh children, never an exec of a process that holds a HIP context.
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
@@ -314,6 +315,13 @@ def main():
             os.close(saved_fd)
 
     ncol = args.columns
+    n_global = ncol * world
+    if args.global_columns > 0:
+        from colnde.distributed import shard_columns
+        lo, hi = shard_columns(args.global_columns, rank, world)
+        ncol, n_global = hi - lo, args.global_columns
+        if ncol < 1:
+            raise SystemExit("--global-columns %d leaves rank %d without columns" % (args.global_columns, rank))
     # each rank generates only its shard of the global synthetic suite (seeded per rank: independent columns)
     prob = synthetic.wind_mixing_problem(ncol, n_frames=args.frames, substeps=args.substeps,
                                          seed=synthetic.SEED + rank)
@@ -323,7 +331,7 @@ def main():
     scal = np.array([1.0, 1.0, 1.0, 5e-3, 5e-3, 5e-3], dtype=np.float64)   # NDE_training.jl:257-258 defaults
 
     nde = colnde.ColumnNDE(cfg, ncol, device=local_rank)
-    nde.set_global_columns(ncol * world)
+    nde.set_global_columns(n_global)
     x0 = torch.from_numpy(prob.x0).to(dev)
     bcs = torch.from_numpy(prob.bcs).to(dev)
     w = torch.from_numpy(wprob.weights).to(dev)
@@ -360,6 +368,20 @@ def main():
         torch.cuda.synchronize()
         return float(te.item())
 
+    def allreduce_raw(t, op):
+        if comm is not None:
+            comm.allreduce(t, op)
+        else:
+            dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op])
+
+    weights_spread = None
+    if comm is not None or dist is not None:
+        # divergence guard: every rank must hold the identical weight vector before (and, in training, between) the all-reduced steps
+        from colnde.distributed import weights_in_sync
+        ok, weights_spread = weights_in_sync(w, lambda t: allreduce_raw(t, "max"))
+        if not ok:
+            raise SystemExit("bench.py: the ranks' weight vectors differ (checksum spread %.3e)" % weights_spread)
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -368,8 +390,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize()
+    own_compute = time.perf_counter() - t0            # this rank's K steps, before it waits for the slowest rank
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    own = time.perf_counter() - t0
+    elapsed = max_over_ranks(own)
     ms_fwd, n_fwd = nde.kernel_time("forward")
     ms_adj, n_adj = nde.kernel_time("adjoint")
     ms_red, n_red = nde.kernel_time("reduce")
@@ -383,9 +408,23 @@ def main():
     barrier()
     elapsed_plain = max_over_ranks(time.perf_counter() - t0)
     res = out.cpu().numpy()
+    per_rank_ms = allreduce_ms = None
+    if comm is not None or dist is not None:
+        slots = torch.zeros(world, dtype=torch.float32, device=dev)
+        slots[rank] = own_compute / args.steps * 1e3
+        allreduce_raw(slots, "sum")
+        per_rank_ms = [float(x) for x in slots.cpu()]
+        # the exchange step alone: K all-reduces of the result buffer, back to back
+        scratch = out.clone()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            allreduce_raw(scratch, "sum")
+        torch.cuda.synchronize()
+        allreduce_ms = max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3
 
     if rank == 0:
-        colsteps_per_step = ncol * world * cfg.n_steps
+        colsteps_per_step = n_global * cfg.n_steps
         value = colsteps_per_step * args.steps / elapsed
         units_per_launch = ncol * cfg.n_steps                     # one adjoint launch covers this rank's columns
         adj_s = ms_adj / max(n_adj, 1) * 1e-3
@@ -413,13 +452,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_without_kernel_events": elapsed_plain / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.global_columns > 0 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "wind_mixing train_NDE 2DaySuite shape (BASELINE configs[2]: 8 sims x 32 levels x 289 frames, fwd+adjoint): synthetic suite replicated to "
                             "%d columns/GPU x %d levels x %d frames, %d RK4 sub-steps/frame, MPP + zero_weights + train_gradient, "
                             "3 x (96-50-20-31 mish), six-term loss" % (ncol, cfg.Nz, args.frames, cfg.substeps),
-                "columns_per_gpu": ncol, "levels": cfg.Nz, "frames": args.frames, "substeps": cfg.substeps,
+                "columns_per_gpu": ncol, "columns_global": n_global, "levels": cfg.Nz, "frames": args.frames, "substeps": cfg.substeps,
                 "rk4_steps": cfg.n_steps, "n_params": cfg.n_params, "parallelism": "columns sharded x%d" % world,
                 "exchange": "none (one rank)" if (comm is None and dist is None) else
                             ("colnde_comm (RCCL behind the C ABI)" if comm is not None else "torch.distributed nccl (RCCL)"),
@@ -446,6 +485,9 @@ def main():
                 "engine": {1: "tile16", 2: "regtile"}.get(nde.engine, str(nde.engine)),
                 "plan": plan,
             },
+            "multi_gpu": None if per_rank_ms is None else {
+                "per_rank_ms_per_step_before_the_barrier": per_rank_ms, "allreduce_alone_ms": allreduce_ms,
+                "allreduce_floats": nde.n_params + 8, "weights_checksum_spread_over_ranks": weights_spread},
             "loss_total": float(res[nde.n_params + 6]),
             "grad_l2": float(np.linalg.norm(res[:nde.n_params])),
         }

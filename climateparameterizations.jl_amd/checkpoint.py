@@ -223,12 +223,21 @@ def write_data_NN(FILE_PATH, uw_NN, vw_NN, wT_NN):
 # ---- extract_NN (data_extraction.jl:1-149) -----------------------------------------------------------------------------------
 def extract_NN(FILE_PATH, OUTPUT_PATH, type: str):
     """Of the LAST stage's entries, keep the one with the smallest total loss (`NN_index = argmin(total_losses)`, :72-75) together
-    with its optimiser (η, β, state) and the whole loss history of that stage; type "NDE" or anything else for a flux-NN log."""
+    with its optimiser (η, β, state) and the whole loss history of that stage; type "NDE" or anything else for a flux-NN log.
+
+    FORMAT: both paths are `GroupFile` directory trees (this module's container), NOT `.jld2` files — a log written here cannot be
+    opened by the reference's Julia `extract_NN` / `train_NDE_args.jl`, nor the reverse; the key paths, the stage/count bookkeeping and
+    the selection rule are the reference's (tests/test_checkpoint.py holds the key list its reader asks for), and INTEGRATION.md has
+    an (untested: no Julia in the build image) copy loop between the two containers.  Like the reference, the last stage is the group
+    named `"$N_stages"` with N_stages = the number of stage groups (data_extraction.jl:6-8): stages must be named 1..N."""
     with GroupFile(FILE_PATH, "r") as file:
         train_files = file["training_info/train_files"]
         if type == "NDE":
             N_stages = len(file.keys("training_data/neural_network/uw"))
-            stage = file.keys("training_data/neural_network/uw")[N_stages - 1]
+            stage = str(N_stages)
+            if not file.haskey("training_data/neural_network/uw/%s" % stage):
+                raise KeyError("training_data/neural_network/uw/%s: the reference indexes the last stage as \"$N_stages\" (data_extraction.jl:8); "
+                               "stage groups must be named 1..N, found %s" % (stage, file.keys("training_data/neural_network/uw")))
             N_data = len(file.keys("training_data/neural_network/uw/%s" % stage))
             train_parameters = file["training_info/parameters"] if "parameters" in file.keys("training_info") else None
             loss_scalings = file["training_info/loss_scalings"] if "loss_scalings" in file.keys("training_info") else None
@@ -269,7 +278,8 @@ def extract_NN(FILE_PATH, OUTPUT_PATH, type: str):
 
 def load_extracted_NDE(EXTRACTED_PATH, rate: Optional[float] = None):
     """What train_NDE_args.jl:124-147 reads back to resume: the three networks, the training parameters and — when `rate` is given —
-    `ADAM(rate)` carrying the stored β and state."""
+    `ADAM(rate)` carrying the stored β and state.  EXTRACTED_PATH is a `GroupFile` tree written by this module's `extract_NN`, not a
+    `.jld2` (see `extract_NN`): networks come back as (θ, layer sizes, activations) records, the ADAM state as flat (m, v, βᵗ)."""
     with GroupFile(EXTRACTED_PATH, "r") as file:
         nets = {k: file["neural_network/%s" % k] for k in ("uw", "vw", "wT")}
         params = file["training_info/parameters"]

@@ -24,6 +24,38 @@ def shard_columns(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def visible_gpu_count(sysfs_root: str = "/sys/class/kfd/kfd/topology/nodes", env=None) -> Optional[int]:
+    """How many GPUs a child process will see, WITHOUT touching HIP (a launcher that forks ranks must not hold a runtime): the KFD
+    topology nodes with compute units (`simd_count` > 0: CPU nodes have 0), cut down by ROCR_VISIBLE_DEVICES and then by
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (comma-separated lists; an empty list hides everything).  None when the topology is
+    not readable (no amdgpu driver in this container): the caller then lets the ranks find out."""
+    env = os.environ if env is None else env
+    n = None
+    try:
+        nodes = sorted(os.listdir(sysfs_root), key=lambda q: int(q) if q.isdigit() else 1 << 30)
+        n = 0
+        for node in nodes:
+            try:
+                with open(os.path.join(sysfs_root, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in env:
+            listed = [q for q in env[var].split(",") if q.strip() != ""]
+            if not listed:
+                return 0                   # an empty list hides every device, whatever the topology says
+            if n is not None:
+                n = min(n, len(listed))
+            if var != "ROCR_VISIBLE_DEVICES":
+                break                      # HIP_VISIBLE_DEVICES wins over CUDA_VISIBLE_DEVICES; both index into what ROCR left visible
+    return n
+
+
 def allreduce_loss_grad(buf, group=None):
     """SUM all-reduce of the [n_params + 8] result buffer (torch tensor, CPU or device); returns it."""
     import torch.distributed as dist
@@ -84,29 +116,68 @@ class Comm:
             pass
 
 
-def exchange_unique_id(rank: int, world: int, make_id, key: str = "colnde_uid") -> bytes:
+_BOOTSTRAPS = 0      # per-process count of exchange_unique_id calls: every rank makes the same sequence of calls, so the n-th call uses the same key everywhere
+
+
+def exchange_unique_id(rank: int, world: int, make_id, key: str = "colnde_uid", store=None) -> bytes:
     """Host-side bootstrap: rank 0 calls `make_id()` and publishes the bytes through the launcher's TCP store (MASTER_ADDR /
     MASTER_PORT, as torch.distributed's env:// rendezvous uses it: every rank a client when torchrun hosts the store, rank 0 the server
-    otherwise); every rank returns the same bytes.  No process group, no collective, no GPU."""
+    otherwise); every rank returns the same bytes.  No process group, no collective, no GPU.
+
+    The store outlives one bootstrap (torchrun's agent keeps it for the whole job), so every call publishes under a key of its own —
+    `<key>/<n>` with n this process's call count, identical on every rank — and rank 0 deletes it once all ranks have read: a second
+    communicator in the same job (another problem, a retry) can never pick up the first one's id."""
+    global _BOOTSTRAPS
     from datetime import timedelta
-    from torch.distributed import TCPStore
-    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = int(os.environ.get("MASTER_PORT", "29500"))
-    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
-    store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300), multi_tenant=True)
+    import time
+    if store is None:
+        from torch.distributed import TCPStore
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29500"))
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
+        store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300), multi_tenant=True)
+    k = "%s/%d" % (key, _BOOTSTRAPS)
+    _BOOTSTRAPS += 1
     if rank == 0:
-        store.set(key, make_id())
-    uid = bytes(store.get(key))
-    # keep the store alive until every rank has read the id (rank 0 may host it)
-    store.add(key + "/read", 1)
+        store.set(k, make_id())
+    uid = bytes(store.get(k))                     # blocks until rank 0 has published THIS bootstrap's id
+    store.add(k + "/read", 1)
     if rank == 0:
-        import time
+        # keep the store alive (rank 0 may host it) and the key in place until every rank has read it, then retire both keys
         t0 = time.time()
-        while int(store.add(key + "/read", 0)) < world and time.time() - t0 < 300:
+        while int(store.add(k + "/read", 0)) < world:
+            if time.time() - t0 > 300:
+                raise RuntimeError("exchange_unique_id: %d of %d ranks read the id within 300 s" % (int(store.add(k + "/read", 0)), world))
             time.sleep(0.01)
+        for dead in (k, k + "/read"):
+            try:
+                store.delete_key(dead)
+            except Exception:                      # a store without delete support: the per-call key already makes reuse impossible
+                pass
     return uid
 
 
 def bootstrap_comm(rank: int, world: int, device: int, key: str = "colnde_uid") -> Comm:
     """Rank 0 makes the RCCL unique id, `exchange_unique_id` hands it to every rank, every rank joins."""
     return Comm(rank, world, exchange_unique_id(rank, world, Comm.unique_id, key), device)
+
+
+def weights_in_sync(theta, rank_allreduce_max, tol: float = 0.0):
+    """Divergence guard for replicated weights.  Every rank forms three float64 checksums (Σθ, Σ|θ|, Σ (1 + i mod 65521) θᵢ — the last
+    one sees permutations), splits each into a float32 head and tail, and contributes [c; −c] (12 floats) to ONE MAX all-reduce: the
+    result holds max and −min of every component over the ranks.
+    Returns (in_sync, spread), spread = the largest max − min (0.0 when the replicas are bit-identical, which identical ADAM steps on an
+    identical all-reduced gradient guarantee).  `rank_allreduce_max(t)` reduces the tensor in place (Comm.allreduce(t, "max"), or
+    torch.distributed.all_reduce with ReduceOp.MAX)."""
+    import torch
+    d = theta.detach().double()
+    pos = (torch.arange(d.numel(), device=d.device, dtype=torch.float64) % 65521.0) + 1.0
+    c64 = torch.stack([d.sum(), d.abs().sum(), (d.reshape(-1) * pos).sum()])
+    hi = c64.float()
+    lo = (c64 - hi.double()).float()
+    c = torch.cat([hi, lo])
+    t = torch.cat([c, -c]).contiguous()
+    rank_allreduce_max(t)
+    t = t.cpu()
+    spread = float((t[:6] + t[6:]).abs().max())
+    return spread <= tol, spread

@@ -148,32 +148,54 @@ def train_NDE(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epoch
         (optimizer, epoch) solve starts from zero moments and βᵗ = β (`continue_state=True` carries them over instead);
       * per iteration: loss and gradient at θ, `cb(θ, total, losses, loss_scalings)` (true = stop), `update!(opt, θ, g)`,
         then `save_best`: if this iteration's loss is the lowest so far, `min_θ = copy(θ)` — taken AFTER the update, i.e. the
-        point one ADAM step past the best-loss point; after `maxiters` iterations θ reverts to `min_θ`."""
+        point one ADAM step past the best-loss point; at `i == maxiters` θ reverts to `min_θ` and `cb(min_θ, min_err...)` is called once
+        more, so a solve that is not halted issues maxiters + 1 callbacks (the log of `write_data_NDE_training` has that many records)."""
     theta = np.array(weights, dtype=np.float32)
     history = []
     for opt in optimizers:
         for _ in range(epochs):
             if not continue_state:
                 opt.reset()
-            best, best_theta = np.inf, theta.copy()
+            best, best_losses, best_theta = np.inf, None, theta.copy()
+            halted = False
             for it in range(maxiters):
                 total, losses, grad = problem.grad_loss(theta)
                 history.append(dict(total=total, **losses))
                 if cb is not None and cb(theta, total, losses, problem.loss_scalings):
+                    halted = True
                     break
                 opt.update(theta, grad.astype(np.float64))
                 if total < best:
-                    best, best_theta = total, theta.copy()
+                    best, best_losses, best_theta = total, losses, theta.copy()
             theta = best_theta
+            # `if i == maxiters ... θ = min_θ; cb(θ, x...); break` — the extra callback on the reverted best point, the one through which
+            # the reference's `write_data_NDE_training` logs the (maxiters+1)-th record of every solve (its return value is ignored)
+            if cb is not None and not halted and maxiters > 0 and best_losses is not None:
+                cb(theta, best, best_losses, problem.loss_scalings)
     return TrainResult(theta, history)
 
 
+def _check_replicas(theta, comm, process_group, it):
+    from .distributed import weights_in_sync
+    if comm is not None:
+        red = lambda t: comm.allreduce(t, "max")
+    else:
+        import torch.distributed as dist
+        red = lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX, group=process_group)
+    ok, spread = weights_in_sync(theta, red)
+    if not ok:
+        raise RuntimeError("train_NDE_device: the ranks' weight vectors differ at iteration %d (checksum spread %.3e): the replicas "
+                           "no longer apply identical updates" % (it, spread))
+
+
 def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epochs: int = 1, maxiters: int = 500,
-                     process_group=None, continue_state: bool = False, comm=None) -> TrainResult:
+                     process_group=None, continue_state: bool = False, comm=None, sync_check_every: int = 0) -> TrainResult:
     """`train_NDE`'s optimiser loop (NDE_training.jl:340-372) with θ, the ADAM state and the best-loss copy resident on the
     GPU: per iteration one `colnde_loss_grad_dev`, [one SUM all-reduce of the gradient buffer when the columns are sharded
     over `process_group`], one fused `colnde_adam_step_dev`; nothing crosses PCIe until the end.  Same update rule, per-solve
-    state reset and `save_best` selection as `train_NDE`; the per-iteration callback is not available here."""
+    state reset and `save_best` selection as `train_NDE`; the per-iteration callback is not available here.
+    sync_check_every = K > 0 (sharded runs): every K iterations, and before the first, the ranks compare checksums of their weight vectors
+    with one 12-float MAX all-reduce (`distributed.weights_in_sync`) and raise if the replicas have drifted apart."""
     import torch
     eng = problem.engine
     dev = torch.device("cuda", eng.device)
@@ -195,6 +217,8 @@ def train_NDE_device(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM]
             best = torch.full((), float("inf"), dtype=torch.float32, device=dev)
             best_theta = theta.clone()
             for it in range(maxiters):
+                if sync_check_every > 0 and it % sync_check_every == 0 and (comm is not None or process_group is not None):
+                    _check_replicas(theta, comm, process_group, it)
                 eng.loss_grad(theta, sc, out=out)
                 if comm is not None:                       # colnde.distributed.Comm: RCCL behind the C ABI
                     comm.allreduce_result(eng, out)

@@ -77,3 +77,76 @@ def test_resume_from_extracted_file_continues_the_optimiser(tmp_path):
     np.testing.assert_array_equal(weights, first.weights)
     second = train_NDE(prob, weights, [opt2], epochs=1, maxiters=10, continue_state=True)
     np.testing.assert_allclose(second.weights, full.weights, rtol=1e-6, atol=1e-7)
+
+
+# What the reference's READER asks a training log for (wind_mixing/src/data_extraction.jl:4-86, type == "NDE"; :88-104 otherwise), as key
+# templates — data, not source — with $S = "$N_stages" and $I = the entry index:
+READER_KEYS_NDE = ["training_info/train_files", "training_info/parameters", "training_info/loss_scalings",
+                   "training_data/neural_network/uw/$S", "training_data/loss/total/$S/$I", "training_data/loss/profile/$S/$I",
+                   "training_data/loss/gradient/$S/$I", "training_data/loss/u/$S/$I", "training_data/loss/v/$S/$I", "training_data/loss/T/$S/$I",
+                   "training_data/loss/∂u∂z/$S/$I", "training_data/loss/∂v∂z/$S/$I", "training_data/loss/∂T∂z/$S/$I",
+                   "training_data/neural_network/uw/$S/$I", "training_data/neural_network/vw/$S/$I", "training_data/neural_network/wT/$S/$I",
+                   "training_data/optimizer/η/$S/$I", "training_data/optimizer/β/$S/$I", "training_data/optimizer/state/$S/$I"]
+READER_KEYS_NN = ["training_info/train_files", "training_info/parameters", "training_data/loss/$I", "training_data/neural_network/$I"]
+
+
+def test_written_tree_has_exactly_the_keys_the_reference_reader_asks_for(tmp_path):
+    """no JLD2 bytes, but the key list of the tree `write_*_training` produces must be the key list
+    `extract_NN` of the reference reads — every reader key present for every stage and entry, and no leaf the reader does not know."""
+    import os
+    import re
+    path = str(tmp_path / "log.tree")
+    opt = ADAM(1e-3)
+    ck.write_metadata_NDE_training(path, ["f"], [1], [range(1, 5)], {"Pr": 1.0}, [[opt]], _net(0), _net(1), _net(2))
+    sc = dict(u=1.0, v=1.0, T=1.0, dudz=5e-3, dvdz=5e-3, dTdz=5e-3)
+    for stage, n in ((1, 2), (2, 3)):
+        for i in range(n):
+            opt.update(np.zeros(3, np.float32), np.ones(3))
+            ck.write_data_NDE_training(path, _losses(1.0 + i), sc, _net(3), _net(4), _net(5), stage, opt)
+    with ck.GroupFile(path) as f:
+        leaves = set()
+
+        def walk(g):
+            for k in f.keys(g):
+                q = (g + "/" + k) if g else k
+                if os.path.isdir(f._p(q)):
+                    walk(q)
+                else:
+                    leaves.add(q)
+        walk("training_data")
+        for stage, n in (("1", 2), ("2", 3)):
+            for i in range(1, n + 1):
+                for t in READER_KEYS_NDE:
+                    assert f.haskey(t.replace("$S", stage).replace("$I", str(i))), t
+        templ = {re.sub(r"/\d+/\d+$", "/$S/$I", q) for q in leaves}
+        assert templ == {t for t in READER_KEYS_NDE if t.endswith("$S/$I")}, templ ^ {t for t in READER_KEYS_NDE if t.endswith("$S/$I")}
+    # the flux-NN log (type != "NDE")
+    p2 = str(tmp_path / "nn.tree")
+    ck.write_metadata_NN_training(p2, ["f"], {"Pr": 1.0}, [1], [ADAM(1e-3)], _net(0), "uw")
+    for i in range(3):
+        ck.write_data_NN_training(p2, 1.0 / (i + 1), _net(i))
+    with ck.GroupFile(p2) as f:
+        for i in (1, 2, 3):
+            for t in READER_KEYS_NN:
+                assert f.haskey(t.replace("$I", str(i))), t
+    # in the build container (where the reference is readable) the templates above are checked against the reader's own text
+    ref = "/root/reference/wind_mixing/src/data_extraction.jl"
+    if os.path.exists(ref):
+        src = open(ref, encoding="utf-8").read()
+        asked = set(re.findall(r'file\["([^"]+)"\]', src[:src.index("@info \"Writing file\"")]))
+        norm = {a.replace("$(N_stages)", "$S").replace("$N_stages", "$S").replace("$NN_index", "$I").replace("$i", "$I") for a in asked}
+        norm.discard("training_data/loss/$S/$I")          # the legacy single-loss layout (:47-59), not written by data_writing.jl any more
+        for group in ("training_info", "training_data", "training_data/loss", "training_data/neural_network/uw"):
+            norm.discard(group)                            # groups the reader only counts the entries of (`keys(file[...])`)
+        assert norm == set(READER_KEYS_NDE) | set(READER_KEYS_NN), norm ^ (set(READER_KEYS_NDE) | set(READER_KEYS_NN))
+
+
+def test_extract_nn_indexes_the_last_stage_by_count_like_the_reference(tmp_path):
+    path = str(tmp_path / "log.tree")
+    opt = ADAM(1e-3)
+    ck.write_metadata_NDE_training(path, ["f"], [1], [range(1, 5)], {"Pr": 1.0}, [[opt]], _net(0), _net(1), _net(2))
+    sc = dict(u=1.0, v=1.0, T=1.0, dudz=5e-3, dvdz=5e-3, dTdz=5e-3)
+    opt.update(np.zeros(3, np.float32), np.ones(3))
+    ck.write_data_NDE_training(path, _losses(1.0), sc, _net(3), _net(4), _net(5), 3, opt)       # one stage group, named "3"
+    with pytest.raises(KeyError, match="N_stages"):
+        ck.extract_NN(path, str(tmp_path / "out.tree"), "NDE")

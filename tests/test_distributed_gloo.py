@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 import colnde
 from colnde import synthetic
-from colnde.distributed import shard_columns, allreduce_loss_grad, split_result
+from colnde.distributed import shard_columns, allreduce_loss_grad, split_result, weights_in_sync
 from oracle import cref, nde_oracle as O
 
 N_COL = 7   # deliberately not divisible by the world size (ragged shards)
@@ -74,3 +74,34 @@ def test_two_rank_gloo_allreduce_matches_single_process(tmp_path):
     assert np.isclose(t, tot, rtol=1e-5)
     np.testing.assert_allclose(te, terms, rtol=1e-4)
     assert np.linalg.norm(g - grad) < 1e-4 * np.linalg.norm(grad)
+
+
+def _guard_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    red = lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    theta = torch.linspace(-1.0, 1.0, 19563, dtype=torch.float32)
+    same = weights_in_sync(theta, red)
+    drift = theta.clone()
+    if rank == 1:
+        drift[777] = torch.nextafter(drift[777], torch.tensor(2.0))        # ONE ulp of ONE weight on one rank
+    one_ulp = weights_in_sync(drift, red)
+    swapped = theta.clone()
+    if rank == 1:
+        swapped[[10, 11]] = swapped[[11, 10]]                              # the same multiset: only the position-weighted checksum sees it
+    np.save(os.path.join(out_dir, "guard%d.npy" % rank), np.array([same[0], same[1], one_ulp[0], one_ulp[1], weights_in_sync(swapped, red)[0]], np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_weight_divergence_guard(tmp_path):
+    """ranks check that their replicated weight vectors are identical with ONE 12-float MAX all-reduce; a one-ulp
+    drift of one weight on one rank is caught on EVERY rank (bench.py runs the check once, train_NDE_device every K iterations)."""
+    world = 2
+    mp.spawn(_guard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        same_ok, same_spread, ulp_ok, ulp_spread, swapped_ok = np.load(tmp_path / ("guard%d.npy" % r))
+        assert same_ok == 1.0 and same_spread == 0.0
+        assert ulp_ok == 0.0 and ulp_spread > 0.0
+        assert swapped_ok == 0.0

@@ -48,21 +48,35 @@ def test_c_port_matches_golden(name):
     assert _rel(cref.rhs(p.cfg, g["x0"], g["bcs"], g["weights"], float(g["rhs_t"])), g["rhs"].astype(np.float64)) < 2e-5
 
 
+# the tolerances of tests/test_gpu_parity.py for the same families (about 10x the error measured on an MI355X, profiles/r03_parity_errors.json):
+# (solution abs, loss/terms rel, gradient rel L2, one RHS rel)
+GOLDEN_TOL = {
+    "wind_mixing_mpp": (2e-5, 8e-5, 2e-4, 1e-6),
+    "wind_mixing_diurnal_smooth": (2e-5, 8e-5, 2e-4, 1e-6),
+    "free_convection_32": (8e-5, 3e-3, 4e-3, 1e-6),
+    "conv_adj_nde_32": (8e-5, 3e-3, 4e-3, 1e-6),
+}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hip_engine_matches_golden(name):
     g = np.load(os.path.join(HERE, name + ".npz"))
     p = CASES[name]()
+    sol_atol, loss_rtol, grad_rel, rhs_rel = GOLDEN_TOL[name]
     with colnde.ColumnNDE(p.cfg, g["x0"].shape[0]) as nde:
         nde.set_problem(g["x0"], g["bcs"], g["truth"])
         sol = nde.forward(g["weights"])
         tot, terms, grad = nde.loss_grad(g["weights"], g["scalings"])
         dx = nde.rhs(g["x0"], g["weights"], g["bcs"], float(g["rhs_t"]))
-    assert np.abs(sol - g["sol"]).max() < 1e-4                      # float32 engine vs float64 oracle, O(1) profiles
-    np.testing.assert_allclose(terms, g["terms"], rtol=2e-3, atol=1e-12)
-    assert np.isclose(tot, float(g["total"]), rtol=2e-3)
-    assert _rel(grad, g["grad"].astype(np.float64)) < 5e-3
-    assert _rel(dx, g["rhs"].astype(np.float64)) < 2e-5
+    from tests.test_gpu_parity import _record
+    _record("golden/" + name, sol_abs=np.abs(sol - g["sol"]).max(), loss_rel=abs(tot - float(g["total"])) / abs(float(g["total"])),
+            grad_rel=_rel(grad, g["grad"].astype(np.float64)), rhs_rel=_rel(dx, g["rhs"].astype(np.float64)))
+    assert np.abs(sol - g["sol"]).max() < sol_atol                  # float32 engine vs float64 oracle, O(1) profiles
+    np.testing.assert_allclose(terms, g["terms"], rtol=loss_rtol, atol=1e-3 * loss_rtol * float(np.sum(g["terms"])))
+    assert np.isclose(tot, float(g["total"]), rtol=loss_rtol)
+    assert _rel(grad, g["grad"].astype(np.float64)) < grad_rel
+    assert _rel(dx, g["rhs"].astype(np.float64)) < rhs_rel
 
 
 @pytest.mark.gpu

@@ -11,7 +11,7 @@ from tests.test_oracle import VARIANTS, INPLACE_VARIANTS
 pytestmark = pytest.mark.gpu
 
 # Tolerances of the float32 HIP path against the float64 oracle: about 10x the largest error MEASURED on an MI355X for the
-# family of cases (profiles/r02_parity_errors.json keeps the run they were set from; COLNDE_RECORD_ERRORS=1 re-measures).
+# family of cases (profiles/r03_parity_errors.json keeps the last measuring run; COLNDE_RECORD_ERRORS=1 re-measures).
 # Wind mixing, 3..9 frames (smooth profiles, loss O(1e-3)): measured sol 2.1e-6, loss 8e-6, gradient 1.8e-5.
 SOL_ATOL = 2e-5          # scaled units, O(1) profiles
 LOSS_RTOL = 8e-5
@@ -36,7 +36,7 @@ def _rel(a, b):
 
 def _record(case, **errs):
     """With COLNDE_RECORD_ERRORS set, append the measured errors to gpurun_out/parity_errors.jsonl: the tolerances in this
-    file are set to about 10x what this records (profiles/r02_parity_errors.json keeps the run they were set from)."""
+    file are set to about 10x what this records (profiles/r03_parity_errors.json keeps the last measuring run)."""
     import json
     import os
     if os.environ.get("COLNDE_RECORD_ERRORS"):
@@ -445,6 +445,67 @@ def test_split_kernels_plain_tape(name, monkeypatch):
         assert np.isclose(res[rich][0], tot, rtol=LOSS_RTOL)
         assert _rel(res[rich][2], g) < GRAD_REL
     assert _rel(res["1"][2], res["0"][2].astype(np.float64)) < 0.25 * GRAD_REL
+
+
+
+# ---- config 2's and config 3's shipped kernels at THEIR size: AUTO at 4,096 columns = the net-split pair with the PLAIN tape --------------
+def _assert_config2_plan(plan, grad=True):
+    assert plan["engine"] == 1 and plan["split_forward"]
+    if grad:
+        assert plan["split_adjoint"] and plan["dw_taped"] and not plan["split_rich_tape"] and plan["block_columns"] > 2048
+
+
+def test_auto_4096_columns_full_horizon_forward_against_oracle_on_sampled_columns():
+    """BASELINE configs[1] as shipped: engine AUTO, 4,096 columns x 32 levels x 576 RK4 steps (`rt16sh_forward_kernel`, one 16-column tile
+    per CU).  Columns are independent given the weights, so the float64 oracle integrates a sample of 64 of them — one from every 64th
+    tile position, every lane of a tile covered — and the HIP trajectories of exactly those columns must match over the whole horizon."""
+    p = synthetic.wind_mixing_problem(4096, n_frames=289, weight_divisor=1e2)
+    idx = np.arange(64) * 64 + (np.arange(64) * 5) % 64              # 64 distinct tiles, all 16 in-tile positions four times
+    sol = O.solve(p.cfg, p.x0[idx], p.bcs[idx], p.weights)
+    with colnde.ColumnNDE(p.cfg, 4096) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        sol_g = nde.forward(p.weights)
+        _assert_config2_plan(nde.plan(), grad=False)
+    _record("auto_4096x576/forward_sampled", sol_abs=np.abs(sol_g[idx] - sol).max())
+    assert np.isfinite(sol_g).all()
+    assert np.abs(sol_g[idx] - sol).max() < LONG_SOL_ATOL
+
+
+def test_auto_4096_columns_full_horizon_gradient_against_oracle_on_replicated_suite():
+    """The same kernels' gradient path at 4,096 columns x 576 steps (plain tape: the rich one stops at 2,048 columns) against the float64
+    oracle.  The loss is a MEAN over simulations (NDE_training.jl:312-317): 64 distinct columns dealt round-robin 64 times over the 4,096
+    slots have exactly the loss terms and gradient of the 64, which is what the oracle evaluates — while the GPU runs config-size grids,
+    tapes and dW GEMM slices."""
+    q = synthetic.wind_mixing_problem(64, n_frames=289, weight_divisor=1e2)
+    truth = O.solve(q.cfg, q.x0, q.bcs, q.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(q.cfg)
+    tot, terms, g, sol = O.loss_and_grad(q.cfg, q.x0, q.bcs, q.weights, truth, sc)
+    rep = np.arange(4096) % 64
+    with colnde.ColumnNDE(q.cfg, 4096) as nde:
+        nde.set_problem(q.x0[rep], q.bcs[rep], truth[rep])
+        tot_g, terms_g, grad_g = nde.loss_grad(q.weights, sc)
+        _assert_config2_plan(nde.plan())
+    _record("auto_4096x576/gradient_replicated", loss_rel=abs(tot_g - tot) / tot, terms_rel=np.abs(terms_g / terms - 1).max(), grad_rel=_rel(grad_g, g))
+    np.testing.assert_allclose(terms_g, terms, rtol=LONG_TERMS_RTOL[1e2], atol=0)
+    assert np.isclose(tot_g, tot, rtol=LONG_LOSS_RTOL[1e2], atol=0)
+    assert _rel(grad_g, g) < LONG_GRAD_REL[1e2]
+
+
+def test_auto_4096_distinct_columns_short_horizon_gradient_against_oracle():
+    """4,096 DISTINCT columns (every tile different, > 2,048: plain tape) over 16 frames: the oracle evaluates all of them."""
+    p = synthetic.wind_mixing_problem(4096, n_frames=17, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, 4096) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+        _assert_config2_plan(nde.plan())
+    _record("auto_4096x32/all_columns", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g))
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    np.testing.assert_allclose(terms_g, terms, rtol=LOSS_RTOL, atol=0)
+    assert _rel(grad_g, g) < GRAD_REL
 
 
 @pytest.mark.parametrize("switch", ["COLNDE_T16_FWD_HELPER", "COLNDE_T16_ADJ_HELPER"])

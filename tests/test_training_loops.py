@@ -41,7 +41,7 @@ class FluxADAM:
         return out
 
 
-def galactic_solve(f, u0, opt, maxiters, keep=None):
+def galactic_solve(f, u0, opt, maxiters, keep=None, cb=None):
     """GalacticOptim 1.2.0 `__solve` for a Flux optimiser, save_best = true."""
     theta = np.array(u0, dtype=np.float64)              # θ = copy(prob.u0): a NEW array ⇒ a new IdDict key
     if keep is not None:
@@ -49,12 +49,16 @@ def galactic_solve(f, u0, opt, maxiters, keep=None):
     min_err, min_theta = np.inf, None
     for i in range(1, maxiters + 1):
         x, _, g = f(theta)
-        # cb(θ, x...) -> false
+        if cb is not None and cb(theta, x):             # cb_call = cb(θ, x...); elseif cb_call break
+            break
         theta -= opt.apply(theta, g)                    # update!(opt, θ, g)
         if x < min_err:
             min_err, min_theta = x, theta.copy()        # min_θ = copy(θ): after the update
-        if i == maxiters:
+        if i == maxiters:                               # "Last iteration, revert to best."
             theta = min_theta
+            if cb is not None:
+                cb(theta, min_err)                      # cb(θ, x...) once more, on the reverted point; then break
+            break
     return theta
 
 
@@ -84,7 +88,7 @@ def test_callback_stops_and_sees_reference_arguments():
     def cb(theta, total, losses, scalings):
         seen.append((theta.copy(), total, losses, scalings))
         return len(seen) >= 4
-    train_NDE(prob, np.zeros(12, np.float32), [ADAM(0.1)], epochs=1, maxiters=50, cb=cb)
+    train_NDE(prob, np.zeros(12, np.float32), [ADAM(0.1)], epochs=1, maxiters=50, cb=cb)      # halted: no extra callback
     assert len(seen) == 4 and seen[0][1] == prob.grad_loss(np.zeros(12))[0] and seen[0][3] is prob.loss_scalings
 
 
@@ -108,3 +112,25 @@ def test_flux_train_keeps_adam_state_across_calls():
     for _ in range(10):
         th -= lit.apply(th, P.q.grad_loss(th)[2])
     np.testing.assert_allclose(a, th, rtol=2e-5, atol=1e-6)
+
+
+def test_solve_issues_maxiters_plus_one_callbacks_the_last_on_the_reverted_best():
+    """GalacticOptim's `__solve` calls `cb(min_θ, min_err...)` once more at `i == maxiters`: an un-halted solve logs
+    maxiters + 1 records, the last one holding the reverted best θ and the best loss."""
+    prob = Quadratic()
+    lit_calls, calls = [], []
+    w = galactic_solve(prob.grad_loss, np.zeros(12), FluxADAM(0.3), 15, cb=lambda th, x: lit_calls.append((th.copy(), x)) and False)
+
+    def cb(theta, total, losses, scalings):
+        calls.append((theta.copy(), total))
+        return False
+    res = train_NDE(prob, np.zeros(12, np.float32), [ADAM(0.3)], epochs=1, maxiters=15, cb=cb)
+    assert len(lit_calls) == len(calls) == 16
+    assert len(res.history) == 15                                     # the extra callback evaluates nothing new
+    np.testing.assert_allclose(calls[-1][0], lit_calls[-1][0], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(calls[-1][0], res.weights, rtol=0, atol=0)
+    assert calls[-1][1] == min(c[1] for c in calls[:-1]) and np.isclose(calls[-1][1], lit_calls[-1][1], rtol=1e-6)
+    # two epochs: 2 x (maxiters + 1); a halted solve gets no extra call
+    calls.clear()
+    train_NDE(prob, np.zeros(12, np.float32), [ADAM(0.3)], epochs=2, maxiters=5, cb=cb)
+    assert len(calls) == 12
