@@ -791,11 +791,19 @@ static int t16_plan_dwtape(colnde_handle* h) {
     const size_t per_col = (size_t)n_steps * m.nst * (R + t16_ztape_col_floats(m) + m.ns) * sizeof(float);
     const int n16 = h->n_tiles * CT;
     int block = 0;
+    // the net-split pair's rich tape replaces the pre-activation tape on small blocks and is 4x its size per column (13,824 floats per
+    // 16-column record against 216 per column): it is part of the fit estimate, not an afterthought behind the 3 GB margin
+    const char* ezt0 = getenv("COLNDE_T16_ZTAPE");
+    const char* er0 = getenv("COLNDE_T16_SPLIT_RICH");
+    const bool rich_possible = h->adj_split && !(ezt0 && atoi(ezt0) == 0) && !(er0 && atoi(er0) == 0);
+    const size_t per_col_rich = (size_t)n_steps * m.nst * (R + rt_split_rich_record_floats() / CT + m.ns) * sizeof(float);
+    bool want_rich = false;
     if (want) {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const size_t margin = ((size_t)3 << 30) + (size_t)h->n_tiles * (m.n_params + 8) * sizeof(float);
-        const size_t fit = free_b > margin ? (free_b - margin) / per_col : 0;
+        const size_t budget = free_b > margin ? free_b - margin : 0;
+        const size_t fit = budget / per_col;
         if (fit >= (size_t)n16) block = n16;
         else if (fit >= CT) {
             const int nb = (int)(((size_t)n16 + fit - 1) / fit);
@@ -806,6 +814,14 @@ static int t16_plan_dwtape(colnde_handle* h) {
         const char* eb = getenv("COLNDE_T16_BLOCK");
         if (eb && atoi(eb) >= CT) block = std::min(n16, (atoi(eb) / CT) * CT);
         if (block <= 0) want = false;
+        // rich tape: by default on blocks of at most 2,048 columns; forced on by COLNDE_T16_SPLIT_RICH=1.  It must fit WITH the other tapes:
+        // a forced rich tape shrinks the block, an automatic one is dropped.
+        want_rich = want && rich_possible && ((er0 && atoi(er0) != 0) || block <= 128 * CT);
+        if (want_rich && (size_t)block * per_col_rich > budget) {
+            const size_t fit_rich = budget / per_col_rich / CT * CT;
+            if (er0 && atoi(er0) != 0 && fit_rich >= CT) block = (int)std::min<size_t>((size_t)block, fit_rich);
+            else want_rich = false;
+        }
     }
     if (!want) { h->t16_dwtape = 0; return 0; }
     const int tiles_b = block / CT;
@@ -864,8 +880,6 @@ static int t16_plan_dwtape(colnde_handle* h) {
     // net-split kernels on a small block (<= 2,048 columns, where it pays: 64-step iteration with the four-wave kernels 2.36 vs 2.48 ms at 1,024
     // columns, 2.69 vs 2.77 at 2,048, 3.99 vs 3.53 at 4,096): the rich tape in place of the pre-activations
     {
-        const char* er = getenv("COLNDE_T16_SPLIT_RICH");
-        const bool want_rich = h->adj_split && !(ezt && atoi(ezt) == 0) && (er ? atoi(er) != 0 : tiles_b <= 128);
         if (want_rich && hipMalloc((void**)&h->d_t16_ztape, n_rec * rt_split_rich_record_floats() * sizeof(float)) == hipSuccess) {
             h->split_rich = true;
             return 0;

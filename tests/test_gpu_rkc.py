@@ -162,7 +162,7 @@ def test_explicit_stage_count_below_the_bound_is_refused():
         assert np.isfinite(nde.forward(p.weights)).all()
 
 
-# tolerances: ~10x the errors measured on an MI355X (profiles/r02_parity_errors.json)
+# tolerances: ~10x the errors measured on an MI355X (profiles/r03_parity_errors.json)
 # absolute floors added to a small multiple of the float32 oracle's own distance from float64 (sol, loss, gradient)
 RKC_WM = (1e-4, 1e-4, 5e-4)                    # wind mixing kappa = 10, 26 stages
 RKC_CA = (2e-2, 2e-2, 5e-2)                    # CA-NDE axis from an inverted layer
