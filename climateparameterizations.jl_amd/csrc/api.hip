@@ -12,6 +12,7 @@
 
 #include "engine_tile16.h"
 #include "engine_regtile.h"
+#include "engine_fc.h"
 #include "column_ops.h"
 
 static thread_local std::string g_err;
@@ -59,6 +60,10 @@ struct colnde_handle {
     bool adj_split = false;         // ... and the gradient by rt16s_adjoint_kernel + tile16's dW GEMM
     bool fwd_split = false;         // forward solves by the net-split kernels (rt16sh_forward_kernel: three net waves + a helper wave per tile)
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
+    bool use_fc = false;            // 32-column free-convection engine (engine_fc.hip: Nz = 32 | 64, the reference's relu network, RK4)
+    float *d_fc_imgf = nullptr, *d_fc_imgb = nullptr, *d_fc_bias = nullptr;
+    unsigned int* d_fc_masks = nullptr;
+    int fc_block = 0, fc_nblocks = 0, fc_rows = 0;   // gradient path: columns per pass (multiple of 32), passes, slab rows
     float* d_wimg = nullptr;
     float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_tapez = nullptr;
     bool rt_fwd32 = false;         // COLNDE_RT_FWD=32 at creation: the 32-column forward kernel (no Z1 tape)
@@ -116,7 +121,7 @@ static int validate(const colnde_config* c) {
     for (int i = 1; i < c->n_save; i++)
         if (!(c->save_times[i] > c->save_times[i - 1])) return fail("save_times must be strictly increasing");
     if (c->n_columns < 1) return fail("n_columns must be >= 1");
-    if (c->engine != COLNDE_ENGINE_AUTO && c->engine != COLNDE_ENGINE_GENERIC && c->engine != COLNDE_ENGINE_MFMA)
+    if (c->engine != COLNDE_ENGINE_AUTO && c->engine != COLNDE_ENGINE_GENERIC && c->engine != COLNDE_ENGINE_MFMA && c->engine != COLNDE_ENGINE_FC32)
         return fail("unknown engine %d", c->engine);
     if (c->stepper != COLNDE_STEPPER_RK4 && c->stepper != COLNDE_STEPPER_RKC2) return fail("unknown stepper %d", c->stepper);
     if (c->rkc_stages != 0 && (c->rkc_stages < 2 || c->rkc_stages > 256)) return fail("rkc_stages = %d outside 2..256 (0 = automatic)", c->rkc_stages);
@@ -404,6 +409,19 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         delete h;
         return fail("engine = regtile requested, but it covers only Nz=32, three 96-50-20-31 nets, no smoothing, training RHS, RK4");
     }
+    // AUTO on the free-convection shape the reference trains: the 32-column engine (COLNDE_FC=0 keeps tile16)
+    {
+        const char* ef = getenv("COLNDE_FC");
+        h->use_fc = fc_supported(h->m, cfg->stepper) && (cfg->engine == COLNDE_ENGINE_FC32 || (cfg->engine == COLNDE_ENGINE_AUTO && !(ef && atoi(ef) == 0)));
+        if (cfg->engine == COLNDE_ENGINE_FC32 && !h->use_fc) {
+            delete h;
+            return fail("engine = fc32 requested, but it covers only FreeConvectionNDE with Dense(Nz,4Nz,relu), Dense(4Nz,4Nz,relu), Dense(4Nz,Nz-1), Nz = 32 or 64, RK4");
+        }
+        if (h->use_fc) {
+            hipError_t e = fc_set_kernel_attributes();
+            if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute (fc32) failed: %s", hipGetErrorString(e)); }
+        }
+    }
     const DevModel& m = h->m;
 #define ALLOC(ptr, n, T)                                                                   \
     do {                                                                                   \
@@ -417,6 +435,11 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     ALLOC(h->d_wf, (size_t)h->pk.pf_net * m.n_nets, float);
     ALLOC(h->d_wb, (size_t)h->pk.pb_net * m.n_nets, float);
     ALLOC(h->d_wimg, RT_IMG_FLOATS, float);
+    if (h->use_fc) {
+        ALLOC(h->d_fc_imgf, fc_image_floats(m.Nz), float);
+        ALLOC(h->d_fc_imgb, fc_image_floats(m.Nz), float);
+        ALLOC(h->d_fc_bias, fc_bias_floats(m.Nz), float);
+    }
     ALLOC(h->d_x0, (size_t)h->n_col * m.ns, float);
     ALLOC(h->d_bcs, (size_t)h->n_col * m.n_bc, float);
     ALLOC(h->d_sol, (size_t)h->n_col * cfg->n_save * m.ns, float);
@@ -454,14 +477,15 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     (void)hipSetDevice(h->device);
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
-                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc};
+                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc,
+                    h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
 }
 
 extern "C" int colnde_n_params(const colnde_handle* h) { return h ? h->m.n_params : -1; }
-extern "C" int colnde_engine(const colnde_handle* h) { return h ? (h->use_rt ? COLNDE_ENGINE_MFMA : COLNDE_ENGINE_GENERIC) : -1; }
+extern "C" int colnde_engine(const colnde_handle* h) { return h ? (h->use_rt ? COLNDE_ENGINE_MFMA : (h->use_fc ? COLNDE_ENGINE_FC32 : COLNDE_ENGINE_GENERIC)) : -1; }
 
 extern "C" int colnde_set_stream(colnde_handle* h, void* s) {
     if (!h) return fail("null handle");
@@ -692,6 +716,17 @@ static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_
     return 0;
 }
 
+// fc32 forward solve of columns [c0, c0 + nc) (c0 a multiple of 32); with_tape: into the handle's (block) records and relu bits
+static int fc_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int c0, int nc) {
+    const size_t ns = h->m.ns;
+    Timed tm(h, K_FORWARD);
+    hipError_t e = fc_launch_forward(h->m, h->d_fc_imgf, h->d_fc_bias, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times,
+                                     h->cfg.n_save, h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
+                                     with_tape ? h->d_dwtape : nullptr, with_tape ? h->d_fc_masks : nullptr, nc, h->stream);
+    if (e != hipSuccess) return fail("fc32 forward launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // ---- forward solve -------------------------------------------------------------------------------------
 // A time step outside RK4's stability region gives a blown-up or NaN trajectory, loss and gradient with rc = 0: refuse it.
 static int check_stability(const colnde_handle* h) {
@@ -716,6 +751,11 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
         hipError_t e = rt_launch_pack(h->m, d_weights, h->d_wimg, h->stream);
         if (e != hipSuccess) return fail("rt pack launch failed: %s", hipGetErrorString(e));
         return rt_forward_range(h, d_sol, false, 0, h->n_col);
+    }
+    if (h->use_fc) {
+        hipError_t e = fc_launch_pack(h->m, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        if (e != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(e));
+        return fc_forward_range(h, d_sol, false, 0, h->n_col);
     }
     if (pack(h, d_weights)) return 1;
     return t16_forward_range(h, d_weights, d_sol, with_tape, 0, h->n_col);
@@ -775,6 +815,81 @@ extern "C" int colnde_loss(colnde_handle* h, const float* weights, const float s
 // tile16, taped weight gradients: decide once per handle.  On when the tapes fit in the free HBM (the in-register adjoint_kernel
 // geometries remain the fallback; 64-256-256-63's 384 gradient tiles spill there);
 // COLNDE_T16_DWTAPE=1 / 0 forces it on / off.
+// The dW GEMM's work list: 64x64 blocks of every layer's weight matrix, and the number of K-slices of the records
+static void build_dw_macros(colnde_handle* h, size_t n_rec, std::vector<DwMacro>& mac) {
+    const DevModel& m = h->m;
+    const size_t R = dwtape_row_floats(m);
+    for (int net = 0; net < m.n_nets; net++)
+        for (int l = 0; l < m.n_layers; l++) {
+            const int ni = m.sizes[l], no = m.sizes[l + 1];
+            for (int i0 = 0; i0 < ni; i0 += 64)
+                for (int j0 = 0; j0 < no; j0 += 64) {
+                    DwMacro d;
+                    d.a_feat = l == 0 ? i0 : dwtape_ns4(m) + net * dwtape_act4(m) + m.act_off[l - 1] + i0;
+                    d.d_feat = dwtape_ns4(m) + (m.n_nets + net) * dwtape_act4(m) + m.act_off[l] + j0;
+                    d.ni_rem = std::min(64, ni - i0);
+                    d.no_rem = std::min(64, no - j0);
+                    d.g_off = net * m.net_size + m.w_off[l] + i0 * no + j0;
+                    d.no = no;
+                    mac.push_back(d);
+                }
+        }
+    h->n_macros = (int)mac.size();
+    const int n_groups = (h->n_macros + 3) / 4;
+    size_t slices = std::max<size_t>(8, ((size_t)2048 / n_groups + 7) / 8 * 8);
+    slices = std::min(slices, std::max<size_t>(8, (n_rec / 8 + 7) / 8 * 8));
+    if (dw_gemm_lds_fits((int)R, h->n_macros))       // one workgroup per CU (two records in LDS): two rounds of slices
+        slices = std::min<size_t>(512, std::max<size_t>(1, n_rec));
+    h->dw_slices = (int)slices;
+}
+
+// fc32 gradient path: the records (forward: xs, a1, a2; adjoint: dz1, dz2, dz3) and the relu bits hold ONE block of columns (a multiple of
+// the 32-column tile); larger problems run forward -> adjoint -> dW GEMM block after block.  COLNDE_FC_BLOCK=<columns> forces a size.
+static int fc_plan_tapes(colnde_handle* h) {
+    if (h->d_dwtape) return 0;
+    const DevModel& m = h->m;
+    const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+    const size_t R = dwtape_row_floats(m);
+    if (R != fc_record_row_floats(m.Nz)) return fail("fc32: record layout mismatch (%zu vs %zu floats per column)", R, fc_record_row_floats(m.Nz));
+    const size_t per_col = (size_t)n_steps * 4 * (R * sizeof(float) + fc_mask_words() * sizeof(unsigned int) / 32);
+    const int n32 = (h->n_col + 31) / 32 * 32;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t margin = ((size_t)3 << 30) + (size_t)(n32 / 32 + 1024) * (m.n_params + 8) * sizeof(float);
+    const size_t fit = free_b > margin ? (free_b - margin) / per_col : 0;
+    int block = 0;
+    if (fit >= (size_t)n32) block = n32;
+    else if (fit >= 32) {
+        const int nb = (int)(((size_t)n32 + fit - 1) / fit);
+        block = ((n32 + nb - 1) / nb + 31) / 32 * 32;
+        if (block >= 8192) block = (block + 8191) / 8192 * 8192;       // whole rounds of one workgroup pair per CU
+        while ((size_t)block > fit) block -= block > 8192 ? 8192 : 32;
+    }
+    const char* eb = getenv("COLNDE_FC_BLOCK");
+    if (eb && atoi(eb) >= 32) block = std::min(n32, (atoi(eb) / 32) * 32);
+    if (block < 32) return fail("fc32: the tapes of even one 32-column tile (%zu bytes) do not fit in the free device memory", 32 * per_col);
+    h->fc_block = block;
+    h->fc_nblocks = (n32 + block - 1) / block;
+    const size_t tiles_b = (size_t)block / 32;
+    const size_t n_rec = tiles_b * 2 * n_steps * 4;
+    std::vector<DwMacro> mac;
+    build_dw_macros(h, n_rec, mac);
+    h->fc_rows = n32 / 32 + h->fc_nblocks * h->dw_slices;
+    const int stride = m.n_params + 8;
+    hipError_t e = hipMalloc((void**)&h->d_dwtape, n_rec * CT * R * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_fc_masks, tiles_b * n_steps * 4 * fc_mask_words() * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_macros, mac.size() * sizeof(DwMacro));
+    if (e == hipSuccess) e = hipMemcpy(h->d_macros, mac.data(), mac.size() * sizeof(DwMacro), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !h->d_slab) e = hipMalloc((void**)&h->d_slab, (size_t)h->fc_rows * stride * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (void** p : {(void**)&h->d_dwtape, (void**)&h->d_fc_masks, (void**)&h->d_macros})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        return fail("fc32: hipMalloc of the tapes (%zu bytes for a block of %d columns) failed: %s", (size_t)block * per_col, block, hipGetErrorString(e));
+    }
+    return 0;
+}
+
 static int t16_plan_dwtape(colnde_handle* h) {
     if (h->t16_dwtape >= 0) return 0;
     const DevModel& m = h->m;
@@ -829,30 +944,8 @@ static int t16_plan_dwtape(colnde_handle* h) {
     const size_t need = n_rec * CT * R * sizeof(float);
     h->t16_block = block;
     h->t16_nblocks = (n16 + block - 1) / block;
-    // 64x64 blocks of every layer's weight matrix
     std::vector<DwMacro> mac;
-    for (int net = 0; net < m.n_nets; net++)
-        for (int l = 0; l < m.n_layers; l++) {
-            const int ni = m.sizes[l], no = m.sizes[l + 1];
-            for (int i0 = 0; i0 < ni; i0 += 64)
-                for (int j0 = 0; j0 < no; j0 += 64) {
-                    DwMacro d;
-                    d.a_feat = l == 0 ? i0 : dwtape_ns4(m) + net * dwtape_act4(m) + m.act_off[l - 1] + i0;
-                    d.d_feat = dwtape_ns4(m) + (m.n_nets + net) * dwtape_act4(m) + m.act_off[l] + j0;
-                    d.ni_rem = std::min(64, ni - i0);
-                    d.no_rem = std::min(64, no - j0);
-                    d.g_off = net * m.net_size + m.w_off[l] + i0 * no + j0;
-                    d.no = no;
-                    mac.push_back(d);
-                }
-        }
-    h->n_macros = (int)mac.size();
-    const int n_groups = (h->n_macros + 3) / 4;
-    size_t slices = std::max<size_t>(8, ((size_t)2048 / n_groups + 7) / 8 * 8);
-    slices = std::min(slices, std::max<size_t>(8, (n_rec / 8 + 7) / 8 * 8));
-    if (dw_gemm_lds_fits((int)R, h->n_macros))       // one workgroup per CU (two records in LDS): two rounds of slices
-        slices = std::min<size_t>(512, std::max<size_t>(1, n_rec));
-    h->dw_slices = (int)slices;
+    build_dw_macros(h, n_rec, mac);
     h->t16_rows = h->n_tiles + h->t16_nblocks * h->dw_slices;
     const int stride = m.n_params + 8;
     hipError_t e = hipMalloc((void**)&h->d_dwtape, need);
@@ -940,6 +1033,43 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         {
             Timed tm(h, K_REDUCE);
             e = launch_reduce(h->d_rt_slab, h->rt_rows, h->m.n_params, stride, lw, d_out, h->stream);
+            if (e != hipSuccess) return fail("reduce launch failed: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    if (h->use_fc) {
+        if (!h->have_problem) return fail("colnde_set_problem has not been called");
+        if (fc_plan_tapes(h)) return 1;
+        LossWeights lw;
+        loss_weights(h, scalings, &lw);
+        const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+        const size_t ns = h->m.ns;
+        hipError_t e = fc_launch_pack(h->m, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        if (e != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(e));
+        HIPCHK(hipMemsetAsync(h->d_slab, 0, (size_t)h->fc_rows * stride * sizeof(float), h->stream));
+        const int n_wg = (h->n_col + 31) / 32;
+        for (int b = 0; b < h->fc_nblocks; b++) {
+            const int c0 = b * h->fc_block, nc = std::min(h->fc_block, h->n_col - c0);
+            if (nc <= 0) break;
+            const size_t tiles_b = ((size_t)nc + 31) / 32;
+            if (fc_forward_range(h, h->d_sol, true, c0, nc)) return 1;
+            {
+                Timed tm(h, K_ADJOINT);
+                e = fc_launch_adjoint(h->m, h->d_fc_imgb, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol + (size_t)c0 * h->cfg.n_save * ns,
+                                      h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_dwtape, h->d_fc_masks, lw.w[2],
+                                      h->d_slab + (size_t)(c0 / 32) * stride, nc, h->stream);
+                if (e != hipSuccess) return fail("fc32 adjoint launch failed: %s", hipGetErrorString(e));
+            }
+            {
+                Timed tm(h, K_DW1);
+                e = launch_dw_gemm(h->d_dwtape, tiles_b * 2 * n_steps * 4, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros, h->dw_slices,
+                                   h->d_slab + ((size_t)n_wg + (size_t)b * h->dw_slices) * stride, stride, h->stream);
+                if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
+            }
+        }
+        {
+            Timed tm(h, K_REDUCE);
+            e = launch_reduce(h->d_slab, h->fc_rows, h->m.n_params, stride, lw, d_out, h->stream);
             if (e != hipSuccess) return fail("reduce launch failed: %s", hipGetErrorString(e));
         }
         return 0;
@@ -1248,8 +1378,13 @@ extern "C" int colnde_pretrain_flux_dev(colnde_handle* h, int flux_type, float* 
 extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
     if (!h || !info) return fail("null argument");
     for (int i = 0; i < 8; i++) info[i] = 0;
-    info[0] = h->use_rt ? COLNDE_ENGINE_MFMA : COLNDE_ENGINE_GENERIC;
-    if (h->use_rt) {
+    info[0] = h->use_rt ? COLNDE_ENGINE_MFMA : (h->use_fc ? COLNDE_ENGINE_FC32 : COLNDE_ENGINE_GENERIC);
+    if (h->use_fc) {
+        info[1] = h->fc_block;
+        info[2] = h->fc_nblocks;
+        info[4] = h->d_dwtape ? 1 : 0;
+        info[5] = h->d_dwtape ? h->dw_slices : 0;
+    } else if (h->use_rt) {
         info[1] = h->rt_block;
         info[2] = h->rt_nblocks;
         info[3] = h->rt_ztape ? 1 : 0;

@@ -16,7 +16,7 @@ from . import _lib
 from .config import NDEConfig, to_c_config
 
 KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4, "dw1": 5, "convadj": 6, "adam": 7, "impldiff": 8}
-ENGINE_AUTO, ENGINE_TILE16, ENGINE_REGTILE = 0, 1, 2
+ENGINE_AUTO, ENGINE_TILE16, ENGINE_REGTILE, ENGINE_FC32 = 0, 1, 2, 3
 
 
 def _f32(a, shape=None):

@@ -32,10 +32,14 @@ enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_t
 enum { COLNDE_ACT_IDENTITY = 0, COLNDE_ACT_RELU = 1, COLNDE_ACT_MISH = 2, COLNDE_ACT_SWISH = 3,
        COLNDE_ACT_TANH = 4, COLNDE_ACT_LEAKYRELU = 5 };
 
-enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it is built for and there are > 8,192 columns, else tile16 (with the net-split kernels where the shape is regtile's) */
+enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it is built for and there are > 8,192 columns, fc32 for its shape, else tile16 (with the net-split kernels where the shape is regtile's) */
        COLNDE_ENGINE_GENERIC = 1,   /* tile16: 16-column MFMA tiles staged through LDS, any layer sizes / model */
-       COLNDE_ENGINE_MFMA = 2 };    /* regtile: 32 columns per wavefront resident in registers (static 96-50-20-31 wind-mixing
+       COLNDE_ENGINE_MFMA = 2,      /* regtile: 32 columns per wavefront resident in registers (static 96-50-20-31 wind-mixing
                                        shape; colnde_create fails if the configuration is not covered) */
+       COLNDE_ENGINE_FC32 = 3 };    /* fc32: 32-column v_mfma_f32_32x32x2_f32 tiles with compile-time shapes for FreeConvectionNDE with the
+                                       reference's network Dense(Nz,4Nz,relu), Dense(4Nz,4Nz,relu), Dense(4Nz,Nz-1)
+                                       (free_convection/train_free_convection_nde.jl:119-121), Nz = 32 | 64, RK4; AUTO picks it for that
+                                       shape; colnde_create fails if it is requested for anything else */
 
 enum { COLNDE_STEPPER_RK4 = 0,      /* classical RK4, `substeps` per save interval (what the bench measures) */
        COLNDE_STEPPER_RKC2 = 1 };   /* stabilised second-order Runge-Kutta-Chebyshev for the stiff variants: `substeps` steps per
