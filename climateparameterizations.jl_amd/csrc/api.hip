@@ -63,6 +63,7 @@ struct colnde_handle {
     bool use_fc = false;            // 32-column free-convection engine (engine_fc.hip: Nz = 32 | 64, the reference's relu network, RK4)
     float *d_fc_imgf = nullptr, *d_fc_imgb = nullptr, *d_fc_bias = nullptr;
     unsigned int* d_fc_masks = nullptr;
+    unsigned long long* d_fc_switch = nullptr;   // ConvectiveAdjustmentNDE: the taped switch patterns
     int fc_block = 0, fc_nblocks = 0, fc_rows = 0;   // gradient path: columns per pass (multiple of 32), passes, slab rows
     float* d_wimg = nullptr;
     float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_tapez = nullptr;
@@ -415,7 +416,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         h->use_fc = fc_supported(h->m, cfg->stepper) && (cfg->engine == COLNDE_ENGINE_FC32 || (cfg->engine == COLNDE_ENGINE_AUTO && !(ef && atoi(ef) == 0)));
         if (cfg->engine == COLNDE_ENGINE_FC32 && !h->use_fc) {
             delete h;
-            return fail("engine = fc32 requested, but it covers only FreeConvectionNDE with Dense(Nz,4Nz,relu), Dense(4Nz,4Nz,relu), Dense(4Nz,Nz-1), Nz = 32 or 64, RK4");
+            return fail("engine = fc32 requested, but it covers only FreeConvectionNDE (RK4) and ConvectiveAdjustmentNDE (RK4, RKC2) with Dense(Nz,4Nz,relu), Dense(4Nz,4Nz,relu), Dense(4Nz,Nz-1), Nz = 32 or 64");
         }
         if (h->use_fc) {
             hipError_t e = fc_set_kernel_attributes();
@@ -478,7 +479,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
                     h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc,
-                    h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks};
+                    h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks, h->d_fc_switch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -722,7 +723,8 @@ static int fc_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int 
     Timed tm(h, K_FORWARD);
     hipError_t e = fc_launch_forward(h->m, h->d_fc_imgf, h->d_fc_bias, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times,
                                      h->cfg.n_save, h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
-                                     with_tape ? h->d_dwtape : nullptr, with_tape ? h->d_fc_masks : nullptr, nc, h->stream);
+                                     with_tape ? h->d_dwtape : nullptr, with_tape ? h->d_fc_masks : nullptr, with_tape ? h->d_fc_switch : nullptr, nc,
+                                     h->stream);
     if (e != hipSuccess) return fail("fc32 forward launch failed: %s", hipGetErrorString(e));
     return 0;
 }
@@ -851,7 +853,8 @@ static int fc_plan_tapes(colnde_handle* h) {
     const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
     const size_t R = dwtape_row_floats(m);
     if (R != fc_record_row_floats(m.Nz)) return fail("fc32: record layout mismatch (%zu vs %zu floats per column)", R, fc_record_row_floats(m.Nz));
-    const size_t per_col = (size_t)n_steps * 4 * (R * sizeof(float) + fc_mask_words() * sizeof(unsigned int) / 32);
+    const bool ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE;
+    const size_t per_col = (size_t)n_steps * m.nst * (R * sizeof(float) + fc_mask_words() * sizeof(unsigned int) / 32 + (ca ? sizeof(unsigned long long) : 0));
     const int n32 = (h->n_col + 31) / 32 * 32;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -871,19 +874,20 @@ static int fc_plan_tapes(colnde_handle* h) {
     h->fc_block = block;
     h->fc_nblocks = (n32 + block - 1) / block;
     const size_t tiles_b = (size_t)block / 32;
-    const size_t n_rec = tiles_b * 2 * n_steps * 4;
+    const size_t n_rec = tiles_b * 2 * n_steps * m.nst;
     std::vector<DwMacro> mac;
     build_dw_macros(h, n_rec, mac);
     h->fc_rows = n32 / 32 + h->fc_nblocks * h->dw_slices;
     const int stride = m.n_params + 8;
     hipError_t e = hipMalloc((void**)&h->d_dwtape, n_rec * CT * R * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_fc_masks, tiles_b * n_steps * 4 * fc_mask_words() * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_fc_masks, tiles_b * n_steps * m.nst * fc_mask_words() * sizeof(unsigned int));
+    if (e == hipSuccess && ca) e = hipMalloc((void**)&h->d_fc_switch, tiles_b * n_steps * m.nst * fc_switch_words() * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_macros, mac.size() * sizeof(DwMacro));
     if (e == hipSuccess) e = hipMemcpy(h->d_macros, mac.data(), mac.size() * sizeof(DwMacro), hipMemcpyHostToDevice);
     if (e == hipSuccess && !h->d_slab) e = hipMalloc((void**)&h->d_slab, (size_t)h->fc_rows * stride * sizeof(float));
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        for (void** p : {(void**)&h->d_dwtape, (void**)&h->d_fc_masks, (void**)&h->d_macros})
+        for (void** p : {(void**)&h->d_dwtape, (void**)&h->d_fc_masks, (void**)&h->d_fc_switch, (void**)&h->d_macros})
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         return fail("fc32: hipMalloc of the tapes (%zu bytes for a block of %d columns) failed: %s", (size_t)block * per_col, block, hipGetErrorString(e));
     }
@@ -1056,13 +1060,13 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
             {
                 Timed tm(h, K_ADJOINT);
                 e = fc_launch_adjoint(h->m, h->d_fc_imgb, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol + (size_t)c0 * h->cfg.n_save * ns,
-                                      h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_dwtape, h->d_fc_masks, lw.w[2],
+                                      h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_dwtape, h->d_fc_masks, h->d_fc_switch, lw.w[2],
                                       h->d_slab + (size_t)(c0 / 32) * stride, nc, h->stream);
                 if (e != hipSuccess) return fail("fc32 adjoint launch failed: %s", hipGetErrorString(e));
             }
             {
                 Timed tm(h, K_DW1);
-                e = launch_dw_gemm(h->d_dwtape, tiles_b * 2 * n_steps * 4, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros, h->dw_slices,
+                e = launch_dw_gemm(h->d_dwtape, tiles_b * 2 * n_steps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros, h->dw_slices,
                                    h->d_slab + ((size_t)n_wg + (size_t)b * h->dw_slices) * stride, stride, h->stream);
                 if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
             }

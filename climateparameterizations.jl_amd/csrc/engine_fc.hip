@@ -30,7 +30,20 @@ typedef unsigned int u32;
 
 extern __shared__ float fc_smem[];
 
+#ifndef FC_PF
 #define FC_PF 8                                    // ring depth in groups of four MFMAs: 8 x 256 cycles of cover
+#endif
+#ifndef FC_NT
+#define FC_NT 0                                    // tape traffic with the non-temporal cache policy: measured SLOWER (A/B on one box, 16,384 columns:
+#endif                                             // Nz = 32 forward 26.8 vs 16.7 ms, adjoint 25.4 vs 17.6; Nz = 64 61.0 vs 53.9 and 61.0 vs 54.0) — an
+                                                   // nt store is acknowledged late, and every wait for a ring load (vmcnt is in order) waits behind it
+#if FC_NT
+#define FC_STORE(v, p) __builtin_nontemporal_store(v, p)
+#define FC_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define FC_STORE(v, p) (*(p) = (v))
+#define FC_LOAD(p) (*(p))
+#endif
 #define FC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // The group addresses of a stage are loop-invariant: left alone, the optimiser computes all ~100 of them once, outside the time loop, and
 // keeps them in (spilled) registers.  An opaque zero added to the wave-uniform bases at the top of every stage keeps them what they should
@@ -152,12 +165,17 @@ __global__ void __launch_bounds__(256) fc_pack_kernel(FcOffsets o, const float* 
 
 // ------------------------------------------------------------------------------------------------
 // forward solve (and, TAPE, the forward half of the tapes)
+//   CA:  ConvectiveAdjustmentNDE (convective_adjustment_nde.jl:33-48): the face flux is [b; NN(T); t] - min(0, K dT/dz)
+//   RKC: the s-stage RKC2 step of colnde_dev.h (coefficient table `rkc`, increment form: see tile16's forward_kernel) instead of classical RK4
+// One record per right-hand-side evaluation: index step * nst + st, nst = 4 (RK4) or s.
 // ------------------------------------------------------------------------------------------------
-template <int NZ, bool TAPE>
+typedef unsigned long long u64;
+
+template <int NZ, bool TAPE, bool CA, bool RKC>
 __global__ void __launch_bounds__(256, 2)
 fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, const float* __restrict__ x0, const float* __restrict__ bcs,
-                  const float* __restrict__ save_times, int n_save, int substeps, float CN, float* __restrict__ sol, float* __restrict__ dwtape,
-                  u32* __restrict__ masks, int n_col) {
+                  const float* __restrict__ save_times, int n_save, int substeps, float CN, float caKN, int nst, const float* __restrict__ rkc,
+                  float* __restrict__ sol, float* __restrict__ dwtape, u32* __restrict__ masks, u64* __restrict__ swtape, int n_col) {
     using S = Fc<NZ>;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
@@ -178,14 +196,13 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
 #pragma unroll
     for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ>(q)] + fc_off<NZ>(q))[lane];
 
-    float xn[S::OWN], ac[S::OWN], kv[S::OWN], bcb[S::OWN], bct[S::OWN];
+    float xn[S::OWN], vst[S::OWN], kv[S::OWN], bcb[S::OWN], bct[S::OWN];
 #pragma unroll
     for (int r = 0; r < S::OWN; r++) {
         const int col = min(col0 + oc[r], n_col - 1);
         xn[r] = x0[(size_t)col * NZ + oi];
         bcb[r] = bcs[(size_t)col * 2];
         bct[r] = bcs[(size_t)col * 2 + 1];
-        ac[r] = 0.0f;
         kv[r] = 0.0f;
         if (sol && col0 + oc[r] < n_col) sol[((size_t)(col0 + oc[r]) * n_save) * NZ + oi] = xn[r];
     }
@@ -196,111 +213,183 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
     for (int r = 0; r < S::OWN; r++) asm volatile("" :: "v"(xn[r]), "v"(bcb[r]), "v"(bct[r]));
     asm volatile("" :: "v"(b3v));
     const int n_steps = (n_save - 1) * substeps;
-    int step = 0;
-    for (int iv = 0; iv < n_save - 1; iv++) {
-        const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
-        for (int s = 0; s < substeps; s++, step++) {
-#pragma nounroll
-            for (int st = 0; st < 4; st++) {
-                int zero = 0;
-                FC_OPAQUE_ZERO(zero);
-                const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
-                const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);            // stage abscissa
-                const float cbp = st == 1 ? 1.0f / 6.0f : 1.0f / 3.0f;                 // RK4 weight of k_{st-1}
-                float* rec = TAPE ? dwtape + (((size_t)blockIdx.x * n_steps + step) * 4 + st) * ((size_t)32 * S::R) : nullptr;
-                u32* mrec = TAPE ? masks + (((size_t)blockIdx.x * n_steps + step) * 4 + st) * 512 + w * 64 + lane : nullptr;
-                // ---- stage input (owner layout) -> LDS rows, tape
+
+    // one right-hand-side evaluation: stage input vst[] (owner layout) -> kv[]; qi = record index step * nst + st
+    auto rhs = [&](int qi) {
+        int zero = 0;
+        FC_OPAQUE_ZERO(zero);
+        const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
+        const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
+        float* rec = TAPE ? dwtape + ri * ((size_t)32 * S::R) : nullptr;
+        u32* mrec = TAPE ? masks + ri * 512 + w * 64 + lane : nullptr;
+        // ---- stage input (owner layout) -> LDS rows, tape
 #pragma unroll
-                for (int r = 0; r < S::OWN; r++) {
-                    float v = xn[r];
-                    if (st > 0) {
-                        ac[r] += cbp * kv[r];
-                        v += ca * dt * kv[r];
-                    }
-                    X[oc[r] * S::LDX + oi] = v;
-                    if (TAPE) __builtin_nontemporal_store(v, rec + (size_t)oc[r] * S::R + oi);
+        for (int r = 0; r < S::OWN; r++) {
+            X[oc[r] * S::LDX + oi] = vst[r];
+            if (TAPE) FC_STORE(vst[r], rec + (size_t)oc[r] * S::R + oi);
+        }
+        FC_BARRIER();
+        // ---- hidden layers: z = W a + b on 32x32x2 MFMA, relu, rows to LDS (next layer's B operand) and to the tape
+        auto hidden = [&](int l /* 1, 2 */, float* dstrows, int j, const fc16& acc) {
+            const int mt = w + 4 * j;
+            const float* bl = BL + (l - 1) * S::H + mt * 32 + 4 * h;
+            u32 bits = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + 8 * q);
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float z = acc[4 * q + e] + bq[e];
+                    a[e] = fmaxf(z, 0.0f);
+                    bits |= (z > 0.0f ? 1u : 0u) << (4 * q + e);
                 }
-                FC_BARRIER();
-                // ---- hidden layers: z = W a + b on 32x32x2 MFMA, relu, rows to LDS (next layer's B operand) and to the tape
-                auto hidden = [&](int l /* 1, 2 */, float* dstrows, int j, const fc16& acc) {
-                    const int mt = w + 4 * j;
-                    const float* bl = BL + (l - 1) * S::H + mt * 32 + 4 * h;
-                    u32 bits = 0;
+                const int f = mt * 32 + 8 * q + 4 * h;
+                *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + f) = a;
+                if (TAPE) FC_STORE(a, reinterpret_cast<f32x4*>(rec + (size_t)n * S::R + NZ + (l - 1) * S::H + f));
+            }
+            return bits;
+        };
+        {
+            u32 mb = 0;
+            fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h,
+                                              [&](int j, const fc16& acc) { mb |= hidden(1, A1, j, acc) << (16 * j); });
+            if (TAPE) FC_STORE(mb, mrec);
+        }
+        FC_BARRIER();
+        {
+            u32 mb = 0;
+            fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h,
+                                                           [&](int j, const fc16& acc) { mb |= hidden(2, A2, j, acc) << (16 * j); });
+            if (TAPE) FC_STORE(mb, mrec + 256);
+        }
+        FC_BARRIER();
+        // ---- output layer: row tile w % MT3, K part w / MT3; partial sums to LDS
+        fc_section<NZ, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, A2 + n * S::LDH + (w / S::MT3) * S::G3 * 8 + 4 * h,
+            [&](int, const fc16& acc) {
+                float* pr = PART + ((w / S::MT3) * 32 + n) * NZ + (w % S::MT3) * 32 + 4 * h;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + 8 * q);
-                        f32x4 a;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const float z = acc[4 * q + e] + bq[e];
-                            a[e] = fmaxf(z, 0.0f);
-                            bits |= (z > 0.0f ? 1u : 0u) << (4 * q + e);
-                        }
-                        const int f = mt * 32 + 8 * q + 4 * h;
-                        *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + f) = a;
-                        if (TAPE) __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(rec + (size_t)n * S::R + NZ + (l - 1) * S::H + f));
-                    }
-                    return bits;
-                };
-                {
-                    u32 mb = 0;
-                    fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h,
-                                                      [&](int j, const fc16& acc) { mb |= hidden(1, A1, j, acc) << (16 * j); });
-                    if (TAPE) __builtin_nontemporal_store(mb, mrec);
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(pr + 8 * q) = v;
                 }
-                FC_BARRIER();
-                {
-                    u32 mb = 0;
-                    fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h,
-                                                                   [&](int j, const fc16& acc) { mb |= hidden(2, A2, j, acc) << (16 * j); });
-                    if (TAPE) __builtin_nontemporal_store(mb, mrec + 256);
-                }
-                FC_BARRIER();
-                // ---- output layer: row tile w % MT3, K part w / MT3; partial sums to LDS
-                fc_section<NZ, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, A2 + n * S::LDH + (w / S::MT3) * S::G3 * 8 + 4 * h,
-                    [&](int, const fc16& acc) {
-                        float* pr = PART + ((w / S::MT3) * 32 + n) * NZ + (w % S::MT3) * 32 + 4 * h;
+            });
+        FC_BARRIER();
+        // ---- physics: faces F = [b; NN(T); t] (free_convection_nde.jl:29-38) [- min(0, K dT/dz) on the interior faces,
+        //      convective_adjustment_nde.jl:43-47], dT = -C Nz (F[i+1] - F[i])
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                            *reinterpret_cast<f32x4*>(pr + 8 * q) = v;
-                        }
-                    });
-                FC_BARRIER();
-                // ---- physics (free_convection_nde.jl:29-38): faces [b; NN(T); t], dT = -C Nz (w[i+1] - w[i])
+        for (int r = 0; r < S::OWN; r++) {
+            float o = b3v;
 #pragma unroll
-                for (int r = 0; r < S::OWN; r++) {
-                    float o = b3v;
-#pragma unroll
-                    for (int ks = 0; ks < S::KS3; ks++) o += PART[(ks * 32 + oc[r]) * NZ + oi];
-                    const float olo = __shfl_up(o, 1);                                // NN output of face i (lane i - 1 holds it)
-                    const float wlo = oi == 0 ? bcb[r] : olo;
-                    const float whi = oi == NZ - 1 ? bct[r] : o;
-                    kv[r] = -CN * (whi - wlo);
+            for (int ks = 0; ks < S::KS3; ks++) o += PART[(ks * 32 + oc[r]) * NZ + oi];
+            const float olo = __shfl_up(o, 1);                                // NN output of face i (lane i - 1 holds it)
+            float wlo = oi == 0 ? bcb[r] : olo;
+            float whi = oi == NZ - 1 ? bct[r] : o;
+            if (CA) {
+                const float vlo = __shfl_up(vst[r], 1), vhi = __shfl_down(vst[r], 1);
+                const float glo = (vst[r] - vlo) * (float)NZ, ghi = (vhi - vst[r]) * (float)NZ;     // dT/dz on faces i and i + 1
+                const bool on = oi >= 1 && glo < 0.0f;
+                if (oi >= 1) wlo -= fminf(0.0f, caKN * (vst[r] - vlo));
+                if (oi <= NZ - 2) whi -= fminf(0.0f, caKN * (vhi - vst[r]));
+                (void)ghi;
+                if (TAPE) {
+                    // the switch pattern of the stage, one bit per face, for the pullback
+                    const u64 bal = __ballot(on);
+                    const u64 mine = NZ == 64 ? bal : (lane < 32 ? (bal & 0xffffffffull) : (bal >> 32));
+                    if (oi == 0) swtape[ri * 32 + oc[r]] = mine;
                 }
             }
-            const bool save = s == substeps - 1;
+            kv[r] = -CN * (whi - wlo);
+        }
+    };
+
+    int step = 0;
+    if constexpr (!RKC) {
+        float ac[S::OWN];
 #pragma unroll
-            for (int r = 0; r < S::OWN; r++) {
-                ac[r] += (1.0f / 6.0f) * kv[r];
-                xn[r] += dt * ac[r];
-                ac[r] = 0.0f;
-                if (save && sol && col0 + oc[r] < n_col) sol[((size_t)(col0 + oc[r]) * n_save + iv + 1) * NZ + oi] = xn[r];
+        for (int r = 0; r < S::OWN; r++) ac[r] = 0.0f;
+        for (int iv = 0; iv < n_save - 1; iv++) {
+            const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
+            for (int s = 0; s < substeps; s++, step++) {
+#pragma nounroll
+                for (int st = 0; st < 4; st++) {
+                    const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);            // stage abscissa
+                    const float cbp = st == 1 ? 1.0f / 6.0f : 1.0f / 3.0f;                 // RK4 weight of k_{st-1}
+#pragma unroll
+                    for (int r = 0; r < S::OWN; r++) {
+                        float v = xn[r];
+                        if (st > 0) {
+                            ac[r] += cbp * kv[r];
+                            v += ca * dt * kv[r];
+                        }
+                        vst[r] = v;
+                    }
+                    rhs(step * 4 + st);
+                }
+                const bool save = s == substeps - 1;
+#pragma unroll
+                for (int r = 0; r < S::OWN; r++) {
+                    ac[r] += (1.0f / 6.0f) * kv[r];
+                    xn[r] += dt * ac[r];
+                    ac[r] = 0.0f;
+                    if (save && sol && col0 + oc[r] < n_col) sol[((size_t)(col0 + oc[r]) * n_save + iv + 1) * NZ + oi] = xn[r];
+                }
+            }
+        }
+    } else {
+        // Y_0 = xn, d_j = Y_j - Y_0 (increments: float32 stays accurate), F_0 = f0; stage st evaluates F_st = f(Y_st); Y_s ends the step
+        const float* mu_t = rkc, *nu_t = rkc + RKC_LD, *mut_t = rkc + 2 * RKC_LD, *gat_t = rkc + 3 * RKC_LD;
+        float ym1[S::OWN], ym2[S::OWN], f0[S::OWN];
+#pragma unroll
+        for (int r = 0; r < S::OWN; r++) { ym1[r] = 0.0f; ym2[r] = 0.0f; f0[r] = 0.0f; }
+        for (int iv = 0; iv < n_save - 1; iv++) {
+            const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
+            for (int s = 0; s < substeps; s++, step++) {
+#pragma nounroll
+                for (int st = 0; st <= nst; st++) {      // st = nst: only the final combination Y_s
+                    const float cmu = mu_t[st], cnu = nu_t[st], cmt = mut_t[st] * dt, cga = gat_t[st] * dt;
+                    const bool last = st == nst;
+                    const bool save = last && s == substeps - 1;
+#pragma unroll
+                    for (int r = 0; r < S::OWN; r++) {
+                        float dj = 0.0f;
+                        if (st == 1) {
+                            f0[r] = kv[r];
+                            dj = cmt * f0[r];
+                        } else if (st >= 2) {
+                            dj = cmu * ym1[r] + cnu * ym2[r] + cmt * kv[r] + cga * f0[r];
+                        }
+                        const float v = xn[r] + dj;
+                        ym2[r] = st == 0 ? 0.0f : ym1[r];
+                        ym1[r] = dj;
+                        if (last) {
+                            xn[r] = v;
+                            if (save && sol && col0 + oc[r] < n_col) sol[((size_t)(col0 + oc[r]) * n_save + iv + 1) * NZ + oi] = v;
+                        } else {
+                            vst[r] = v;
+                        }
+                    }
+                    if (last) break;
+                    rhs(step * nst + st);
+                }
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// adjoint: back-propagation through the RK4 stages from the taped relu bits; fills the dz part of the delta-tape records
+// adjoint: back-propagation through the stages from the taped relu (and switch) bits; fills the dz part of the delta-tape records.
+// RKC: the discrete adjoint of the RKC2 recurrence as in tile16's adjoint_kernel — cotangents of Y_j (lam), Y_{j-1}, Y_{j-2}, Y_0 and F_0
+// per state item — with ONE convective-adjustment switch pattern per step (that of Y_{s-1}, the first stage the backward sweep meets:
+// DESIGN §2 "a finding about discrete adjoints of stabilised steppers").
 // ------------------------------------------------------------------------------------------------
 struct FcGrad { int b[3]; int n_params; };
 
-template <int NZ>
+template <int NZ, bool CA, bool RKC>
 __global__ void __launch_bounds__(256, 2)
-fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save_times, int n_save, int substeps, float CN,
-                  const float* __restrict__ sol, const float* __restrict__ truth, float* __restrict__ dwtape, const u32* __restrict__ masks,
-                  float w_loss, float* __restrict__ slab, FcGrad go, int n_col) {
+fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save_times, int n_save, int substeps, float CN, float caKN, int nst,
+                  const float* __restrict__ rkc, const float* __restrict__ sol, const float* __restrict__ truth, float* __restrict__ dwtape,
+                  const u32* __restrict__ masks, const u64* __restrict__ swtape, float w_loss, float* __restrict__ slab, FcGrad go, int n_col) {
     using S = Fc<NZ>;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
@@ -319,17 +408,13 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
 #pragma unroll
     for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ>(q)] + fc_off<NZ>(q))[lane];
 
-    float lam[S::OWN], xb[S::OWN], xbs[S::OWN], db3[S::OWN];
-    fc16 db2[S::JH], db1[S::JH];
-#pragma unroll
-    for (int j = 0; j < S::JH; j++) {
-        db2[j] = (fc16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        db1[j] = db2[j];
-    }
+    float lam[S::OWN], xb[S::OWN], kb[S::OWN], db3[S::OWN];
+    u32 swp = 0;                                 // switch bits of this thread's items: bit 2r = face oi, bit 2r + 1 = face oi + 1 of item r
+    float db2 = 0.0f, db1 = 0.0f;                // bias gradients of hidden unit tid (< H): column sums of the dz rows, taken from LDS
     float sumsq = 0.0f;
 #pragma unroll
     for (int r = 0; r < S::OWN; r++) {
-        lam[r] = 0.0f; xb[r] = 0.0f; db3[r] = 0.0f;
+        lam[r] = 0.0f; xb[r] = 0.0f; db3[r] = 0.0f; kb[r] = 0.0f;
         if (col0 + oc[r] < n_col) {                                 // save point 0 enters the loss value only
             const size_t q = ((size_t)(col0 + oc[r]) * n_save) * NZ + oi;
             const float d = sol[q] - truth[q];
@@ -337,6 +422,103 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
         }
     }
     const int n_steps = (n_save - 1) * substeps;
+
+    // pullback of one right-hand-side evaluation: stage cotangent kb[] (owner layout) -> xb[] = J(Y)ᵀ kb; qi = record index
+    auto pull = [&](int qi) {
+        int zero = 0;
+        FC_OPAQUE_ZERO(zero);
+        const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
+        const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
+        float* rec = dwtape + ri * ((size_t)32 * S::R);
+        const u32* mrec = masks + ri * 512 + w * 64 + lane;
+        const u32 m1 = FC_LOAD(mrec), m2 = FC_LOAD(mrec + 256);
+        // ---- physics pullback: dz3[i] = C Nz (k̄[i+1] - k̄[i]) on the Nz-1 interior faces; CA: x̄ += Dᶠᵀ(switch ∘ (-K) ∘ that)
+        float xph[S::OWN];
+#pragma unroll
+        for (int r = 0; r < S::OWN; r++) {
+            const float kn = __shfl_down(kb[r], 1);
+            const float dz = oi < S::NO ? CN * (kn - kb[r]) : 0.0f;                 // face i + 1
+            xph[r] = 0.0f;
+            if (CA) {
+                const float dlo = __shfl_up(dz, 1);                                 // face i
+                const float ghi = (oi < S::NO && ((swp >> (2 * r + 1)) & 1u)) ? -dz * caKN : 0.0f;
+                const float glo = (oi >= 1 && ((swp >> (2 * r)) & 1u)) ? -dlo * caKN : 0.0f;
+                xph[r] = glo - ghi;
+            }
+            DZ3[oc[r] * S::LDX + oi] = dz;
+            FC_STORE(dz, rec + (size_t)oc[r] * S::R + NZ + S::ACT4 + 2 * S::H + oi);
+            db3[r] += dz;
+        }
+        FC_BARRIER();
+        auto hidden = [&](int l /* 2, 1: layer whose dz this is */, float* dstrows, u32 bits, int j, const fc16& acc) {
+            const int mt = w + 4 * j;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; e++) d[e] = ((bits >> (16 * j + 4 * q + e)) & 1u) ? acc[4 * q + e] : 0.0f;
+                const int f = mt * 32 + 8 * q + 4 * h;
+                *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + f) = d;
+                FC_STORE(d, reinterpret_cast<f32x4*>(rec + (size_t)n * S::R + NZ + S::ACT4 + (l - 1) * S::H + f));
+            }
+        };
+        // ---- dz2 = relu'(z2) ∘ W3ᵀ dz3
+        fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, DZ3 + n * S::LDX + 4 * h,
+                                          [&](int j, const fc16& acc) { hidden(2, DZ2, m2, j, acc); });
+        FC_BARRIER();
+        // bias gradients: hidden unit tid's column sum of the finished dz rows, straight from LDS (16 accumulator registers per row tile
+        // and layer — 64 at Nz = 64 — would otherwise ride along in every lane)
+        auto colsum = [&](const float* rows) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 32; c += 4) {
+                a0 += rows[(c + 0) * S::LDH + tid];
+                a1 += rows[(c + 1) * S::LDH + tid];
+                a2 += rows[(c + 2) * S::LDH + tid];
+                a3 += rows[(c + 3) * S::LDH + tid];
+            }
+            return (a0 + a1) + (a2 + a3);
+        };
+        if (S::H == 256 || tid < S::H) db2 += colsum(DZ2);
+        // ---- dz1 = relu'(z1) ∘ W2ᵀ dz2
+        fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, DZ2 + n * S::LDH + 4 * h,
+                                                       [&](int j, const fc16& acc) { hidden(1, DZ1, m1, j, acc); });
+        FC_BARRIER();
+        if (S::H == 256 || tid < S::H) db1 += colsum(DZ1);
+        // ---- x̄ = W1ᵀ dz1: row tile w % MT3, K part w / MT3
+        fc_section<NZ, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, DZ1 + n * S::LDH + (w / S::MT3) * S::G3 * 8 + 4 * h,
+            [&](int, const fc16& acc) {
+                float* pr = XBP + ((w / S::MT3) * 32 + n) * NZ + (w % S::MT3) * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(pr + 8 * q) = v;
+                }
+            });
+        FC_BARRIER();
+#pragma unroll
+        for (int r = 0; r < S::OWN; r++) {
+            float v = xph[r];
+#pragma unroll
+            for (int ks = 0; ks < S::KS3; ks++) v += XBP[(ks * 32 + oc[r]) * NZ + oi];
+            xb[r] = v;
+        }
+        // (the next evaluation writes DZ3 = DZ1's rows: every wave's reads of DZ1 ended before the barrier above; XBP = DZ2's rows
+        //  are next written two barriers from here)
+    };
+    auto load_switch = [&](int qi) {
+        if (CA) {
+            const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
+            swp = 0;
+#pragma unroll
+            for (int r = 0; r < S::OWN; r++) swp |= (u32)((swtape[ri * 32 + oc[r]] >> oi) & 3ull) << (2 * r);
+        }
+    };
+
+    const float* mu_t = rkc, *nu_t = rkc + RKC_LD, *mut_t = rkc + 2 * RKC_LD, *gat_t = rkc + 3 * RKC_LD, *kap_t = rkc + 5 * RKC_LD;
+    float xbs[S::OWN], yb1[S::OWN], yb2[S::OWN], yb0[S::OWN], f0b[S::OWN];
+#pragma unroll
+    for (int r = 0; r < S::OWN; r++) { xbs[r] = 0.0f; yb1[r] = 0.0f; yb2[r] = 0.0f; yb0[r] = 0.0f; f0b[r] = 0.0f; }
     for (int iv = n_save - 2; iv >= 0; iv--) {
         const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
         // λ += ∂loss/∂sol[:, iv+1]   (nde_loss = Flux.mse over every (level, save point, simulation): training.jl:55-62)
@@ -350,77 +532,61 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
             }
         for (int s = substeps - 1; s >= 0; s--) {
             const int step = iv * substeps + s;
+            if constexpr (!RKC) {
 #pragma unroll
-            for (int r = 0; r < S::OWN; r++) xbs[r] = 0.0f;
+                for (int r = 0; r < S::OWN; r++) xbs[r] = 0.0f;
 #pragma nounroll
-            for (int st = 3; st >= 0; st--) {
-                // k̄4 = dt/6 λ; k̄3 = dt/3 λ + dt x̄4; k̄2 = dt/3 λ + dt/2 x̄3; k̄1 = dt/6 λ + dt/2 x̄2
-                int zero = 0;
-                FC_OPAQUE_ZERO(zero);
-                const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
-                const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
-                const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
-                float* rec = dwtape + (((size_t)blockIdx.x * n_steps + step) * 4 + st) * ((size_t)32 * S::R);
-                const u32* mrec = masks + (((size_t)blockIdx.x * n_steps + step) * 4 + st) * 512 + w * 64 + lane;
-                const u32 m1 = __builtin_nontemporal_load(mrec), m2 = __builtin_nontemporal_load(mrec + 256);
-                // ---- stage cotangent and the physics pullback: dz3[i] = C Nz (k̄[i+1] - k̄[i]) on the Nz-1 interior faces
+                for (int st = 3; st >= 0; st--) {
+                    // k̄4 = dt/6 λ; k̄3 = dt/3 λ + dt x̄4; k̄2 = dt/3 λ + dt/2 x̄3; k̄1 = dt/6 λ + dt/2 x̄2
+                    const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
+                    const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
 #pragma unroll
-                for (int r = 0; r < S::OWN; r++) {
-                    const float kb = cwl * lam[r] + cwx * xb[r];
-                    const float kn = __shfl_down(kb, 1);
-                    const float dz = oi < S::NO ? CN * (kn - kb) : 0.0f;
-                    DZ3[oc[r] * S::LDX + oi] = dz;
-                    __builtin_nontemporal_store(dz, rec + (size_t)oc[r] * S::R + NZ + S::ACT4 + 2 * S::H + oi);
-                    db3[r] += dz;
+                    for (int r = 0; r < S::OWN; r++) kb[r] = cwl * lam[r] + cwx * xb[r];
+                    load_switch(step * 4 + st);                 // RK4: every stage's own pattern (the exact discrete adjoint)
+                    pull(step * 4 + st);
+#pragma unroll
+                    for (int r = 0; r < S::OWN; r++) xbs[r] += xb[r];
                 }
-                FC_BARRIER();
-                auto hidden = [&](int l /* 2, 1: layer whose dz this is */, float* dstrows, u32 bits, fc16& dbacc, int j, const fc16& acc) {
-                    const int mt = w + 4 * j;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        f32x4 d;
+                for (int r = 0; r < S::OWN; r++) lam[r] += xbs[r];
+            } else {
+                load_switch(step * nst + nst - 1);              // one switch pattern per step: that of Y_{s-1}
+#pragma nounroll
+                for (int st = nst - 1; st >= 0; st--) {
+                    // stage input Y_st feeds Y_j, j = st + 1, through mu~_j h F_st
+                    const float cmu = mu_t[st + 1], cnu = nu_t[st + 1], cmt = mut_t[st + 1] * dt, cga = gat_t[st + 1] * dt, ck0 = kap_t[st + 1];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            d[e] = ((bits >> (16 * j + 4 * q + e)) & 1u) ? acc[4 * q + e] : 0.0f;
-                            dbacc[4 * q + e] += d[e];
+                    for (int r = 0; r < S::OWN; r++) {
+                        // lam = cotangent of Y_j, complete once the previous iteration's pullback (xb: J(Y_j)ᵀ F̄_j) is added
+                        if (st < nst - 1) {
+                            const float yj = yb1[r] + xb[r];
+                            yb1[r] = yb2[r];
+                            yb2[r] = 0.0f;
+                            lam[r] = yj;
                         }
-                        const int f = mt * 32 + 8 * q + 4 * h;
-                        *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + f) = d;
-                        __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(rec + (size_t)n * S::R + NZ + S::ACT4 + (l - 1) * S::H + f));
+                        if (st >= 1) {
+                            yb0[r] += ck0 * lam[r];
+                            yb1[r] += cmu * lam[r];
+                            yb2[r] += cnu * lam[r];
+                            f0b[r] += cga * lam[r];
+                            kb[r] = cmt * lam[r];
+                        } else {
+                            // Y_1 = Y_0 + mu~_1 h F_0: lam holds Ȳ_1, yb1 the nu_2 part of Ȳ_0
+                            yb0[r] += lam[r] + yb1[r];
+                            kb[r] = f0b[r] + cmt * lam[r];
+                            yb1[r] = 0.0f;
+                            f0b[r] = 0.0f;
+                        }
                     }
-                };
-                // ---- dz2 = relu'(z2) ∘ W3ᵀ dz3
-                fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, DZ3 + n * S::LDX + 4 * h,
-                                                  [&](int j, const fc16& acc) { hidden(2, DZ2, m2, db2[j], j, acc); });
-                FC_BARRIER();
-                // ---- dz1 = relu'(z1) ∘ W2ᵀ dz2
-                fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, DZ2 + n * S::LDH + 4 * h,
-                                                               [&](int j, const fc16& acc) { hidden(1, DZ1, m1, db1[j], j, acc); });
-                FC_BARRIER();
-                // ---- x̄ = W1ᵀ dz1: row tile w % MT3, K part w / MT3
-                fc_section<NZ, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, DZ1 + n * S::LDH + (w / S::MT3) * S::G3 * 8 + 4 * h,
-                    [&](int, const fc16& acc) {
-                        float* pr = XBP + ((w / S::MT3) * 32 + n) * NZ + (w % S::MT3) * 32 + 4 * h;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                            *reinterpret_cast<f32x4*>(pr + 8 * q) = v;
-                        }
-                    });
-                FC_BARRIER();
+                    pull(step * nst + st);
+                }
+                // λ_n = Ȳ_0 + J(Y_0)ᵀ F̄_0
 #pragma unroll
                 for (int r = 0; r < S::OWN; r++) {
-                    float v = 0.0f;
-#pragma unroll
-                    for (int ks = 0; ks < S::KS3; ks++) v += XBP[(ks * 32 + oc[r]) * NZ + oi];
-                    xb[r] = v;
-                    xbs[r] += v;
+                    lam[r] = yb0[r] + xb[r];
+                    yb0[r] = 0.0f;
                 }
-                // (the next stage writes DZ3 = DZ1's rows: every wave's reads of DZ1 ended before the barrier above; XBP = DZ2's rows
-                //  are next written two barriers from here)
             }
-#pragma unroll
-            for (int r = 0; r < S::OWN; r++) lam[r] += xbs[r];
         }
     }
     // ---- flush: bias gradients and the loss sum into this workgroup's slab row (weight gradients come from the dW GEMM)
@@ -440,25 +606,18 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
     FC_BARRIER();
     if (tid < S::NO) out[go.b[2] + tid] = (scr[tid] + scr[NZ + tid]) + (scr[2 * NZ + tid] + scr[3 * NZ + tid]);
     if (tid == 0) out[go.n_params + 2] = (scr[4 * NZ] + scr[4 * NZ + 1]) + (scr[4 * NZ + 2] + scr[4 * NZ + 3]);
-#pragma unroll
-    for (int j = 0; j < S::JH; j++)
-#pragma unroll
-        for (int l = 0; l < 2; l++) {
-            const fc16& acc = l == 0 ? db1[j] : db2[j];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float v = acc[r];
-                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);      // over the 32 columns of this half (h fixed)
-                if (n == 0) out[go.b[l] + (w + 4 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = v;
-            }
-        }
+    if (tid < S::H) {
+        out[go.b[0] + tid] = db1;
+        out[go.b[1] + tid] = db2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 bool fc_supported(const DevModel& m, int stepper) {
-    if (m.model != COLNDE_MODEL_FREE_CONVECTION || stepper != COLNDE_STEPPER_RK4) return false;
+    const bool fc = m.model == COLNDE_MODEL_FREE_CONVECTION, ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE;
+    if (!(fc && stepper == COLNDE_STEPPER_RK4) && !(ca && (stepper == COLNDE_STEPPER_RK4 || stepper == COLNDE_STEPPER_RKC2))) return false;
     if (m.Nz != 32 && m.Nz != 64) return false;
     if (m.n_layers != 3 || m.n_nets != 1) return false;
     if (m.sizes[0] != m.Nz || m.sizes[1] != 4 * m.Nz || m.sizes[2] != 4 * m.Nz || m.sizes[3] != m.Nz - 1) return false;
@@ -472,16 +631,20 @@ size_t fc_record_row_floats(int Nz) { return Nz == 64 ? Fc<64>::R : Fc<32>::R; }
 template <int NZ> static size_t fc_lds_fwd() { return (size_t)(32 * Fc<NZ>::LDX + 2 * 32 * Fc<NZ>::LDH + Fc<NZ>::BIAS) * sizeof(float); }
 template <int NZ> static size_t fc_lds_adj() { return (size_t)(2 * 32 * Fc<NZ>::LDH) * sizeof(float); }
 
+// the instantiated (model, stepper) pairs: FreeConvectionNDE x RK4; ConvectiveAdjustmentNDE x {RK4, RKC2}
+#define FC_FOR_EACH_FWD(M) M(64, true, false, false) M(64, false, false, false) M(32, true, false, false) M(32, false, false, false) \
+                           M(64, true, true, false) M(64, false, true, false) M(32, true, true, false) M(32, false, true, false)     \
+                           M(64, true, true, true) M(64, false, true, true) M(32, true, true, true) M(32, false, true, true)
+#define FC_FOR_EACH_ADJ(M) M(64, false, false) M(32, false, false) M(64, true, false) M(32, true, false) M(64, true, true) M(32, true, true)
+
 hipError_t fc_set_kernel_attributes() {
     hipError_t e;
-#define FC_ATTR(K, B) if ((e = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B))) != hipSuccess) return e
-    FC_ATTR((fc_forward_kernel<64, true>), fc_lds_fwd<64>());
-    FC_ATTR((fc_forward_kernel<64, false>), fc_lds_fwd<64>());
-    FC_ATTR((fc_forward_kernel<32, true>), fc_lds_fwd<32>());
-    FC_ATTR((fc_forward_kernel<32, false>), fc_lds_fwd<32>());
-    FC_ATTR((fc_adjoint_kernel<64>), fc_lds_adj<64>());
-    FC_ATTR((fc_adjoint_kernel<32>), fc_lds_adj<32>());
-#undef FC_ATTR
+#define FC_ATTR_F(N, T, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_forward_kernel<N, T, C, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<N>())) != hipSuccess) return e;
+#define FC_ATTR_A(N, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_adjoint_kernel<N, C, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_adj<N>())) != hipSuccess) return e;
+    FC_FOR_EACH_FWD(FC_ATTR_F)
+    FC_FOR_EACH_ADJ(FC_ATTR_A)
+#undef FC_ATTR_F
+#undef FC_ATTR_A
     return hipSuccess;
 }
 
@@ -494,31 +657,45 @@ hipError_t fc_launch_pack(const DevModel& m, const float* w, float* imgf, float*
 }
 
 hipError_t fc_launch_forward(const DevModel& m, const float* imgf, const float* bias, const float* x0, const float* bcs, const float* save_times,
-                             int n_save, int substeps, float* sol, float* dwtape, unsigned int* masks, int n_col, hipStream_t stream) {
+                             int n_save, int substeps, float* sol, float* dwtape, unsigned int* masks, unsigned long long* swtape, int n_col,
+                             hipStream_t stream) {
     if (n_col < 1) return hipErrorInvalidValue;
     const dim3 grid((n_col + 31) / 32), block(256);
-    const float CN = m.C_fc * (float)m.Nz;
-    const bool tape = dwtape != nullptr;
-    if (tape && !masks) return hipErrorInvalidValue;
-#define FC_FWD(N, T) hipLaunchKernelGGL((fc_forward_kernel<N, T>), grid, block, fc_lds_fwd<N>(), stream, imgf, bias, x0, bcs, save_times, n_save, substeps, CN, sol, dwtape, masks, n_col)
-    if (m.Nz == 64) { if (tape) FC_FWD(64, true); else FC_FWD(64, false); }
-    else { if (tape) FC_FWD(32, true); else FC_FWD(32, false); }
+    const float CN = m.C_fc * (float)m.Nz, caKN = m.ca_K * (float)m.Nz;
+    const bool tape = dwtape != nullptr, ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE, rk = m.rkc != nullptr;
+    if (tape && (!masks || (ca && !swtape))) return hipErrorInvalidValue;
+    if (rk && !ca) return hipErrorInvalidValue;
+    bool launched = false;
+#define FC_FWD(N, T, C, K)                                                                                                                        \
+    if (!launched && m.Nz == N && tape == T && ca == C && rk == K) {                                                                              \
+        hipLaunchKernelGGL((fc_forward_kernel<N, T, C, K>), grid, block, fc_lds_fwd<N>(), stream, imgf, bias, x0, bcs, save_times, n_save, substeps, \
+                           CN, caKN, m.nst, m.rkc, sol, dwtape, masks, swtape, n_col);                                                            \
+        launched = true;                                                                                                                          \
+    }
+    FC_FOR_EACH_FWD(FC_FWD)
 #undef FC_FWD
-    return hipGetLastError();
+    return launched ? hipGetLastError() : hipErrorInvalidValue;
 }
 
 hipError_t fc_launch_adjoint(const DevModel& m, const float* imgb, const float* save_times, int n_save, int substeps, const float* sol,
-                             const float* truth, float* dwtape, const unsigned int* masks, float w_loss, float* slab, int n_col,
-                             hipStream_t stream) {
+                             const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape, float w_loss,
+                             float* slab, int n_col, hipStream_t stream) {
     if (n_col < 1 || !dwtape || !masks) return hipErrorInvalidValue;
     const dim3 grid((n_col + 31) / 32), block(256);
-    const float CN = m.C_fc * (float)m.Nz;
+    const float CN = m.C_fc * (float)m.Nz, caKN = m.ca_K * (float)m.Nz;
+    const bool ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE, rk = m.rkc != nullptr;
+    if ((ca && !swtape) || (rk && !ca)) return hipErrorInvalidValue;
     FcGrad go;
     for (int l = 0; l < 3; l++) go.b[l] = m.b_off[l];
     go.n_params = m.n_params;
-    if (m.Nz == 64) hipLaunchKernelGGL(fc_adjoint_kernel<64>, grid, block, fc_lds_adj<64>(), stream, imgb, save_times, n_save, substeps, CN, sol, truth,
-                                       dwtape, masks, w_loss, slab, go, n_col);
-    else hipLaunchKernelGGL(fc_adjoint_kernel<32>, grid, block, fc_lds_adj<32>(), stream, imgb, save_times, n_save, substeps, CN, sol, truth, dwtape,
-                            masks, w_loss, slab, go, n_col);
-    return hipGetLastError();
+    bool launched = false;
+#define FC_ADJ(N, C, K)                                                                                                                           \
+    if (!launched && m.Nz == N && ca == C && rk == K) {                                                                                           \
+        hipLaunchKernelGGL((fc_adjoint_kernel<N, C, K>), grid, block, fc_lds_adj<N>(), stream, imgb, save_times, n_save, substeps, CN, caKN, m.nst, \
+                           m.rkc, sol, truth, dwtape, masks, swtape, w_loss, slab, go, n_col);                                                    \
+        launched = true;                                                                                                                          \
+    }
+    FC_FOR_EACH_ADJ(FC_ADJ)
+#undef FC_ADJ
+    return launched ? hipGetLastError() : hipErrorInvalidValue;
 }

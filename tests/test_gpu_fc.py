@@ -90,14 +90,82 @@ def test_fc32_config4_time_axis_129_save_points():
 
 def test_fc32_selection_and_refusals(monkeypatch):
     p = synthetic.free_convection_problem(8, Nz=32, n_save=3)
-    with pytest.raises(colnde.ColndeError, match="fc32"):           # ConvectiveAdjustmentNDE is not covered: explicit request fails loudly
-        colnde.ColumnNDE(synthetic.free_convection_problem(8, Nz=32, n_save=3, substeps=40, convective_adjustment=True).cfg, 8, engine=ENGINE_FC32)
+    with pytest.raises(colnde.ColndeError, match="fc32"):           # wind mixing is not covered: an explicit request fails loudly
+        colnde.ColumnNDE(synthetic.wind_mixing_problem(8, n_frames=3).cfg, 8, engine=ENGINE_FC32)
     with pytest.raises(colnde.ColndeError, match="fc32"):           # another network shape
         colnde.ColumnNDE(synthetic.free_convection_problem(8, Nz=32, n_save=3, layer_sizes=(32, 48, 40, 31)).cfg, 8, engine=ENGINE_FC32)
     with colnde.ColumnNDE(synthetic.free_convection_problem(8, Nz=32, n_save=3, layer_sizes=(32, 48, 40, 31)).cfg, 8) as nde:
         assert nde.engine == ENGINE_TILE16                           # AUTO falls back
     with colnde.ColumnNDE(p.cfg.with_(stepper="rkc2"), 8) as nde:
-        assert nde.engine == ENGINE_TILE16                           # RKC2 lives in tile16
+        assert nde.engine == ENGINE_TILE16                           # FreeConvectionNDE under RKC2 (not stiff: nobody needs it) stays in tile16
+    ca = synthetic.free_convection_problem(8, Nz=32, n_save=3, substeps=40, convective_adjustment=True).cfg
+    for cfg in (ca, ca.with_(stepper="rkc2", substeps=2)):
+        with colnde.ColumnNDE(cfg, 8) as nde:
+            assert nde.engine == ENGINE_FC32                         # ConvectiveAdjustmentNDE: RK4 and RKC2
     monkeypatch.setenv("COLNDE_FC", "0")
     with colnde.ColumnNDE(p.cfg, 8) as nde:
         assert nde.engine == ENGINE_TILE16
+
+
+@pytest.mark.parametrize("Nz,ncol", [(32, 19), (32, 70), (64, 45)])
+def test_fc32_conv_adj_nde_rk4_against_oracle_and_tile16(Nz, ncol):
+    """ConvectiveAdjustmentNDE (convective_adjustment_nde.jl:33-48) on the fc32 engine, sub-stepped RK4, from a profile with an inverted
+    layer so that the min(0, K dT/dz) switch is live: the exact discrete adjoint (every stage's own switch pattern, taped as bits)."""
+    p = synthetic.free_convection_problem(ncol, Nz=Nz, n_save=5, substeps=20 * (Nz // 32) ** 2, convective_adjustment=True, t_end=0.01)
+    x0 = p.x0.copy()
+    x0[:, Nz // 2:Nz // 2 + 6] = x0[:, Nz // 2:Nz // 2 + 6][:, ::-1]
+    truth = O.solve(p.cfg, x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(p.cfg)
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, x0, p.bcs, p.weights, truth, sc)
+    tot32, _, g32, sol32 = O.loss_and_grad(p.cfg, x0, p.bcs, p.weights, truth, sc, dtype=np.float32)
+    res = {}
+    for eng in (0, ENGINE_TILE16):
+        with colnde.ColumnNDE(p.cfg, ncol, engine=eng) as nde:
+            assert nde.engine == (ENGINE_FC32 if eng == 0 else ENGINE_TILE16)
+            nde.set_problem(x0, p.bcs, truth)
+            sol_g = nde.forward(p.weights)
+            tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+            tot_2, _, grad_2 = nde.loss_grad(p.weights, sc)
+        assert tot_2 == tot_g and np.array_equal(grad_2, grad_g)
+        res[eng] = (sol_g, tot_g, grad_g)
+    sol_g, tot_g, grad_g = res[0]
+    e32 = (np.abs(sol32 - sol).max(), abs(tot32 - tot) / tot, _rel(g32, g))
+    _record("fc32/ca_rk4/%d/%d" % (Nz, ncol), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g),
+            grad_rel_f32=_rel(grad_g, g32.astype(np.float64)), grad_rel_oracle32_vs_64=e32[2], grad_rel_vs_tile16=_rel(grad_g, res[ENGINE_TILE16][2].astype(np.float64)))
+    # layers sitting on the kink make float32 part from float64 (DESIGN §2): the yardstick is the float32 oracle's own distance
+    assert np.abs(sol_g - sol).max() < 3 * e32[0] + 2 * FC_SOL_ATOL
+    assert abs(tot_g - tot) / abs(tot) < 3 * e32[1] + FC_LOSS_RTOL
+    assert _rel(grad_g, g) < 3 * e32[2] + FC_GRAD_REL
+
+
+@pytest.mark.parametrize("Nz,ncol,case", [(32, 37, "stratified"), (64, 33, "stratified"), (64, 5, "inverted")])
+def test_fc32_conv_adj_nde_rkc2_against_oracle_and_tile16(Nz, ncol, case):
+    """ConvectiveAdjustmentNDE under the stabilised RKC2 stepper (the configs[3] half the reference integrates with ROCK4) on the fc32
+    engine: the oracle's RKC2 recurrence and its one-switch-pattern-per-step pullback, as in tile16 (tests/test_gpu_rkc.py)."""
+    p = synthetic.free_convection_problem(ncol, Nz=Nz, n_save=9, substeps=2, convective_adjustment=True, t_end=0.06)
+    cfg = p.cfg.with_(stepper="rkc2")
+    x0 = p.x0.copy()
+    if case == "inverted":
+        x0[:, 20:44] = x0[:, 20:44][:, ::-1]
+    assert colnde.rkc_stages(cfg) >= 4
+    truth = O.solve(cfg, x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(cfg)
+    tot, terms, g, sol = O.loss_and_grad(cfg, x0, p.bcs, p.weights, truth, sc)
+    tot32, _, g32, sol32 = O.loss_and_grad(cfg, x0, p.bcs, p.weights, truth, sc, dtype=np.float32)
+    res = {}
+    for eng in (0, ENGINE_TILE16):
+        with colnde.ColumnNDE(cfg, ncol, engine=eng) as nde:
+            assert nde.engine == (ENGINE_FC32 if eng == 0 else ENGINE_TILE16)
+            nde.set_problem(x0, p.bcs, truth)
+            sol_g = nde.forward(p.weights)
+            tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+        res[eng] = (sol_g, tot_g, grad_g)
+    sol_g, tot_g, grad_g = res[0]
+    e32 = (np.abs(sol32 - sol).max(), abs(tot32 - tot) / tot, _rel(g32, g))
+    _record("fc32/ca_rkc2/%d/%s" % (Nz, case), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g),
+            sol_abs_oracle32_vs_64=e32[0], loss_rel_oracle32_vs_64=e32[1], grad_rel_oracle32_vs_64=e32[2],
+            sol_abs_vs_tile16=np.abs(sol_g - res[ENGINE_TILE16][0]).max(), grad_rel_vs_tile16=_rel(grad_g, res[ENGINE_TILE16][2].astype(np.float64)))
+    assert np.isfinite(sol_g).all() and np.isfinite(grad_g).all()
+    assert np.abs(sol_g - sol).max() < 5 * e32[0] + 2 * FC_SOL_ATOL
+    assert abs(tot_g - tot) / abs(tot) < 5 * e32[1] + FC_LOSS_RTOL
+    assert _rel(grad_g, g) < 5 * e32[2] + FC_GRAD_REL
