@@ -394,15 +394,17 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     // AUTO on a regtile-shaped problem too small for regtile (a latency point): the net-split kernels take the forward solves and
     // the adjoint (8 simulations: forward 19.8 -> 8.3 ms, adjoint 25.0 -> 8.2 ms), tile16 the tapes' formats, the dW GEMM and the reduction.
     // An explicit engine = tile16 stays pure tile16; COLNDE_T16_FWD_SPLIT=0|1 and COLNDE_T16_ADJ_SPLIT=0 override.
-    h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && cfg->engine == COLNDE_ENGINE_AUTO;
     {
-        const char* es = getenv("COLNDE_T16_FWD_SPLIT");
-        if (es) h->fwd_split = !h->use_rt && rt_supported(h->m) && cfg->stepper == COLNDE_STEPPER_RK4 && atoi(es) != 0;
-        // the gradient behind a split forward: rt16s_adjoint_kernel (same decomposition) when the taped mode with both tapes is planned
+        // (round 3: the stabilised RKC2 stepper too — in the four-wave kernels, so only with both helper waves on)
         const char* eh = getenv("COLNDE_T16_FWD_HELPER");      // 0: the three-wave forward (8 simulations 9.8 vs 8.3 ms, 4,096 columns 8.27 vs 7.65 ms)
         h->fwd_helper = !(eh && atoi(eh) == 0);
         const char* eah = getenv("COLNDE_T16_ADJ_HELPER");     // 0: the three-wave adjoint (8 simulations 11.3 vs 8.2 ms)
         h->adj_helper = !(eah && atoi(eah) == 0);
+        const bool stepper_ok = cfg->stepper == COLNDE_STEPPER_RK4 || (cfg->stepper == COLNDE_STEPPER_RKC2 && h->fwd_helper && h->adj_helper);
+        h->fwd_split = !h->use_rt && rt_supported(h->m) && stepper_ok && cfg->engine == COLNDE_ENGINE_AUTO;
+        const char* es = getenv("COLNDE_T16_FWD_SPLIT");
+        if (es) h->fwd_split = !h->use_rt && rt_supported(h->m) && stepper_ok && atoi(es) != 0;
+        // the gradient behind a split forward: rt16s_adjoint_kernel (same decomposition) when the taped mode with both tapes is planned
         const char* ea = getenv("COLNDE_T16_ADJ_SPLIT");
         h->adj_split = h->fwd_split && !(ea && atoi(ea) == 0);
     }
@@ -1383,6 +1385,8 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
     if (!h || !info) return fail("null argument");
     for (int i = 0; i < 8; i++) info[i] = 0;
     info[0] = h->use_rt ? COLNDE_ENGINE_MFMA : (h->use_fc ? COLNDE_ENGINE_FC32 : COLNDE_ENGINE_GENERIC);
+    // RKC2 on a model with a convective-adjustment switch: the gradient is the one-switch-pattern pullback (include/colnde.h)
+    info[7] = (h->cfg.stepper == COLNDE_STEPPER_RKC2 && (h->m.model == COLNDE_MODEL_CONV_ADJ_NDE || (h->m.ca && !h->m.mpp))) ? 1 : 0;
     if (h->use_fc) {
         info[1] = h->fc_block;
         info[2] = h->fc_nblocks;

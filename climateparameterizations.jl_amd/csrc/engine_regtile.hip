@@ -1797,9 +1797,14 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
 #pragma unroll
         for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
     const int n_steps = (n_save - 1) * substeps;
-    float* tp = t16_tape ? t16_tape + (size_t)tile * n_steps * 4 * 1536 + j * 96 + n * 32 + 4 * g : nullptr;
-    float* tz = (t16_ztape && !RICH) ? t16_ztape + (size_t)tile * n_steps * 4 * (16 * 216) + j * 216 + n * 72 + g : nullptr;
-    float* tr = (t16_ztape && RICH) ? t16_ztape + (size_t)tile * n_steps * 4 * RT16S_RREC + lane * 4 : nullptr;
+    // stepper: classical RK4 (nst = 4) or the s-stage RKC2 step of colnde_dev.h (m.rkc: coefficient table; increment form as in tile16's
+    // forward_kernel) — a wave-uniform run-time switch: the bookkeeping is a handful of vector operations per stage
+    const int nst = m.nst;
+    const bool rkc = m.rkc != nullptr;
+    const float* mu_t = m.rkc, *nu_t = m.rkc + RKC_LD, *mut_t = m.rkc + 2 * RKC_LD, *gat_t = m.rkc + 3 * RKC_LD, *c_t = m.rkc + 4 * RKC_LD;
+    float* tp = t16_tape ? t16_tape + (size_t)tile * n_steps * nst * 1536 + j * 96 + n * 32 + 4 * g : nullptr;
+    float* tz = (t16_ztape && !RICH) ? t16_ztape + (size_t)tile * n_steps * nst * (16 * 216) + j * 216 + n * 72 + g : nullptr;
+    float* tr = (t16_ztape && RICH) ? t16_ztape + (size_t)tile * n_steps * nst * RT16S_RREC + lane * 4 : nullptr;
     const float Nz = 32.0f;
     const float L2E = 1.4426950408889634f;
     const float cU = m.sig_u * Nz, sU = m.sig_u * m.eps, cV = m.sig_v * Nz, sV = m.sig_v * m.eps, cB = m.B * Nz, sB = m.B * m.eps;
@@ -1816,16 +1821,19 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
             const float ts = t0 + (float)s * dt;
             Kacc.t[0] = (f32x4t)(0.0f);
             Kacc.t[1] = (f32x4t)(0.0f);
+            V16 Ym1, Ym2, F0;                           // RKC2: d_{j-1}, d_{j-2} (increments Y_j - Y_0) and F_0 of variable n
+#pragma unroll
+            for (int tau = 0; tau < 2; tau++) { Ym1.t[tau] = (f32x4t)(0.0f); Ym2.t[tau] = (f32x4t)(0.0f); F0.t[tau] = (f32x4t)(0.0f); }
 #pragma nounroll
-            for (int st = 0; st < 4; st++) {
-                const float ca = st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f);
+            for (int st = 0; st < nst; st++) {
+                const float ca = rkc ? c_t[st] : (st == 0 ? 0.0f : (st == 3 ? 1.0f : 0.5f));
                 const float cb = (st == 0 || st == 3) ? 1.0f / 6.0f : 1.0f / 3.0f;
                 RT_STAMP_BEGIN();
                 f32x4v* eb = ex + buf * 384;
                 if (helper) {
                     // ---- the Richardson-number closure of all three variables (predict_flux), once, on the fourth SIMD, while the net waves run
                     //      their chains: diffusive face fluxes to LDS, and (RICH) the nine pullback coefficients to the tape
-                    float* orr = tr ? tr + ((size_t)step * 4 + st) * RT16S_RREC : nullptr;
+                    float* orr = tr ? tr + ((size_t)step * nst + st) * RT16S_RREC : nullptr;
                     V16 C[3];
                     if (m.mpp) {
                         const V16 Ud = shift_down16(Xs[0], lane, 0.0f), Vd = shift_down16(Xs[1], lane, 0.0f), Td = shift_down16(Xs[2], lane, 0.0f);
@@ -1900,12 +1908,12 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
 #pragma unroll
                     for (int r = 0; r < 4; r++) Xme.t[tau][r] = n == 0 ? Xs[0].t[tau][r] : (n == 1 ? Xs[1].t[tau][r] : Xs[2].t[tau][r]);
                 if (tp) {
-                    float* o = tp + ((size_t)step * 4 + st) * 1536;
+                    float* o = tp + ((size_t)step * nst + st) * 1536;
 #pragma unroll
                     for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(o + 16 * tau) = Xme.t[tau];
                 }
-                float* oz = tz ? tz + ((size_t)step * 4 + st) * (16 * 216) : nullptr;
-                float* orr = tr ? tr + ((size_t)step * 4 + st) * RT16S_RREC : nullptr;
+                float* oz = tz ? tz + ((size_t)step * nst + st) * (16 * 216) : nullptr;
+                float* orr = tr ? tr + ((size_t)step * nst + st) * RT16S_RREC : nullptr;
                 const float top_raw = n == 2 ? rt_top_flux(m, bc5, ts + ca * dt) : bct;
                 RT_STAMP(0);
                 // ---- net n ----------------------------------------------------------------------------------------------
@@ -1993,6 +2001,20 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                 RT_STAMP(3);
                 // ---- RK4 bookkeeping for variable n; the next stage input (or, after stage 3, the new state) is exchanged -------------
                 V16 Xnext;
+                if (rkc) {
+                    // Y_j, j = st + 1: d_1 = mu~_1 h F_0;  d_j = mu_j d_{j-1} + nu_j d_{j-2} + mu~_j h F_{j-1} + gamma~_j h F_0;  Y_s ends the step
+                    const int jj = st + 1;
+                    const float cmu = mu_t[jj], cnu = nu_t[jj], cmt = mut_t[jj] * dt, cga = gat_t[jj] * dt;
+#pragma unroll
+                    for (int tau = 0; tau < 2; tau++) {
+                        if (st == 0) F0.t[tau] = F.t[tau];
+                        const f32x4t dj = st == 0 ? cmt * F0.t[tau] : cmu * Ym1.t[tau] + cnu * Ym2.t[tau] + cmt * F.t[tau] + cga * F0.t[tau];
+                        Xnext.t[tau] = Xn.t[tau] + dj;
+                        Ym2.t[tau] = Ym1.t[tau];
+                        Ym1.t[tau] = dj;
+                        if (jj == nst) Xn.t[tau] = Xnext.t[tau];
+                    }
+                } else {
 #pragma unroll
                 for (int tau = 0; tau < 2; tau++) {
                     Kacc.t[tau] += cb * F.t[tau];
@@ -2003,6 +2025,7 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                         Xn.t[tau] += dt * Kacc.t[tau];
                         Xnext.t[tau] = Xn.t[tau];
                     }
+                }
                 }
 #pragma unroll
                 for (int tau = 0; tau < 2; tau++) eb[(n * 2 + tau) * 64 + lane] = Xnext.t[tau];
@@ -2563,13 +2586,15 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
     const bool valid = col < n_col;
     const int colc = min(col, n_col - 1);
     const int n_steps = (n_save - 1) * substeps;
-    const float* tp = t16_tape + (size_t)tile * n_steps * 4 * 1536 + j * 96 + 4 * g;
+    const int nst = m.nst;                                              // RHS evaluations (= tape records) per step: 4 (RK4) or s (RKC2)
+    const bool rkc = m.rkc != nullptr;
+    const float* tp = t16_tape + (size_t)tile * n_steps * nst * 1536 + j * 96 + 4 * g;
     const bool phys = m.mpp || m.ca;
     float* out = slab + (size_t)tile * (m.n_params + 8);
 
     if (helper) {
         // ================================================= the helper wave: λ, x̄, loss injection, physics pullback ======================
-        const float* tzr = t16_ztape + (size_t)tile * n_steps * 4 * RT16S_RREC + lane * 4;             // RICH: the rich tape
+        const float* tzr = t16_ztape + (size_t)tile * n_steps * nst * RT16S_RREC + lane * 4;             // RICH: the rich tape
         V16 lam[3], xb[3], xbs[3];
 #pragma unroll
         for (int q = 0; q < 3; q++)
@@ -2636,31 +2661,69 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                     for (int tau = 0; tau < 2; tau++) Xp[q].t[tau] = *reinterpret_cast<const f32x4v*>(sx + q * 32 + 16 * tau);
             }
         };
+        // RKC2 (discrete adjoint of the recurrence, as in tile16's adjoint_kernel): cotangents of Y_{j-1} (yb1), Y_{j-2} (yb2), Y_0 (yb0), F_0 (f0b);
+        // lam is the cotangent of Y_j.  The convective-adjustment switch is pulled back with ONE pattern per step, that of Y_{s-1}:
+        // the physics data of every stage of a step are then read from the record of its last stage.
+        V16 yb0[3], yb1[3], yb2[3], f0b[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int tau = 0; tau < 2; tau++) { yb0[q].t[tau] = (f32x4t)(0.0f); yb1[q].t[tau] = (f32x4t)(0.0f); yb2[q].t[tau] = (f32x4t)(0.0f); f0b[q].t[tau] = (f32x4t)(0.0f); }
+        const float* mu_t = m.rkc, *nu_t = m.rkc + RKC_LD, *mut_t = m.rkc + 2 * RKC_LD, *gat_t = m.rkc + 3 * RKC_LD, *kap_t = m.rkc + 5 * RKC_LD;
+        const bool one_pattern = rkc && m.ca && !m.mpp;
+#define PHYS_Q(q) (one_pattern ? ((q) / nst) * nst + nst - 1 : (q))
         inject(0, false);
-        prefetch(n_steps * 4 - 1);
+        prefetch(PHYS_Q(n_steps * nst - 1));
         for (int iv = n_save - 2; iv >= 0; iv--) {
             const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
             inject(iv + 1, true);
             for (int s = substeps - 1; s >= 0; s--) {
                 const int step = iv * substeps + s;
 #pragma nounroll
-                for (int st = 3; st >= 0; st--) {
+                for (int st = nst - 1; st >= 0; st--) {
                     const float cwl = (st == 0 || st == 3) ? dt / 6.0f : dt / 3.0f;
                     const float cwx = st == 3 ? 0.0f : (st == 2 ? dt : 0.5f * dt);
-                    const int qs = step * 4 + st;
+                    const int qs = step * nst + st;
                     V16 kb[3], xbp[3];
+                    if (rkc) {
+                        // stage input Y_st feeds Y_j, j = st + 1, through mu~_j h F_st
+                        const float cmu = mu_t[st + 1], cnu = nu_t[st + 1], cmt = mut_t[st + 1] * dt, cga = gat_t[st + 1] * dt, ck0 = kap_t[st + 1];
+#pragma unroll
+                        for (int q = 0; q < 3; q++)
+#pragma unroll
+                            for (int tau = 0; tau < 2; tau++) {
+                                if (st < nst - 1) {        // lam = cotangent of Y_j, complete once the previous pullback (xb: J(Y_j)^T F̄_j) is added
+                                    lam[q].t[tau] = yb1[q].t[tau] + xb[q].t[tau];
+                                    yb1[q].t[tau] = yb2[q].t[tau];
+                                    yb2[q].t[tau] = (f32x4t)(0.0f);
+                                }
+                                if (st >= 1) {
+                                    yb0[q].t[tau] += ck0 * lam[q].t[tau];
+                                    yb1[q].t[tau] += cmu * lam[q].t[tau];
+                                    yb2[q].t[tau] += cnu * lam[q].t[tau];
+                                    f0b[q].t[tau] += cga * lam[q].t[tau];
+                                    kb[q].t[tau] = cmt * lam[q].t[tau];
+                                } else {                   // Y_1 = Y_0 + mu~_1 h F_0: lam holds Ȳ_1, yb1 the nu_2 part of Ȳ_0
+                                    yb0[q].t[tau] += lam[q].t[tau] + yb1[q].t[tau];
+                                    kb[q].t[tau] = f0b[q].t[tau] + cmt * lam[q].t[tau];
+                                    yb1[q].t[tau] = (f32x4t)(0.0f);
+                                    f0b[q].t[tau] = (f32x4t)(0.0f);
+                                }
+                            }
+                    } else {
 #pragma unroll
                     for (int q = 0; q < 3; q++)
 #pragma unroll
                         for (int tau = 0; tau < 2; tau++) kb[q].t[tau] = cwl * lam[q].t[tau] + cwx * xb[q].t[tau];
+                    }
                     if (RICH) {
                         rt16_physics_apply(m, Pp, kb, lane, xbp);                        // kb now holds dO
-                        if (qs > 0) prefetch(qs - 1);
+                        if (qs > 0) prefetch(PHYS_Q(qs - 1));
                     } else {
                         V16 X[3];
 #pragma unroll
                         for (int q = 0; q < 3; q++) X[q] = Xp[q];
-                        if (qs > 0) prefetch(qs - 1);
+                        if (qs > 0) prefetch(PHYS_Q(qs - 1));
                         rt16_physics_vjp(m, X, kb, lane, xbp);
                     }
 #pragma unroll
@@ -2679,11 +2742,15 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                             xbs[q].t[tau] += xb[q].t[tau];
                         }
                 }
-                // λ_n = λ_{n+1} + x̄_1 + x̄_2 + x̄_3 + x̄_4
+                // RK4: λ_n = λ_{n+1} + x̄_1 + x̄_2 + x̄_3 + x̄_4;  RKC2: λ_n = Ȳ_0 + J(Y_0)^T F̄_0
 #pragma unroll
                 for (int q = 0; q < 3; q++)
 #pragma unroll
-                    for (int tau = 0; tau < 2; tau++) { lam[q].t[tau] += xbs[q].t[tau]; xbs[q].t[tau] = (f32x4t)(0.0f); }
+                    for (int tau = 0; tau < 2; tau++) {
+                        if (rkc) { lam[q].t[tau] = yb0[q].t[tau] + xb[q].t[tau]; yb0[q].t[tau] = (f32x4t)(0.0f); }
+                        else lam[q].t[tau] += xbs[q].t[tau];
+                        xbs[q].t[tau] = (f32x4t)(0.0f);
+                    }
             }
         }
 #pragma unroll
@@ -2716,9 +2783,9 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
     for (int t = 0; t < 4; t++) gb1[t] = (f32x4t)(0.0f);
 #pragma unroll
     for (int u = 0; u < 2; u++) { gb2[u] = (f32x4t)(0.0f); gb3[u] = (f32x4t)(0.0f); }
-    const float* tz = RICH ? t16_ztape + (size_t)tile * n_steps * 4 * RT16S_RREC + lane * 4
-                           : t16_ztape + (size_t)tile * n_steps * 4 * RT16S_ZREC + j * 216 + n * 72 + g;
-    float* rec0 = dwtape + (size_t)tile * n_steps * 4 * RT16S_REC;
+    const float* tz = RICH ? t16_ztape + (size_t)tile * n_steps * nst * RT16S_RREC + lane * 4
+                           : t16_ztape + (size_t)tile * n_steps * nst * RT16S_ZREC + j * 216 + n * 72 + g;
+    float* rec0 = dwtape + (size_t)tile * n_steps * nst * RT16S_REC;
     int stg_rd[11], rec_wr[11];
 #pragma unroll
     for (int i = 0; i < 11; i++) {
@@ -2748,14 +2815,14 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
             for (int Q2 = 0; Q2 < 5; Q2++) z2p[Q2] = sz[52 + 4 * Q2];
         }
     };
-    prefetch(n_steps * 4 - 1);
+    prefetch(n_steps * nst - 1);
     RT_STAMP_DECL;
     for (int iv = n_save - 2; iv >= 0; iv--) {
         for (int s = substeps - 1; s >= 0; s--) {
             const int step = iv * substeps + s;
 #pragma nounroll
-            for (int st = 3; st >= 0; st--) {
-                const int qs = step * 4 + st;
+            for (int st = nst - 1; st >= 0; st--) {
+                const int qs = step * nst + st;
                 RT_STAMP_BEGIN();
                 // ---- before (B), beside the helper's pullback: everything that depends on the tapes alone ----
                 f32x4t A1[4], D1[4], A2[2], D2[2];
@@ -3042,6 +3109,7 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
     const dim3 grid((n_col + 15) / 16), block(192);
     const size_t ldsh = lds + 384 * 16;
     const dim3 blockh(256);
+    if (m.nst != 4 && !(m.rkc && use_helper)) return hipErrorInvalidValue;      // RKC2 lives in the four-wave kernels only
 #define RT_FWDS(A)                                                                                                                              \
     do {                                                                                                                                        \
         if (use_helper && rich) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
@@ -3066,7 +3134,7 @@ hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const f
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
                                    int n_col, float* dwtape, bool rich, bool use_helper, hipStream_t stream) {
     // the record formats this kernel reads and writes are tile16's for exactly this shape
-    if (!rt_supported(m) || dwtape_row_floats(m) * CT != RT16S_REC || t16_ztape_col_floats(m) * CT != RT16S_ZREC || m.nst != 4)
+    if (!rt_supported(m) || dwtape_row_floats(m) * CT != RT16S_REC || t16_ztape_col_floats(m) * CT != RT16S_ZREC || (m.nst != 4 && !(m.rkc && use_helper)))
         return hipErrorInvalidValue;
     const size_t lds = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + 2 * (3 * 6 * 64) * 16 + 3 * RT16S_STG * sizeof(float);
     const dim3 grid((n_col + 15) / 16), block(192);

@@ -112,7 +112,8 @@ class ColumnNDE:
         info = (ctypes.c_int * 8)()
         _lib.check(self._L.colnde_plan(self._h, info))
         return dict(engine=info[0], block_columns=info[1], n_blocks=info[2], z1_taped=bool(info[3]),
-                    dw_taped=bool(info[4]), dw_slices=info[5], split_forward=bool(info[6] & 1), split_adjoint=bool(info[6] & 2), split_rich_tape=bool(info[6] & 4))
+                    dw_taped=bool(info[4]), dw_slices=info[5], split_forward=bool(info[6] & 1), split_adjoint=bool(info[6] & 2), split_rich_tape=bool(info[6] & 4),
+                    approximate_gradient=bool(info[7] & 1))
 
     def pretrain_flux(self, flux_type: int, theta, m, v, profiles, bcs, fluxes, order, gradient_scaling: float, opt, update: bool = True):
         """`colnde_pretrain_flux_dev`: one `Flux.train!` pass (one ADAM update per sample, in `order`) over device tensors; `opt` is a

@@ -43,8 +43,17 @@ enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it 
 
 enum { COLNDE_STEPPER_RK4 = 0,      /* classical RK4, `substeps` per save interval (what the bench measures) */
        COLNDE_STEPPER_RKC2 = 1 };   /* stabilised second-order Runge-Kutta-Chebyshev for the stiff variants: `substeps` steps per
-                                       save interval of `rkc_stages` stages each (tile16 engine).  Stands where the reference
-                                       uses ROCK4 (wind_mixing/train_NDE.jl:143, free_convection/test_free_convection_nde.jl:32-35) */
+                                       save interval of `rkc_stages` stages each (tile16; the net-split latency kernels; fc32 for
+                                       ConvectiveAdjustmentNDE).  Stands where the reference uses ROCK4 (wind_mixing/train_NDE.jl:143,
+                                       free_convection/test_free_convection_nde.jl:32-35).
+                                       GRADIENT CAVEAT: for the models with a convective-adjustment switch (min(0, K dT/dz):
+                                       ConvectiveAdjustmentNDE, the wind-mixing `convective_adjustment` branch) the RKC2 gradient is
+                                       NOT the exact discrete adjoint — that one is unbounded, the stage Jacobians of one step
+                                       differing in their switch patterns — but the pullback with ONE switch pattern per step (that
+                                       of the last stage input).  It converges to the sub-stepped RK4 gradient as the step shrinks
+                                       (6.5 % / cosine 0.998 at 8 steps per save interval of the 64-level model, 2 % at 16)
+                                       and is exact for smooth closures (the Richardson-number branch).  colnde_plan reports it
+                                       (info[7] bit 0). */
 
 /* Mirrors the `constants`, `scalings`, `conditions` NamedTuples of prepare_parameters_NDE_training
  * (wind_mixing/src/NDE_training.jl:1-44, :205-207) and the parameter tail of the free-convection NDEs
@@ -229,7 +238,8 @@ int  colnde_allreduce_result_dev(colnde_handle* h, colnde_comm* comm, float* d_o
  * pre-activations taped (1) or recomputed (0), [4] tile16: weight gradients taped (1) or accumulated in registers (0),
  * [5] tile16 taped mode: K-slices of the dW GEMM, [6] net-split kernels of the latency points (per 16-column tile one wavefront per flux net
  * plus a helper wavefront): bit 0 = forward solve, bit 1 = adjoint, bit 2 = with the rich tape (activations, their derivatives and the physics-pullback
- * coefficients taped by the forward kernel: blocks of at most 2,048 columns), [7] reserved (0). */
+ * coefficients taped by the forward kernel: blocks of at most 2,048 columns), [7] bit 0 = the gradient is the one-switch-pattern
+ * RKC2 pullback, an approximation of the discrete adjoint (see COLNDE_STEPPER_RKC2); 0 = exact discrete adjoint of the stepper. */
 int colnde_plan(const colnde_handle* h, int info[8]);
 
 /* ---- measurement: HIP-event timing of the handle's kernels on its stream.

@@ -187,12 +187,14 @@ function compute_neural_network_forcing!(forcing::Matrix{Float32}, h::Handle, we
     forcing
 end
 
-"how the gradient path runs: (engine, block_columns, n_blocks, z1_taped, dw_taped, dw_slices, split_forward, split_adjoint, split_rich_tape) — colnde_plan"
+"how the gradient path runs: (engine, block_columns, n_blocks, z1_taped, dw_taped, dw_slices, split_forward, split_adjoint, split_rich_tape,
+approximate_gradient = the one-switch-pattern RKC2 pullback, see COLNDE_STEPPER_RKC2 in colnde.h) — colnde_plan"
 function plan(h::Handle)
     info = zeros(Cint, 8)
     check(ccall((:colnde_plan, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Cint}), h.ptr, info))
     (engine=info[1], block_columns=info[2], n_blocks=info[3], z1_taped=info[4] != 0, dw_taped=info[5] != 0, dw_slices=info[6],
-     split_forward=(info[7] & 1) != 0, split_adjoint=(info[7] & 2) != 0, split_rich_tape=(info[7] & 4) != 0)
+     split_forward=(info[7] & 1) != 0, split_adjoint=(info[7] & 2) != 0, split_rich_tape=(info[7] & 4) != 0,
+     approximate_gradient=(info[8] & 1) != 0)
 end
 
 # ---- multi-GPU: one Julia process per GPU, columns sharded, ONE exchange per optimiser iteration (include/colnde.h, colnde_comm_*) ----
