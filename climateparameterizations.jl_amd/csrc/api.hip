@@ -1177,6 +1177,15 @@ extern "C" int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights
     if (h->m.model == COLNDE_MODEL_WIND_MIXING) return fail("infer_forcing needs a single T-only network (free-convection model)");
     if (n_columns < 1 || !(Lz > 0.0f)) return fail("n_columns >= 1 and Lz > 0 required");
     HIPCHK(hipSetDevice(h->device));
+    if (h->use_fc && h->m.model == COLNDE_MODEL_FREE_CONVECTION) {
+        // the reference's forcing network IS the fc32 shape (32-128-128-31 in double_gyre_nn.jl): the 32-column engine's sections, one evaluation
+        hipError_t ef = fc_launch_pack(h->m, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        if (ef != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(ef));
+        Timed tm(h, K_INFER);
+        ef = fc_launch_infer(h->m, h->d_fc_imgf, h->d_fc_bias, d_T, d_top_flux, (float)h->m.Nz / Lz, d_out, n_columns, h->stream);
+        if (ef != hipSuccess) return fail("fc32 infer launch failed: %s", hipGetErrorString(ef));
+        return 0;
+    }
     if (pack(h, d_weights)) return 1;
     Timed tm(h, K_INFER);
     hipError_t e = launch_infer(h->m, h->pk, d_weights, h->d_wf, d_T, d_top_flux, (float)h->m.Nz / Lz, d_out, n_columns, 256,

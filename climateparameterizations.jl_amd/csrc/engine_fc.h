@@ -22,3 +22,6 @@ hipError_t fc_launch_forward(const DevModel& m, const float* imgf, const float* 
 hipError_t fc_launch_adjoint(const DevModel& m, const float* imgb, const float* save_times, int n_save, int substeps, const float* sol,
                              const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape, float w_loss,
                              float* slab, int n_col, hipStream_t stream);
+// compute_neural_network_forcing! (double_gyre_nn.jl:149-168): T [n_col][Nz] model units, top_flux [n_col], out = -dz(wT) on cell centres
+hipError_t fc_launch_infer(const DevModel& m, const float* imgf, const float* bias, const float* T, const float* top_flux, float inv_dz,
+                           float* out, int n_col, hipStream_t stream);

@@ -378,6 +378,91 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
 }
 
 // ------------------------------------------------------------------------------------------------
+// embedded inference: compute_neural_network_forcing! (free_convection/double_gyre_nn.jl:149-168; BASELINE configs[4]) — one evaluation of
+// the network per column and the divergence of the flux it predicts.  The same sections as the forward solve, a workgroup walking over
+// tiles (gridDim.x workgroups, tile += gridDim.x) so that the A-operand ring keeps streaming from one tile to the next.
+//   T̂ = T_scaling(19.65 + T/20) (:156-158), wT = enforce_fluxes(inv(wT_scaling)(NN(T̂)), 0, surface_flux) (:160), forcing = -∂z wT (:135)
+// ------------------------------------------------------------------------------------------------
+template <int NZ>
+__global__ void __launch_bounds__(256, 2)
+fc_infer_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, const float* __restrict__ T, const float* __restrict__ top_flux,
+                float mu_T, float inv_sig_T, float sig_wT, float mu_wT, float inv_dz, float* __restrict__ out, int n_col) {
+    using S = Fc<NZ>;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    float* X = fc_smem;
+    float* A1 = X + 32 * S::LDX;
+    float* A2 = A1 + 32 * S::LDH;
+    float* PART = A1;
+    float* BL = A2 + 32 * S::LDH;
+    for (int q = tid; q < S::BIAS; q += 256) BL[q] = bias[q];
+    FC_OWNER_INDEX();
+    const f32x4* base[3];
+    base[0] = reinterpret_cast<const f32x4*>(imgf + S::F1) + (w * S::S_IN) * 64;
+    base[1] = reinterpret_cast<const f32x4*>(imgf + S::F2) + (w * S::S_H) * 64;
+    base[2] = reinterpret_cast<const f32x4*>(imgf + S::F3) + ((w % S::MT3) * S::S_H + (w / S::MT3) * S::G3) * 64;
+    f32x4 ring[FC_PF];
+#pragma unroll
+    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ>(q)] + fc_off<NZ>(q))[lane];
+    const float b3v = oi < S::NO ? bias[2 * S::H + oi] : 0.0f;
+    asm volatile("" :: "v"(b3v));
+    const int n_tiles = (n_col + 31) / 32;
+#pragma nounroll
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int zero = 0;
+        FC_OPAQUE_ZERO(zero);
+        const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
+        const int col0 = tile * 32;
+        float tf[S::OWN];
+#pragma unroll
+        for (int r = 0; r < S::OWN; r++) {
+            const int col = min(col0 + oc[r], n_col - 1);
+            X[oc[r] * S::LDX + oi] = ((19.65f + T[(size_t)col * NZ + oi] / 20.0f) - mu_T) * inv_sig_T;
+            tf[r] = top_flux[col];
+        }
+        FC_BARRIER();
+        auto hidden = [&](int l, float* dstrows, int j, const fc16& acc) {
+            const int mt = w + 4 * j;
+            const float* bl = BL + (l - 1) * S::H + mt * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + 8 * q);
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; e++) a[e] = fmaxf(acc[4 * q + e] + bq[e], 0.0f);
+                *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + mt * 32 + 8 * q + 4 * h) = a;
+            }
+        };
+        fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h, [&](int j, const fc16& acc) { hidden(1, A1, j, acc); });
+        FC_BARRIER();
+        fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h, [&](int j, const fc16& acc) { hidden(2, A2, j, acc); });
+        FC_BARRIER();
+        fc_section<NZ, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, A2 + n * S::LDH + (w / S::MT3) * S::G3 * 8 + 4 * h,
+            [&](int, const fc16& acc) {
+                float* pr = PART + ((w / S::MT3) * 32 + n) * NZ + (w % S::MT3) * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(pr + 8 * q) = v;
+                }
+            });
+        FC_BARRIER();
+#pragma unroll
+        for (int r = 0; r < S::OWN; r++) {
+            float o = b3v;
+#pragma unroll
+            for (int ks = 0; ks < S::KS3; ks++) o += PART[(ks * 32 + oc[r]) * NZ + oi];
+            const float wT = sig_wT * o + mu_wT;                                   // face oi + 1
+            const float below = __shfl_up(wT, 1);                                  // face oi
+            const float lo = oi == 0 ? 0.0f : below;
+            const float hi = oi == NZ - 1 ? tf[r] : wT;
+            if (col0 + oc[r] < n_col) out[(size_t)(col0 + oc[r]) * NZ + oi] = -(hi - lo) * inv_dz;
+        }
+        FC_BARRIER();                                                               // PART (= A1's rows) is rewritten by the next tile's first layer
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // adjoint: back-propagation through the stages from the taped relu (and switch) bits; fills the dz part of the delta-tape records.
 // RKC: the discrete adjoint of the RKC2 recurrence as in tile16's adjoint_kernel — cotangents of Y_j (lam), Y_{j-1}, Y_{j-2}, Y_0 and F_0
 // per state item — with ONE convective-adjustment switch pattern per step (that of Y_{s-1}, the first stage the backward sweep meets:
@@ -642,10 +727,24 @@ hipError_t fc_set_kernel_attributes() {
 #define FC_ATTR_F(N, T, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_forward_kernel<N, T, C, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<N>())) != hipSuccess) return e;
 #define FC_ATTR_A(N, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_adjoint_kernel<N, C, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_adj<N>())) != hipSuccess) return e;
     FC_FOR_EACH_FWD(FC_ATTR_F)
+    if ((e = hipFuncSetAttribute((const void*)(fc_infer_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<64>())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)(fc_infer_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<32>())) != hipSuccess) return e;
     FC_FOR_EACH_ADJ(FC_ATTR_A)
 #undef FC_ATTR_F
 #undef FC_ATTR_A
     return hipSuccess;
+}
+
+hipError_t fc_launch_infer(const DevModel& m, const float* imgf, const float* bias, const float* T, const float* top_flux, float inv_dz,
+                           float* out, int n_col, hipStream_t stream) {
+    if (n_col < 1) return hipErrorInvalidValue;
+    const int n_tiles = (n_col + 31) / 32;
+    const dim3 grid(n_tiles < 512 ? n_tiles : 512), block(256);                  // two workgroups per CU, each walking over its tiles
+    if (m.Nz == 64) hipLaunchKernelGGL(fc_infer_kernel<64>, grid, block, fc_lds_fwd<64>(), stream, imgf, bias, T, top_flux, m.mu_T, 1.0f / m.sig_T,
+                                       m.sig_wT, m.mu_wT, inv_dz, out, n_col);
+    else hipLaunchKernelGGL(fc_infer_kernel<32>, grid, block, fc_lds_fwd<32>(), stream, imgf, bias, T, top_flux, m.mu_T, 1.0f / m.sig_T, m.sig_wT,
+                            m.mu_wT, inv_dz, out, n_col);
+    return hipGetLastError();
 }
 
 hipError_t fc_launch_pack(const DevModel& m, const float* w, float* imgf, float* imgb, float* bias, hipStream_t stream) {

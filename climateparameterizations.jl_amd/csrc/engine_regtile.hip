@@ -640,8 +640,13 @@ __device__ __forceinline__ void rt_physics_vjp(const DevModel& m, const f32x16 (
 // 19.92 -> 19.66 ms, non-temporal delta-tape stores in the adjoint 64.1 -> 63.8 ms; the forward kernel's tape stores showed nothing either way
 // and stay default.
 #define RT_DMA_AUX 2                                   // aux of global_load_lds: 2 = nt
+#ifdef RT_PLAIN_TAPE_STORES      // A/B aid (round 3: in fc32 non-temporal tape STORES were the slower choice; here they are not — profiles/r03l_ab_regtile_nt.log)
+#define RT_NT_STORE4(p, v) (*reinterpret_cast<f32x4v*>(p) = (f32x4v)(v))
+#define RT_NT_STORE1(p, v) (*(float*)(p) = (float)(v))
+#else
 #define RT_NT_STORE4(p, v) __builtin_nontemporal_store((f32x4v)(v), reinterpret_cast<f32x4v*>(p))
 #define RT_NT_STORE1(p, v) __builtin_nontemporal_store((float)(v), (float*)(p))
+#endif
 #define RT_TAPE_LOAD4(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p))   // the adjoint's stage-input and Z1 tape loads: 63.75 -> 63.48 ms
 #define RT_TB (32 * 36)   // floats of a wave's transposition tile
 // λ in LDS, wave-private: element e of a lane at [e / 4][lane][e % 4] — four consecutive elements are one 16-byte access

@@ -169,3 +169,20 @@ def test_fc32_conv_adj_nde_rkc2_against_oracle_and_tile16(Nz, ncol, case):
     assert np.abs(sol_g - sol).max() < 5 * e32[0] + 2 * FC_SOL_ATOL
     assert abs(tot_g - tot) / abs(tot) < 5 * e32[1] + FC_LOSS_RTOL
     assert _rel(grad_g, g) < 5 * e32[2] + FC_GRAD_REL
+
+
+@pytest.mark.parametrize("nx,ny", [(1, 1), (16, 9), (33, 31), (256, 256)])
+def test_fc32_inference_forcing_against_oracle_and_tile16(nx, ny):
+    """`compute_neural_network_forcing!` (double_gyre_nn.jl:149-168; BASELINE configs[4]'s 256 x 256 grid included) on the fc32 sections: a
+    workgroup walks over 32-column tiles with the A-operand ring streaming across them; against the float64 oracle and against tile16."""
+    cfg, T, top, w = synthetic.inference_problem(nx, ny)
+    n = nx * ny
+    ref = O.infer_forcing(cfg, T[:4096], top[:4096], w, 1000.0)
+    res = {}
+    for eng in (0, ENGINE_TILE16):
+        with colnde.ColumnNDE(cfg, n, engine=eng) as nde:
+            assert nde.engine == (ENGINE_FC32 if eng == 0 else ENGINE_TILE16)
+            res[eng] = nde.infer_forcing(w, T, top, 1000.0)
+    _record("fc32/infer/%d" % n, rel=_rel(res[0][:4096], ref), rel_vs_tile16=_rel(res[0], res[ENGINE_TILE16].astype(np.float64)))
+    assert _rel(res[0][:4096], ref) < 2e-6
+    assert _rel(res[0], res[ENGINE_TILE16].astype(np.float64)) < 1e-6
