@@ -65,6 +65,8 @@ struct colnde_handle {
     unsigned int* d_fc_masks = nullptr;
     unsigned long long* d_fc_switch = nullptr;   // ConvectiveAdjustmentNDE: the taped switch patterns
     int fc_block = 0, fc_nblocks = 0, fc_rows = 0;   // gradient path: columns per pass (multiple of 32), passes, slab rows
+    int fc_seg = 0, fc_nseg = 0;                      // ... save intervals per time segment of the tapes, segments (1: the tapes hold the whole axis)
+    float* d_fc_lam = nullptr;                        // λ handed from one time segment to the one before it
     float* d_wimg = nullptr;
     float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_tapez = nullptr;
     bool rt_fwd32 = false;         // COLNDE_RT_FWD=32 at creation: the 32-column forward kernel (no Z1 tape)
@@ -481,7 +483,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
                     h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc,
-                    h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks, h->d_fc_switch};
+                    h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks, h->d_fc_switch, h->d_fc_lam};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -719,12 +721,17 @@ static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_
     return 0;
 }
 
-// fc32 forward solve of columns [c0, c0 + nc) (c0 a multiple of 32); with_tape: into the handle's (block) records and relu bits
-static int fc_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int c0, int nc) {
+// fc32 forward solve of columns [c0, c0 + nc) (c0 a multiple of 32) over the save intervals [iv0, iv1); with_tape: into the handle's records and
+// bits.  iv0 > 0 restarts from the state a previous (tape-less) pass saved in d_sol at save point iv0 — exact: the saved state is the stepper's.
+static int fc_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int c0, int nc, int iv0 = 0, int iv1 = -1, int tape_iv0 = -1) {
     const size_t ns = h->m.ns;
+    if (iv1 < 0) iv1 = h->cfg.n_save - 1;
+    if (tape_iv0 < 0) tape_iv0 = iv0;                // (a later tape_iv0: the tape-less pass of a segmented gradient tapes its last segment on the way)
+    const float* init = iv0 == 0 ? h->d_x0 + (size_t)c0 * ns : d_sol + ((size_t)c0 * h->cfg.n_save + iv0) * ns;
+    const size_t stride = iv0 == 0 ? ns : (size_t)h->cfg.n_save * ns;
     Timed tm(h, K_FORWARD);
-    hipError_t e = fc_launch_forward(h->m, h->d_fc_imgf, h->d_fc_bias, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times,
-                                     h->cfg.n_save, h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
+    hipError_t e = fc_launch_forward(h->m, h->d_fc_imgf, h->d_fc_bias, init, stride, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
+                                     iv0, iv1, tape_iv0, h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
                                      with_tape ? h->d_dwtape : nullptr, with_tape ? h->d_fc_masks : nullptr, with_tape ? h->d_fc_switch : nullptr, nc,
                                      h->stream);
     if (e != hipSuccess) return fail("fc32 forward launch failed: %s", hipGetErrorString(e));
@@ -847,51 +854,78 @@ static void build_dw_macros(colnde_handle* h, size_t n_rec, std::vector<DwMacro>
     h->dw_slices = (int)slices;
 }
 
-// fc32 gradient path: the records (forward: xs, a1, a2; adjoint: dz1, dz2, dz3) and the relu bits hold ONE block of columns (a multiple of
-// the 32-column tile); larger problems run forward -> adjoint -> dW GEMM block after block.  COLNDE_FC_BLOCK=<columns> forces a size.
+// fc32 gradient path: the records (forward: xs, a1, a2; adjoint: dz1, dz2, dz3) and the bit tapes.  When they do not fit in the free HBM for the
+// whole problem there are two ways to cut it:
+//   * column blocks (a multiple of the 32-column tile): forward -> adjoint -> dW GEMM block after block.  No extra work, but a block of fewer than
+//     16,384 columns leaves CUs with one workgroup or none (the kernels get their speed from two per CU);
+//   * time segments: ALL columns, the tapes hold `fc_seg` save intervals.  One tape-less forward pass first (it saves the state at every save
+//     point, and tapes the last segment on its way), then, from the last segment to the first, a taped forward restarted from the saved state,
+//     the adjoint over the segment (λ handed on through d_fc_lam) and the dW GEMM.  Costs (n_seg - 1)/n_seg of an extra forward solve, keeps every
+//     CU at two workgroups.
+// Blocks are used when they hold at least 16,384 columns (or everything), segments otherwise; COLNDE_FC_BLOCK=<columns> / COLNDE_FC_SEG=<intervals> force.
 static int fc_plan_tapes(colnde_handle* h) {
     if (h->d_dwtape) return 0;
     const DevModel& m = h->m;
-    const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
+    const int n_iv = h->cfg.n_save - 1;
     const size_t R = dwtape_row_floats(m);
     if (R != fc_record_row_floats(m.Nz)) return fail("fc32: record layout mismatch (%zu vs %zu floats per column)", R, fc_record_row_floats(m.Nz));
     const bool ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE;
-    const size_t per_col = (size_t)n_steps * m.nst * (R * sizeof(float) + fc_mask_words() * sizeof(unsigned int) / 32 + (ca ? sizeof(unsigned long long) : 0));
+    // bytes of tape per column and save interval
+    const size_t per_col_iv = (size_t)h->cfg.substeps * m.nst * (R * sizeof(float) + fc_mask_words() * sizeof(unsigned int) / 32 + (ca ? sizeof(unsigned long long) : 0));
     const int n32 = (h->n_col + 31) / 32 * 32;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const size_t margin = ((size_t)3 << 30) + (size_t)(n32 / 32 + 1024) * (m.n_params + 8) * sizeof(float);
-    const size_t fit = free_b > margin ? (free_b - margin) / per_col : 0;
-    int block = 0;
+    const size_t margin = ((size_t)3 << 30) + (size_t)(n32 / 32 * 8 + 4096) * (m.n_params + 8) * sizeof(float) + (size_t)n32 * m.Nz * sizeof(float);
+    const size_t budget = free_b > margin ? free_b - margin : 0;
+    const size_t fit = budget / (per_col_iv * n_iv);                 // columns whose whole-axis tapes fit
+    int block = 0, seg = n_iv;
     if (fit >= (size_t)n32) block = n32;
-    else if (fit >= 32) {
-        const int nb = (int)(((size_t)n32 + fit - 1) / fit);
-        block = ((n32 + nb - 1) / nb + 31) / 32 * 32;
-        if (block >= 8192) block = (block + 8191) / 8192 * 8192;       // whole rounds of one workgroup pair per CU
-        while ((size_t)block > fit) block -= block > 8192 ? 8192 : 32;
+    else {
+        if (fit >= 32) {
+            const int nb = (int)(((size_t)n32 + fit - 1) / fit);
+            block = ((n32 + nb - 1) / nb + 31) / 32 * 32;
+            if (block >= 8192) block = (block + 8191) / 8192 * 8192;       // whole rounds of one workgroup pair per CU
+            while ((size_t)block > fit) block -= block > 8192 ? 8192 : 32;
+        }
+        if (block < 16384) {
+            // time segments of all columns instead (or of the largest column block one interval fits for)
+            const size_t cols_iv = budget / per_col_iv / 32 * 32;     // columns whose ONE-interval tapes fit
+            if (cols_iv >= 32) {
+                block = (int)std::min<size_t>((size_t)n32, cols_iv);
+                if (block < n32 && block >= 8192) block = block / 8192 * 8192;
+                seg = (int)std::min<size_t>((size_t)n_iv, budget / (per_col_iv * (size_t)block));
+            }
+        }
     }
     const char* eb = getenv("COLNDE_FC_BLOCK");
-    if (eb && atoi(eb) >= 32) block = std::min(n32, (atoi(eb) / 32) * 32);
-    if (block < 32) return fail("fc32: the tapes of even one 32-column tile (%zu bytes) do not fit in the free device memory", 32 * per_col);
+    if (eb && atoi(eb) >= 32) { block = std::min(n32, (atoi(eb) / 32) * 32); if (!getenv("COLNDE_FC_SEG")) seg = n_iv; }
+    const char* es = getenv("COLNDE_FC_SEG");
+    if (es && atoi(es) >= 1) seg = std::min(n_iv, atoi(es));
+    if (block < 32 || seg < 1) return fail("fc32: the tapes of even one 32-column tile and one save interval (%zu bytes) do not fit in the free device memory", 32 * per_col_iv);
     h->fc_block = block;
     h->fc_nblocks = (n32 + block - 1) / block;
+    h->fc_seg = seg;
+    h->fc_nseg = (n_iv + seg - 1) / seg;
     const size_t tiles_b = (size_t)block / 32;
-    const size_t n_rec = tiles_b * 2 * n_steps * m.nst;
+    const size_t stage_recs = (size_t)seg * h->cfg.substeps * m.nst;          // (tile, stage) records per tile held by the tapes
+    const size_t n_rec = tiles_b * 2 * stage_recs;
     std::vector<DwMacro> mac;
     build_dw_macros(h, n_rec, mac);
-    h->fc_rows = n32 / 32 + h->fc_nblocks * h->dw_slices;
+    h->fc_rows = (n32 / 32) * h->fc_nseg + h->fc_nblocks * h->fc_nseg * h->dw_slices;
     const int stride = m.n_params + 8;
     hipError_t e = hipMalloc((void**)&h->d_dwtape, n_rec * CT * R * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_fc_masks, tiles_b * n_steps * m.nst * fc_mask_words() * sizeof(unsigned int));
-    if (e == hipSuccess && ca) e = hipMalloc((void**)&h->d_fc_switch, tiles_b * n_steps * m.nst * fc_switch_words() * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_fc_masks, tiles_b * stage_recs * fc_mask_words() * sizeof(unsigned int));
+    if (e == hipSuccess && ca) e = hipMalloc((void**)&h->d_fc_switch, tiles_b * stage_recs * fc_switch_words() * sizeof(unsigned long long));
+    if (e == hipSuccess && h->fc_nseg > 1) e = hipMalloc((void**)&h->d_fc_lam, (size_t)n32 * m.Nz * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_macros, mac.size() * sizeof(DwMacro));
     if (e == hipSuccess) e = hipMemcpy(h->d_macros, mac.data(), mac.size() * sizeof(DwMacro), hipMemcpyHostToDevice);
     if (e == hipSuccess && !h->d_slab) e = hipMalloc((void**)&h->d_slab, (size_t)h->fc_rows * stride * sizeof(float));
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        for (void** p : {(void**)&h->d_dwtape, (void**)&h->d_fc_masks, (void**)&h->d_fc_switch, (void**)&h->d_macros})
+        for (void** p : {(void**)&h->d_dwtape, (void**)&h->d_fc_masks, (void**)&h->d_fc_switch, (void**)&h->d_fc_lam, (void**)&h->d_macros})
             if (*p) { (void)hipFree(*p); *p = nullptr; }
-        return fail("fc32: hipMalloc of the tapes (%zu bytes for a block of %d columns) failed: %s", (size_t)block * per_col, block, hipGetErrorString(e));
+        return fail("fc32: hipMalloc of the tapes (%zu bytes for %d columns x %d save intervals) failed: %s", (size_t)block * per_col_iv * seg, block, seg,
+                    hipGetErrorString(e));
     }
     return 0;
 }
@@ -1048,29 +1082,36 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         if (fc_plan_tapes(h)) return 1;
         LossWeights lw;
         loss_weights(h, scalings, &lw);
-        const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
         const size_t ns = h->m.ns;
         hipError_t e = fc_launch_pack(h->m, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
         if (e != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(e));
         HIPCHK(hipMemsetAsync(h->d_slab, 0, (size_t)h->fc_rows * stride * sizeof(float), h->stream));
-        const int n_wg = (h->n_col + 31) / 32;
+        const int n_wg = (h->n_col + 31) / 32, n_iv = h->cfg.n_save - 1, nseg = h->fc_nseg;
+        const size_t gemm_rows0 = (size_t)n_wg * nseg;                      // slab: [tile][segment] adjoint rows, then [block][segment][slice] GEMM rows
         for (int b = 0; b < h->fc_nblocks; b++) {
             const int c0 = b * h->fc_block, nc = std::min(h->fc_block, h->n_col - c0);
             if (nc <= 0) break;
             const size_t tiles_b = ((size_t)nc + 31) / 32;
-            if (fc_forward_range(h, h->d_sol, true, c0, nc)) return 1;
-            {
-                Timed tm(h, K_ADJOINT);
-                e = fc_launch_adjoint(h->m, h->d_fc_imgb, h->d_times, h->cfg.n_save, h->cfg.substeps, h->d_sol + (size_t)c0 * h->cfg.n_save * ns,
-                                      h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_dwtape, h->d_fc_masks, h->d_fc_switch, lw.w[2],
-                                      h->d_slab + (size_t)(c0 / 32) * stride, nc, h->stream);
-                if (e != hipSuccess) return fail("fc32 adjoint launch failed: %s", hipGetErrorString(e));
-            }
-            {
-                Timed tm(h, K_DW1);
-                e = launch_dw_gemm(h->d_dwtape, tiles_b * 2 * n_steps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros, h->dw_slices,
-                                   h->d_slab + ((size_t)n_wg + (size_t)b * h->dw_slices) * stride, stride, h->stream);
-                if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
+            // time segments: the states at the save points first (tape-less), then segment by segment from the end of the axis
+            // (that first pass tapes the LAST segment on its way, which is the first one the backward sweep needs)
+            if (nseg > 1 && fc_forward_range(h, h->d_sol, true, c0, nc, 0, n_iv, (nseg - 1) * h->fc_seg)) return 1;
+            for (int sg = nseg - 1; sg >= 0; sg--) {
+                const int iv0 = sg * h->fc_seg, iv1 = std::min(n_iv, iv0 + h->fc_seg);
+                if (!(nseg > 1 && sg == nseg - 1) && fc_forward_range(h, h->d_sol, true, c0, nc, iv0, iv1)) return 1;
+                {
+                    Timed tm(h, K_ADJOINT);
+                    e = fc_launch_adjoint(h->m, h->d_fc_imgb, h->d_times, h->cfg.n_save, iv0, iv1, h->cfg.substeps, h->d_sol + (size_t)c0 * h->cfg.n_save * ns,
+                                          h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_dwtape, h->d_fc_masks, h->d_fc_switch, lw.w[2],
+                                          nseg > 1 ? h->d_fc_lam + (size_t)c0 * h->m.Nz : nullptr,
+                                          h->d_slab + ((size_t)sg * n_wg + (size_t)(c0 / 32)) * stride, nc, h->stream);
+                    if (e != hipSuccess) return fail("fc32 adjoint launch failed: %s", hipGetErrorString(e));
+                }
+                {
+                    Timed tm(h, K_DW1);
+                    e = launch_dw_gemm(h->d_dwtape, tiles_b * 2 * (size_t)(iv1 - iv0) * h->cfg.substeps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros,
+                                       h->n_macros, h->dw_slices, h->d_slab + (gemm_rows0 + ((size_t)b * nseg + sg) * h->dw_slices) * stride, stride, h->stream);
+                    if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
+                }
             }
         }
         {
@@ -1399,6 +1440,7 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
     if (h->use_fc) {
         info[1] = h->fc_block;
         info[2] = h->fc_nblocks;
+        info[3] = h->fc_nseg > 1 ? h->fc_nseg : 0;       // fc32: time segments of the tapes (0: the tapes hold the whole axis)
         info[4] = h->d_dwtape ? 1 : 0;
         info[5] = h->d_dwtape ? h->dw_slices : 0;
     } else if (h->use_rt) {

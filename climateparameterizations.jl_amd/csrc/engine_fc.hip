@@ -173,9 +173,14 @@ typedef unsigned long long u64;
 
 template <int NZ, bool TAPE, bool CA, bool RKC>
 __global__ void __launch_bounds__(256, 2)
-fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, const float* __restrict__ x0, const float* __restrict__ bcs,
-                  const float* __restrict__ save_times, int n_save, int substeps, float CN, float caKN, int nst, const float* __restrict__ rkc,
-                  float* __restrict__ sol, float* __restrict__ dwtape, u32* __restrict__ masks, u64* __restrict__ swtape, int n_col) {
+fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, const float* __restrict__ x0, size_t x0_stride,
+                  const float* __restrict__ bcs, const float* __restrict__ save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float CN,
+                  float caKN, int nst, const float* __restrict__ rkc, float* __restrict__ sol, float* __restrict__ dwtape, u32* __restrict__ masks,
+                  u64* __restrict__ swtape, int n_col) {
+    // Save intervals [iv_begin, iv_end) of the time axis, starting from x0 (column stride x0_stride: the initial state, or — a time SEGMENT
+    // of the gradient path — the state the tape-less pass saved at save point iv_begin; restarting there is exact: the saved state IS xn).
+    // Only the intervals from tape_iv0 on are taped (the records are numbered from its first step): the tape-less pass of a time-segmented
+    // gradient tapes its LAST segment on the way, which that segment's own pass would otherwise have to repeat.
     using S = Fc<NZ>;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
@@ -200,11 +205,11 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
 #pragma unroll
     for (int r = 0; r < S::OWN; r++) {
         const int col = min(col0 + oc[r], n_col - 1);
-        xn[r] = x0[(size_t)col * NZ + oi];
+        xn[r] = x0[(size_t)col * x0_stride + oi];
         bcb[r] = bcs[(size_t)col * 2];
         bct[r] = bcs[(size_t)col * 2 + 1];
         kv[r] = 0.0f;
-        if (sol && col0 + oc[r] < n_col) sol[((size_t)(col0 + oc[r]) * n_save) * NZ + oi] = xn[r];
+        if (sol && iv_begin == 0 && col0 + oc[r] < n_col) sol[((size_t)(col0 + oc[r]) * n_save) * NZ + oi] = xn[r];
     }
     const float b3v = oi < S::NO ? bias[2 * S::H + oi] : 0.0f;
     // every load issued so far is consumed HERE: a register still "in flight" at the loop header makes the wait-count pass put a
@@ -212,21 +217,24 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
 #pragma unroll
     for (int r = 0; r < S::OWN; r++) asm volatile("" :: "v"(xn[r]), "v"(bcb[r]), "v"(bct[r]));
     asm volatile("" :: "v"(b3v));
-    const int n_steps = (n_save - 1) * substeps;
+    const int n_steps = (iv_end - tape_iv0) * substeps;          // taped steps (and, x nst, records per tile) of this launch
+    const int step_t0 = (tape_iv0 - iv_begin) * substeps;         // first taped step
 
     // one right-hand-side evaluation: stage input vst[] (owner layout) -> kv[]; qi = record index step * nst + st
-    auto rhs = [&](int qi) {
+    auto rhs = [&](int qs) {
+        const int qi = qs - step_t0 * nst;
+        const bool tp = TAPE && qi >= 0;                              // wave-uniform
         int zero = 0;
         FC_OPAQUE_ZERO(zero);
         const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
         const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
-        float* rec = TAPE ? dwtape + ri * ((size_t)32 * S::R) : nullptr;
-        u32* mrec = TAPE ? masks + ri * 512 + w * 64 + lane : nullptr;
+        float* rec = tp ? dwtape + ri * ((size_t)32 * S::R) : nullptr;
+        u32* mrec = tp ? masks + ri * 512 + w * 64 + lane : nullptr;
         // ---- stage input (owner layout) -> LDS rows, tape
 #pragma unroll
         for (int r = 0; r < S::OWN; r++) {
             X[oc[r] * S::LDX + oi] = vst[r];
-            if (TAPE) FC_STORE(vst[r], rec + (size_t)oc[r] * S::R + oi);
+            if (tp) FC_STORE(vst[r], rec + (size_t)oc[r] * S::R + oi);
         }
         FC_BARRIER();
         // ---- hidden layers: z = W a + b on 32x32x2 MFMA, relu, rows to LDS (next layer's B operand) and to the tape
@@ -246,7 +254,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
                 }
                 const int f = mt * 32 + 8 * q + 4 * h;
                 *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + f) = a;
-                if (TAPE) FC_STORE(a, reinterpret_cast<f32x4*>(rec + (size_t)n * S::R + NZ + (l - 1) * S::H + f));
+                if (tp) FC_STORE(a, reinterpret_cast<f32x4*>(rec + (size_t)n * S::R + NZ + (l - 1) * S::H + f));
             }
             return bits;
         };
@@ -254,14 +262,14 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
             u32 mb = 0;
             fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h,
                                               [&](int j, const fc16& acc) { mb |= hidden(1, A1, j, acc) << (16 * j); });
-            if (TAPE) FC_STORE(mb, mrec);
+            if (tp) FC_STORE(mb, mrec);
         }
         FC_BARRIER();
         {
             u32 mb = 0;
             fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h,
                                                            [&](int j, const fc16& acc) { mb |= hidden(2, A2, j, acc) << (16 * j); });
-            if (TAPE) FC_STORE(mb, mrec + 256);
+            if (tp) FC_STORE(mb, mrec + 256);
         }
         FC_BARRIER();
         // ---- output layer: row tile w % MT3, K part w / MT3; partial sums to LDS
@@ -292,7 +300,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
                 if (oi >= 1) wlo -= fminf(0.0f, caKN * (vst[r] - vlo));
                 if (oi <= NZ - 2) whi -= fminf(0.0f, caKN * (vhi - vst[r]));
                 (void)ghi;
-                if (TAPE) {
+                if (tp) {
                     // the switch pattern of the stage, one bit per face, for the pullback
                     const u64 bal = __ballot(on);
                     const u64 mine = NZ == 64 ? bal : (lane < 32 ? (bal & 0xffffffffull) : (bal >> 32));
@@ -308,7 +316,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
         float ac[S::OWN];
 #pragma unroll
         for (int r = 0; r < S::OWN; r++) ac[r] = 0.0f;
-        for (int iv = 0; iv < n_save - 1; iv++) {
+        for (int iv = iv_begin; iv < iv_end; iv++) {
             const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
             for (int s = 0; s < substeps; s++, step++) {
 #pragma nounroll
@@ -342,7 +350,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
         float ym1[S::OWN], ym2[S::OWN], f0[S::OWN];
 #pragma unroll
         for (int r = 0; r < S::OWN; r++) { ym1[r] = 0.0f; ym2[r] = 0.0f; f0[r] = 0.0f; }
-        for (int iv = 0; iv < n_save - 1; iv++) {
+        for (int iv = iv_begin; iv < iv_end; iv++) {
             const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
             for (int s = 0; s < substeps; s++, step++) {
 #pragma nounroll
@@ -472,9 +480,12 @@ struct FcGrad { int b[3]; int n_params; };
 
 template <int NZ, bool CA, bool RKC>
 __global__ void __launch_bounds__(256, 2)
-fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save_times, int n_save, int substeps, float CN, float caKN, int nst,
-                  const float* __restrict__ rkc, const float* __restrict__ sol, const float* __restrict__ truth, float* __restrict__ dwtape,
-                  const u32* __restrict__ masks, const u64* __restrict__ swtape, float w_loss, float* __restrict__ slab, FcGrad go, int n_col) {
+fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save_times, int n_save, int iv_begin, int iv_end, int substeps, float CN,
+                  float caKN, int nst, const float* __restrict__ rkc, const float* __restrict__ sol, const float* __restrict__ truth,
+                  float* __restrict__ dwtape, const u32* __restrict__ masks, const u64* __restrict__ swtape, float w_loss, float* __restrict__ lam_io,
+                  float* __restrict__ slab, FcGrad go, int n_col) {
+    // Save intervals [iv_begin, iv_end), backwards.  lam_io [columns][NZ] (or null: one launch covers the axis) carries λ from one time
+    // segment to the one before it: read unless this is the last segment of the axis, written unless it is the first.
     using S = Fc<NZ>;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
@@ -500,13 +511,14 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
 #pragma unroll
     for (int r = 0; r < S::OWN; r++) {
         lam[r] = 0.0f; xb[r] = 0.0f; db3[r] = 0.0f; kb[r] = 0.0f;
-        if (col0 + oc[r] < n_col) {                                 // save point 0 enters the loss value only
+        if (lam_io && iv_end < n_save - 1) lam[r] = lam_io[(size_t)(col0 + oc[r]) * NZ + oi];
+        if (iv_begin == 0 && col0 + oc[r] < n_col) {                // save point 0 enters the loss value only
             const size_t q = ((size_t)(col0 + oc[r]) * n_save) * NZ + oi;
             const float d = sol[q] - truth[q];
             sumsq += d * d;
         }
     }
-    const int n_steps = (n_save - 1) * substeps;
+    const int n_steps = (iv_end - iv_begin) * substeps;          // steps (and, x nst, records per tile) of this launch
 
     // pullback of one right-hand-side evaluation: stage cotangent kb[] (owner layout) -> xb[] = J(Y)ᵀ kb; qi = record index
     auto pull = [&](int qi) {
@@ -604,7 +616,7 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
     float xbs[S::OWN], yb1[S::OWN], yb2[S::OWN], yb0[S::OWN], f0b[S::OWN];
 #pragma unroll
     for (int r = 0; r < S::OWN; r++) { xbs[r] = 0.0f; yb1[r] = 0.0f; yb2[r] = 0.0f; yb0[r] = 0.0f; f0b[r] = 0.0f; }
-    for (int iv = n_save - 2; iv >= 0; iv--) {
+    for (int iv = iv_end - 1; iv >= iv_begin; iv--) {
         const float dt = (save_times[iv + 1] - save_times[iv]) / (float)substeps;
         // λ += ∂loss/∂sol[:, iv+1]   (nde_loss = Flux.mse over every (level, save point, simulation): training.jl:55-62)
 #pragma unroll
@@ -616,7 +628,7 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
                 lam[r] += 2.0f * w_loss * d;
             }
         for (int s = substeps - 1; s >= 0; s--) {
-            const int step = iv * substeps + s;
+            const int step = (iv - iv_begin) * substeps + s;
             if constexpr (!RKC) {
 #pragma unroll
                 for (int r = 0; r < S::OWN; r++) xbs[r] = 0.0f;
@@ -674,6 +686,9 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
             }
         }
     }
+    if (lam_io && iv_begin > 0)
+#pragma unroll
+        for (int r = 0; r < S::OWN; r++) lam_io[(size_t)(col0 + oc[r]) * NZ + oi] = lam[r];
     // ---- flush: bias gradients and the loss sum into this workgroup's slab row (weight gradients come from the dW GEMM)
     FC_BARRIER();
     float* out = slab + (size_t)blockIdx.x * (go.n_params + 8);
@@ -755,10 +770,10 @@ hipError_t fc_launch_pack(const DevModel& m, const float* w, float* imgf, float*
     return hipGetLastError();
 }
 
-hipError_t fc_launch_forward(const DevModel& m, const float* imgf, const float* bias, const float* x0, const float* bcs, const float* save_times,
-                             int n_save, int substeps, float* sol, float* dwtape, unsigned int* masks, unsigned long long* swtape, int n_col,
-                             hipStream_t stream) {
-    if (n_col < 1) return hipErrorInvalidValue;
+hipError_t fc_launch_forward(const DevModel& m, const float* imgf, const float* bias, const float* x0, size_t x0_stride, const float* bcs,
+                             const float* save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float* sol, float* dwtape,
+                             unsigned int* masks, unsigned long long* swtape, int n_col, hipStream_t stream) {
+    if (n_col < 1 || iv_begin < 0 || iv_end > n_save - 1 || iv_begin >= iv_end || tape_iv0 < iv_begin || tape_iv0 >= iv_end) return hipErrorInvalidValue;
     const dim3 grid((n_col + 31) / 32), block(256);
     const float CN = m.C_fc * (float)m.Nz, caKN = m.ca_K * (float)m.Nz;
     const bool tape = dwtape != nullptr, ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE, rk = m.rkc != nullptr;
@@ -767,8 +782,8 @@ hipError_t fc_launch_forward(const DevModel& m, const float* imgf, const float* 
     bool launched = false;
 #define FC_FWD(N, T, C, K)                                                                                                                        \
     if (!launched && m.Nz == N && tape == T && ca == C && rk == K) {                                                                              \
-        hipLaunchKernelGGL((fc_forward_kernel<N, T, C, K>), grid, block, fc_lds_fwd<N>(), stream, imgf, bias, x0, bcs, save_times, n_save, substeps, \
-                           CN, caKN, m.nst, m.rkc, sol, dwtape, masks, swtape, n_col);                                                            \
+        hipLaunchKernelGGL((fc_forward_kernel<N, T, C, K>), grid, block, fc_lds_fwd<N>(), stream, imgf, bias, x0, x0_stride, bcs, save_times, n_save, \
+                           iv_begin, iv_end, tape_iv0, substeps, CN, caKN, m.nst, m.rkc, sol, dwtape, masks, swtape, n_col);                      \
         launched = true;                                                                                                                          \
     }
     FC_FOR_EACH_FWD(FC_FWD)
@@ -776,10 +791,11 @@ hipError_t fc_launch_forward(const DevModel& m, const float* imgf, const float* 
     return launched ? hipGetLastError() : hipErrorInvalidValue;
 }
 
-hipError_t fc_launch_adjoint(const DevModel& m, const float* imgb, const float* save_times, int n_save, int substeps, const float* sol,
-                             const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape, float w_loss,
-                             float* slab, int n_col, hipStream_t stream) {
-    if (n_col < 1 || !dwtape || !masks) return hipErrorInvalidValue;
+hipError_t fc_launch_adjoint(const DevModel& m, const float* imgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
+                             const float* sol, const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape,
+                             float w_loss, float* lam_io, float* slab, int n_col, hipStream_t stream) {
+    if (n_col < 1 || !dwtape || !masks || iv_begin < 0 || iv_end > n_save - 1 || iv_begin >= iv_end) return hipErrorInvalidValue;
+    if ((iv_begin > 0 || iv_end < n_save - 1) && !lam_io) return hipErrorInvalidValue;
     const dim3 grid((n_col + 31) / 32), block(256);
     const float CN = m.C_fc * (float)m.Nz, caKN = m.ca_K * (float)m.Nz;
     const bool ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE, rk = m.rkc != nullptr;
@@ -790,8 +806,8 @@ hipError_t fc_launch_adjoint(const DevModel& m, const float* imgb, const float* 
     bool launched = false;
 #define FC_ADJ(N, C, K)                                                                                                                           \
     if (!launched && m.Nz == N && ca == C && rk == K) {                                                                                           \
-        hipLaunchKernelGGL((fc_adjoint_kernel<N, C, K>), grid, block, fc_lds_adj<N>(), stream, imgb, save_times, n_save, substeps, CN, caKN, m.nst, \
-                           m.rkc, sol, truth, dwtape, masks, swtape, w_loss, slab, go, n_col);                                                    \
+        hipLaunchKernelGGL((fc_adjoint_kernel<N, C, K>), grid, block, fc_lds_adj<N>(), stream, imgb, save_times, n_save, iv_begin, iv_end, substeps, \
+                           CN, caKN, m.nst, m.rkc, sol, truth, dwtape, masks, swtape, w_loss, lam_io, slab, go, n_col);                           \
         launched = true;                                                                                                                          \
     }
     FC_FOR_EACH_ADJ(FC_ADJ)

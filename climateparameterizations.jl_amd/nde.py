@@ -111,7 +111,8 @@ class ColumnNDE:
         """How the gradient path runs (valid after the first loss_grad): engine, column blocks, which tapes are in use."""
         info = (ctypes.c_int * 8)()
         _lib.check(self._L.colnde_plan(self._h, info))
-        return dict(engine=info[0], block_columns=info[1], n_blocks=info[2], z1_taped=bool(info[3]),
+        return dict(engine=info[0], block_columns=info[1], n_blocks=info[2], z1_taped=bool(info[3]) and info[0] == ENGINE_REGTILE,
+                    time_segments=info[3] if info[0] == ENGINE_FC32 else 0,
                     dw_taped=bool(info[4]), dw_slices=info[5], split_forward=bool(info[6] & 1), split_adjoint=bool(info[6] & 2), split_rich_tape=bool(info[6] & 4),
                     approximate_gradient=bool(info[7] & 1))
 

@@ -235,7 +235,7 @@ int  colnde_allreduce_result_dev(colnde_handle* h, colnde_comm* comm, float* d_o
 
 /* How the handle runs its gradient path (filled in by the first colnde_loss_grad[_dev]; zeros before that):
  * info[0] engine (COLNDE_ENGINE_*), [1] columns per block of the gradient path (the tapes hold one block), [2] number of blocks, [3] regtile: layer-1
- * pre-activations taped (1) or recomputed (0), [4] tile16: weight gradients taped (1) or accumulated in registers (0),
+ * pre-activations taped (1) or recomputed (0); fc32: number of time segments the tapes are cut into (0: they hold the whole axis), [4] tile16: weight gradients taped (1) or accumulated in registers (0),
  * [5] tile16 taped mode: K-slices of the dW GEMM, [6] net-split kernels of the latency points (per 16-column tile one wavefront per flux net
  * plus a helper wavefront): bit 0 = forward solve, bit 1 = adjoint, bit 2 = with the rich tape (activations, their derivatives and the physics-pullback
  * coefficients taped by the forward kernel: blocks of at most 2,048 columns), [7] bit 0 = the gradient is the one-switch-pattern

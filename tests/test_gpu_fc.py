@@ -186,3 +186,41 @@ def test_fc32_inference_forcing_against_oracle_and_tile16(nx, ny):
     _record("fc32/infer/%d" % n, rel=_rel(res[0][:4096], ref), rel_vs_tile16=_rel(res[0], res[ENGINE_TILE16].astype(np.float64)))
     assert _rel(res[0][:4096], ref) < 2e-6
     assert _rel(res[0], res[ENGINE_TILE16].astype(np.float64)) < 1e-6
+
+
+@pytest.mark.parametrize("model,seg,block", [("fc", 3, None), ("fc", 1, None), ("ca_rk4", 2, None), ("ca_rkc2", 3, None), ("fc", 2, 32)])
+def test_fc32_time_segmented_tapes_equal_the_single_pass(model, seg, block, monkeypatch):
+    """When the tapes of all columns do not fit, fc32 cuts the TIME axis instead of the columns (every CU keeps its two workgroups): a tape-less
+    forward pass saves the states at the save points, then each segment — from the last to the first — is re-run with tapes from its saved state,
+    back-propagated (λ handed on through a device buffer) and contracted.  Restarting at a save point is exact, so the segmented gradient must
+    equal the single-pass one to summation order, for every stepper and with column blocks on top (COLNDE_FC_SEG / COLNDE_FC_BLOCK force the cuts)."""
+    ca = model != "fc"
+    p = synthetic.free_convection_problem(75, Nz=32, n_save=8, substeps=24 if model == "ca_rk4" else 2, convective_adjustment=ca, t_end=0.02)
+    cfg = p.cfg.with_(stepper="rkc2") if model == "ca_rkc2" else p.cfg
+    x0 = p.x0.copy()
+    if ca:
+        x0[:, 14:20] = x0[:, 14:20][:, ::-1]
+    truth = O.solve(cfg, x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(cfg)
+    tot, terms, g, sol = O.loss_and_grad(cfg, x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(cfg, 75) as nde:
+        nde.set_problem(x0, p.bcs, truth)
+        one = nde.loss_grad(p.weights, sc)
+        assert nde.plan()["time_segments"] == 0
+    monkeypatch.setenv("COLNDE_FC_SEG", str(seg))
+    if block:
+        monkeypatch.setenv("COLNDE_FC_BLOCK", str(block))
+    with colnde.ColumnNDE(cfg, 75) as nde:
+        nde.set_problem(x0, p.bcs, truth)
+        cut = nde.loss_grad(p.weights, sc)
+        again = nde.loss_grad(p.weights, sc)
+        plan = nde.plan()
+    assert plan["time_segments"] == -(-7 // seg) and plan["n_blocks"] == (3 if block else 1)
+    assert again[0] == cut[0] and np.array_equal(again[2], cut[2])
+    _record("fc32/segments/%s/%d" % (model, seg), loss_rel_vs_single=abs(cut[0] - one[0]) / abs(one[0]), grad_rel_vs_single=_rel(cut[2], one[2].astype(np.float64)),
+            grad_rel=_rel(cut[2], g))
+    assert np.isclose(cut[0], one[0], rtol=2e-6)
+    np.testing.assert_allclose(cut[1], one[1], rtol=2e-6, atol=1e-12)
+    assert _rel(cut[2], one[2].astype(np.float64)) < 2e-6
+    if not ca:
+        assert np.isclose(cut[0], tot, rtol=FC_LOSS_RTOL) and _rel(cut[2], g) < FC_GRAD_REL
