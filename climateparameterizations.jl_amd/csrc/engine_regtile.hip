@@ -1746,7 +1746,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 // The same solve with a FOURTH wavefront (the workgroup's idle SIMD) as helper: it evaluates the Richardson-number closure of all three variables
 // once per stage — the diffusive face fluxes go to LDS, the rich tape's nine pullback coefficients to HBM — while the three net waves run their
 // chains; a second bare barrier per stage (B) hands the fluxes over.  Every wave executes exactly the barriers (B) and (A) in every stage.
-template <int ACT, bool RICH>
+template <int ACT, bool RICH, bool RKC = false>
 __global__ void __launch_bounds__(256)
 rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
                      const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
@@ -1803,9 +1803,9 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
         for (int tau = 0; tau < 2; tau++) *reinterpret_cast<f32x4v*>(sol + ((size_t)col * n_save) * 96 + n * 32 + 16 * tau + 4 * g) = Xn.t[tau];
     const int n_steps = (n_save - 1) * substeps;
     // stepper: classical RK4 (nst = 4) or the s-stage RKC2 step of colnde_dev.h (m.rkc: coefficient table; increment form as in tile16's
-    // forward_kernel) — a wave-uniform run-time switch: the bookkeeping is a handful of vector operations per stage
-    const int nst = m.nst;
-    const bool rkc = m.rkc != nullptr;
+    // forward_kernel) — a template parameter: as a run-time switch it cost the RK4 latency kernels 8 % (8 simulations: 16.6 -> 18.2 ms)
+    const int nst = RKC ? m.nst : 4;
+    constexpr bool rkc = RKC;
     const float* mu_t = m.rkc, *nu_t = m.rkc + RKC_LD, *mut_t = m.rkc + 2 * RKC_LD, *gat_t = m.rkc + 3 * RKC_LD, *c_t = m.rkc + 4 * RKC_LD;
     float* tp = t16_tape ? t16_tape + (size_t)tile * n_steps * nst * 1536 + j * 96 + n * 32 + 4 * g : nullptr;
     float* tz = (t16_ztape && !RICH) ? t16_ztape + (size_t)tile * n_steps * nst * (16 * 216) + j * 216 + n * 72 + g : nullptr;
@@ -2567,7 +2567,7 @@ rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 // parts into x̄.  While the helper works (between A and B) the net waves do what depends on the tapes alone: next stage's prefetch, this
 // stage's activations, the record's x and a parts.  Every wave executes exactly the barriers B and A in every stage.
 // ------------------------------------------------------------------------------------------------
-template <int ACT, bool RICH>
+template <int ACT, bool RICH, bool RKC = false>
 __global__ void __launch_bounds__(256)
 rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ save_times, int n_save, int substeps,
                       const float* __restrict__ sol, const float* __restrict__ truth, const float* __restrict__ t16_tape,
@@ -2591,8 +2591,8 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
     const bool valid = col < n_col;
     const int colc = min(col, n_col - 1);
     const int n_steps = (n_save - 1) * substeps;
-    const int nst = m.nst;                                              // RHS evaluations (= tape records) per step: 4 (RK4) or s (RKC2)
-    const bool rkc = m.rkc != nullptr;
+    const int nst = RKC ? m.nst : 4;                                    // RHS evaluations (= tape records) per step: 4 (RK4) or s (RKC2)
+    constexpr bool rkc = RKC;
     const float* tp = t16_tape + (size_t)tile * n_steps * nst * 1536 + j * 96 + 4 * g;
     const bool phys = m.mpp || m.ca;
     float* out = slab + (size_t)tile * (m.n_params + 8);
@@ -2994,52 +2994,76 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_IDENTITY, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true, true>));
     RT_SETATTR(rt_dw1_kernel);
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -3117,7 +3141,9 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
     if (m.nst != 4 && !(m.rkc && use_helper)) return hipErrorInvalidValue;      // RKC2 lives in the four-wave kernels only
 #define RT_FWDS(A)                                                                                                                              \
     do {                                                                                                                                        \
-        if (use_helper && rich) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        if (use_helper && rich && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else if (use_helper && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else if (use_helper && rich) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else if (use_helper) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else if (rich) hipLaunchKernelGGL((rt16s_forward_kernel<A, true>), grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else hipLaunchKernelGGL((rt16s_forward_kernel<A, false>), grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
@@ -3147,7 +3173,9 @@ hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const f
     const dim3 blockh(256);
 #define RT_ADJS(A)                                                                                                                              \
     do {                                                                                                                                        \
-        if (use_helper && rich) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        if (use_helper && rich && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else if (use_helper && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else if (use_helper && rich) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else if (use_helper) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else if (rich) hipLaunchKernelGGL((rt16s_adjoint_kernel<A, true>), grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else hipLaunchKernelGGL((rt16s_adjoint_kernel<A, false>), grid, block, lds, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \

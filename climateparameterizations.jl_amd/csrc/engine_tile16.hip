@@ -1355,13 +1355,18 @@ dw_gemm_kernel(const float* __restrict__ dwtape, size_t n_records, int R, const 
 #define DW_MAXM 3          // blocks per wave: 3 x 64 accumulator registers leave room for two waves per SIMD
 #define DW_NW 8            // waves per workgroup
 
-template <int MAXM, int NW>
+// Round 3: (a) the operands of k-step t + 1 are read from LDS BEFORE the four MFMAs of step t are issued (the straight compiler schedule
+// issued eight reads after each eight MFMAs and waited for them with the pipe draining: 72 % busy, profiles/r03g_cs_table.csv); (b) MAXM is a
+// template parameter chosen from the number of blocks (a 32-level network has 8: one per wave, not three slots of which two are empty);
+// (c) small records are staged RPB at a time, so that a barrier closes at least ~6 k cycles of MFMA work.
+template <int MAXM, int NW, int RPB>
 __global__ void __launch_bounds__(64 * NW)
 dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, const DwMacro* __restrict__ macros, int n_macros,
                    int n_slices, float* __restrict__ slab_rows, int stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slice = blockIdx.x;
     const int rec_floats = CT * R;                       // multiple of 4 (checked by the host)
+    const int stage_floats = RPB * rec_floats;           // one LDS buffer: RPB consecutive records
     const size_t per = (n_records + n_slices - 1) / n_slices;
     const size_t r0 = (size_t)slice * per, r1 = r0 + per < n_records ? r0 + per : n_records;
     const int f = lane & 31, kk = lane >> 5;
@@ -1380,37 +1385,51 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[q][t] = (dwf32x16)(0.0f);
     }
-    // asynchronous copy of one record into an LDS buffer: 1 KB per wave instruction, lanes contiguous
+    // asynchronous copy of up to RPB records into an LDS buffer: 1 KB per wave instruction, lanes contiguous
     auto fetch = [&](size_t r, int dst /* float offset of the buffer inside smem */) {
+        const size_t nrec = r1 - r < (size_t)RPB ? r1 - r : (size_t)RPB;
+        const int nfl = (int)nrec * rec_floats;
         const float* src = dwtape + r * (size_t)rec_floats;
-        for (int o = wave * 256; o < rec_floats; o += NW * 256) {
-            if (o + lane * 4 < rec_floats)
+        for (int o = wave * 256; o < nfl; o += NW * 256) {
+            if (o + lane * 4 < nfl)
                 __builtin_amdgcn_global_load_lds(src + o + lane * 4, smem + dst + o, 16, 0, 0);
         }
     };
     if (r0 < r1) fetch(r0, 0);
     __syncthreads();
     int cur = 0;                                         // float offset of the buffer being contracted
-    for (size_t r = r0; r < r1; r++) {
-        if (r + 1 < r1) fetch(r + 1, rec_floats - cur);
-        const float* rec = smem + cur;
-        // straight-line: all four 32x32 tiles of every block are issued (blocks narrower than 64 read clamped, in-range
-        // features whose products are never stored) so that the operand reads of later k-steps pipeline under the MFMAs
+    for (size_t r = r0; r < r1; r += RPB) {
+        if (r + RPB < r1) fetch(r + RPB, stage_floats - cur);
+        const int nv = (int)(r1 - r < (size_t)RPB ? r1 - r : (size_t)RPB);
 #pragma unroll
-        for (int q = 0; q < MAXM; q++) {
-            if (mc[q].ni_rem == 0) continue;          // empty slot of this wave (wave-uniform)
+        for (int rr = 0; rr < RPB; rr++) {
+            if (rr >= nv) break;                         // wave-uniform: the last stage of a slice may hold fewer records
+            const float* rec = smem + cur + rr * rec_floats;
+            // straight-line over the wave's MAXM blocks x 8 k-steps (2 columns each); all four 32x32 tiles of a block are issued (a block
+            // narrower than 64 reads clamped, in-range features whose products are never stored; an empty slot likewise)
+            constexpr int T = MAXM * 8;
+            float op[2][4];
+            auto load = [&](int t, float (&o)[4]) {
+                const int q = t >> 3, sgrp = t & 7;
+                const float* row = rec + 2 * sgrp * R;
+                o[0] = row[fa0[q]]; o[1] = row[fd0[q]]; o[2] = row[fa1[q]]; o[3] = row[fd1[q]];
+            };
+            load(0, op[0]);
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const float* row = rec + 2 * s * R;
-                const float a0 = row[fa0[q]], d0 = row[fd0[q]], a1 = row[fa1[q]], d1 = row[fd1[q]];
+            for (int t = 0; t < T; t++) {
+                if (t + 1 < T) load(t + 1, op[(t + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int q = t >> 3;
+                const float a0 = op[t & 1][0], d0 = op[t & 1][1], a1 = op[t & 1][2], d1 = op[t & 1][3];
                 acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d0, acc[q][0], 0, 0, 0);
                 acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d1, acc[q][1], 0, 0, 0);
                 acc[q][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d0, acc[q][2], 0, 0, 0);
                 acc[q][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d1, acc[q][3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();          // every wave is done with this buffer, and (vmcnt drain) the next record has landed
-        cur = rec_floats - cur;
+        __syncthreads();          // every wave is done with this buffer, and (vmcnt drain) the next stage has landed
+        cur = stage_floats - cur;
     }
 #pragma unroll
     for (int q = 0; q < MAXM; q++) {
@@ -1433,12 +1452,24 @@ bool dw_gemm_lds_fits(int row_floats, int n_macros) {
     return n_macros <= DW_NW * DW_MAXM && ((CT * row_floats) & 3) == 0 && (size_t)2 * CT * row_floats * sizeof(float) <= 160 * 1024;
 }
 
+// records staged per LDS buffer: as many as fit in half the LDS, at most 4
+static int dw_gemm_rpb(int row_floats) {
+    const size_t rec = (size_t)CT * row_floats * sizeof(float);
+    const size_t n = (80 * 1024) / rec;
+    return n >= 4 ? 4 : (n >= 2 ? 2 : 1);
+}
+
 hipError_t launch_dw_gemm(const float* dwtape, size_t n_records, int row_floats, const DwMacro* macros, int n_macros, int n_slices,
                           float* slab_rows, int slab_stride, hipStream_t stream) {
     if (dw_gemm_lds_fits(row_floats, n_macros)) {
         if (n_records == 0 || n_slices < 1) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((dw_gemm_lds_kernel<DW_MAXM, DW_NW>), dim3(n_slices), dim3(64 * DW_NW), (size_t)2 * CT * row_floats * sizeof(float), stream, dwtape,
-                           n_records, row_floats, macros, n_macros, n_slices, slab_rows, slab_stride);
+        const int maxm = (n_macros + DW_NW - 1) / DW_NW, rpb = dw_gemm_rpb(row_floats);
+        const size_t lds = (size_t)2 * rpb * CT * row_floats * sizeof(float);
+#define DW_LAUNCH(M, P) hipLaunchKernelGGL((dw_gemm_lds_kernel<M, DW_NW, P>), dim3(n_slices), dim3(64 * DW_NW), lds, stream, dwtape, n_records, row_floats, macros, n_macros, n_slices, slab_rows, slab_stride)
+        if (maxm == 1) { if (rpb == 4) DW_LAUNCH(1, 4); else if (rpb == 2) DW_LAUNCH(1, 2); else DW_LAUNCH(1, 1); }
+        else if (maxm == 2) { if (rpb == 4) DW_LAUNCH(2, 4); else if (rpb == 2) DW_LAUNCH(2, 2); else DW_LAUNCH(2, 1); }
+        else { if (rpb == 4) DW_LAUNCH(3, 4); else if (rpb == 2) DW_LAUNCH(3, 2); else DW_LAUNCH(3, 1); }
+#undef DW_LAUNCH
         return hipGetLastError();
     }
     if (n_records == 0 || n_macros < 1 || n_slices < 8 || (n_slices & 7)) return hipErrorInvalidValue;
@@ -1704,7 +1735,9 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     SETATTR((adjoint_kernel<1, 1024, 2, false, true, true>));
     SETATTR((adjoint_kernel<1, 1024, 2, true, true, false>));
     SETATTR((adjoint_kernel<1, 1024, 2, true, true, true>));
-    SETATTR((dw_gemm_lds_kernel<DW_MAXM, DW_NW>));
+    SETATTR((dw_gemm_lds_kernel<1, DW_NW, 1>)); SETATTR((dw_gemm_lds_kernel<1, DW_NW, 2>)); SETATTR((dw_gemm_lds_kernel<1, DW_NW, 4>));
+    SETATTR((dw_gemm_lds_kernel<2, DW_NW, 1>)); SETATTR((dw_gemm_lds_kernel<2, DW_NW, 2>)); SETATTR((dw_gemm_lds_kernel<2, DW_NW, 4>));
+    SETATTR((dw_gemm_lds_kernel<3, DW_NW, 1>)); SETATTR((dw_gemm_lds_kernel<3, DW_NW, 2>)); SETATTR((dw_gemm_lds_kernel<3, DW_NW, 4>));
 #undef SETATTR
     return hipSuccess;
 }
