@@ -9,34 +9,50 @@
 // c = Δt/Δz².  L is strictly diagonally dominant by rows and columns, so the reference's pivoted LU (`Tridiagonal \`)
 // never pivots and the Thomas recurrence below is the same elimination.
 //
-// HBM-bound (2·4·Nz bytes per column, ~8 flop per level).  A workgroup of 256 threads stages 256 columns through LDS with
-// coalesced float4 traffic (rows padded to NZ+1 floats: conflict-free per-thread column walks), one thread solves one column.
+// HBM-bound (2·4·Nz bytes per column, ~8 flop per level).  A workgroup stages its columns through LDS with coalesced float4 traffic
+// (rows padded to NZ+1 floats: conflict-free per-thread column walks), one thread solves one column.
 // ------------------------------------------------------------------------------------------------
+// Round 3: ONE WAVE per workgroup (64 columns, 8.4 KB of LDS at Nz = 32) instead of four — what took the three-field kernel below to 70 % of the
+// HBM peak: many small workgroups per CU are in different phases, one's solve hides under the others' float4 traffic (256-thread workgroups: 4.6–4.9 TB/s).
 template <int NZ>
-__global__ void __launch_bounds__(256) convadj_kernel(const float* __restrict__ T, const float* __restrict__ halo_bottom,
-                                                      const float* __restrict__ halo_top, float c, float K, float* __restrict__ out, int n_col) {
+__global__ void __launch_bounds__(64) convadj_kernel(const float* T, const float* __restrict__ halo_bottom,
+                                                     const float* __restrict__ halo_top, float c, float K, float* out, int n_col) {
     extern __shared__ float cs_smem[];
-    constexpr int LD = NZ + 1;
-    const int col0 = blockIdx.x * 256;
-    const int ncol = min(256, n_col - col0);
-    const float4* src = reinterpret_cast<const float4*>(T + (size_t)col0 * NZ);
-    for (int e = threadIdx.x; e < ncol * (NZ / 4); e += 256) {
-        const float4 v = src[e];
-        const int cl = e / (NZ / 4), k = (e % (NZ / 4)) * 4;
-        float* d = cs_smem + cl * LD + k;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    constexpr int LD = NZ + 1, Q = NZ / 4;
+    const int lane = threadIdx.x;
+    const int col0 = blockIdx.x * 64;
+    const int ncol = min(64, n_col - col0);
+    typedef float ca_f32x4 __attribute__((ext_vector_type(4)));
+    const ca_f32x4* src = reinterpret_cast<const ca_f32x4*>(T + (size_t)col0 * NZ);
+    if (ncol == 64) {
+        ca_f32x4 r[Q];
+#pragma unroll
+        for (int i = 0; i < Q; i++) r[i] = __builtin_nontemporal_load(src + i * 64 + lane);
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+            const int e = i * 64 + lane, cl = e / Q, k = (e % Q) * 4;
+            float* d = cs_smem + cl * LD + k;
+            d[0] = r[i].x; d[1] = r[i].y; d[2] = r[i].z; d[3] = r[i].w;
+        }
+    } else {
+        for (int e = lane; e < ncol * Q; e += 64) {
+            const ca_f32x4 v = src[e];
+            const int cl = e / Q, k = (e % Q) * 4;
+            float* d = cs_smem + cl * LD + k;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
     }
     __syncthreads();
-    if ((int)threadIdx.x < ncol) {
-        float* t = cs_smem + threadIdx.x * LD;
+    if (lane < ncol) {
+        float* t = cs_smem + lane * LD;
         float x[NZ], cp[NZ];
 #pragma unroll
         for (int k = 0; k < NZ; k++) x[k] = t[k];
         const float ck = c * K;
         // κ of cell k as c·κ_k: statically unstable where T[k+1] - T[k-1] < 0; the halo cells are the caller's (they carry
         // the field's boundary conditions) or, absent, the nearest interior value (zero-gradient fill)
-        const float below = halo_bottom ? halo_bottom[col0 + threadIdx.x] : x[0];
-        const float above = halo_top ? halo_top[col0 + threadIdx.x] : x[NZ - 1];
+        const float below = halo_bottom ? halo_bottom[col0 + lane] : x[0];
+        const float above = halo_top ? halo_top[col0 + lane] : x[NZ - 1];
         float kk[NZ];
 #pragma unroll
         for (int k = 0; k < NZ; k++) kk[k] = ((k + 1 < NZ ? x[k + 1] : above) - (k > 0 ? x[k - 1] : below)) < 0.0f ? ck : 0.0f;
@@ -59,11 +75,22 @@ __global__ void __launch_bounds__(256) convadj_kernel(const float* __restrict__ 
         for (int k = 0; k < NZ; k++) t[k] = x[k];
     }
     __syncthreads();
-    float4* dst = reinterpret_cast<float4*>(out + (size_t)col0 * NZ);
-    for (int e = threadIdx.x; e < ncol * (NZ / 4); e += 256) {
-        const int cl = e / (NZ / 4), k = (e % (NZ / 4)) * 4;
-        const float* d = cs_smem + cl * LD + k;
-        dst[e] = make_float4(d[0], d[1], d[2], d[3]);
+    ca_f32x4* dst = reinterpret_cast<ca_f32x4*>(out + (size_t)col0 * NZ);
+    if (ncol == 64) {
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+            const int e = i * 64 + lane, cl = e / Q, k = (e % Q) * 4;
+            const float* d = cs_smem + cl * LD + k;
+            const ca_f32x4 q = {d[0], d[1], d[2], d[3]};
+            __builtin_nontemporal_store(q, dst + e);
+        }
+    } else {
+        for (int e = lane; e < ncol * Q; e += 64) {
+            const int cl = e / Q, k = (e % Q) * 4;
+            const float* d = cs_smem + cl * LD + k;
+            const ca_f32x4 q = {d[0], d[1], d[2], d[3]};
+            dst[e] = q;
+        }
     }
 }
 
@@ -97,13 +124,13 @@ __global__ void __launch_bounds__(256) convadj_generic_kernel(const float* __res
 hipError_t launch_convective_adjustment(const float* T, const float* halo_bottom, const float* halo_top, float c, float K, float* out,
                                         int Nz, int n_col, hipStream_t stream) {
     if (Nz < 2 || Nz > 128 || n_col < 1) return hipErrorInvalidValue;
-    const dim3 grid((n_col + 255) / 256), block(256);
-#define CA_LAUNCH(N) hipLaunchKernelGGL(convadj_kernel<N>, grid, block, 256 * (N + 1) * sizeof(float), stream, T, halo_bottom, halo_top, c, K, out, n_col)
+    const dim3 grid((n_col + 63) / 64), block(64);
+#define CA_LAUNCH(N) hipLaunchKernelGGL(convadj_kernel<N>, grid, block, 64 * (N + 1) * sizeof(float), stream, T, halo_bottom, halo_top, c, K, out, n_col)
     const bool aligned = (((uintptr_t)T | (uintptr_t)out) & 15) == 0;
     if (aligned && Nz == 16) CA_LAUNCH(16);
     else if (aligned && Nz == 32) CA_LAUNCH(32);
     else if (aligned && Nz == 64) CA_LAUNCH(64);
-    else hipLaunchKernelGGL(convadj_generic_kernel, grid, block, 0, stream, T, halo_bottom, halo_top, c, K, out, Nz, n_col);
+    else hipLaunchKernelGGL(convadj_generic_kernel, dim3((n_col + 255) / 256), dim3(256), 0, stream, T, halo_bottom, halo_top, c, K, out, Nz, n_col);
 #undef CA_LAUNCH
     return hipGetLastError();
 }
