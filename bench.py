@@ -238,6 +238,8 @@ def other_configs(dev, budget_s=120.0):
     guarded("config3_8_simulations_conv_adj_kappa10_rkc2", c3ca)
     guarded("config5_inference_65536", c5)
     guarded("implicit_steps_4M_columns", impl)
+    guarded("free_convection_8_simulations_32_levels", lambda: fc(8, 32, False, 3, "free convection at a latency size: 8 simulations x 32 levels x 512 RK4 steps, fwd+adjoint (fc32 on 16-column tiles)"))
+    guarded("free_convection_8_simulations_64_levels", lambda: fc(8, 64, False, 3, "free convection at a latency size: 8 simulations x 64 levels x 512 RK4 steps, fwd+adjoint (fc32 on 16-column tiles)"))
     guarded("free_convection_32_levels_16384", lambda: fc(16384, 32, False, 2, "free convection 32 levels (32-128-128-31 relu), 16384 columns x 512 RK4 steps, fwd+adjoint"))
     guarded("config4_shard_16384x64", lambda: fc(16384, 64, False, 2, "configs[3] one GPU's shard: FreeConvectionNDE, 16384 columns x 64 levels x 512 RK4 steps, 64-256-256-63 relu, fwd+adjoint"))
     guarded("config4_shard_16384x64_conv_adj_rkc2", lambda: fc(16384, 64, True, 1, "configs[3] one GPU's shard: ConvectiveAdjustmentNDE (K = 10), 16384 columns x 64 levels x 512 RKC2 steps, fwd+adjoint"))

@@ -66,6 +66,7 @@ struct colnde_handle {
     unsigned long long* d_fc_switch = nullptr;   // ConvectiveAdjustmentNDE: the taped switch patterns
     int fc_block = 0, fc_nblocks = 0, fc_rows = 0;   // gradient path: columns per pass (multiple of 32), passes, slab rows
     int fc_seg = 0, fc_nseg = 0;                      // ... save intervals per time segment of the tapes, segments (1: the tapes hold the whole axis)
+    int fc_cw = 32;                                   // columns per workgroup tile: 32, or 16 for problems of at most 4,096 columns (fc_tile_width)
     float* d_fc_lam = nullptr;                        // λ handed from one time segment to the one before it
     float* d_wimg = nullptr;
     float *d_rt_tape = nullptr, *d_rt_tape2 = nullptr, *d_rt_slab = nullptr, *d_rt_tapez = nullptr;
@@ -423,6 +424,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
             return fail("engine = fc32 requested, but it covers only FreeConvectionNDE (RK4) and ConvectiveAdjustmentNDE (RK4, RKC2) with Dense(Nz,4Nz,relu), Dense(4Nz,4Nz,relu), Dense(4Nz,Nz-1), Nz = 32 or 64");
         }
         if (h->use_fc) {
+            h->fc_cw = fc_tile_width(cfg->n_columns);
             hipError_t e = fc_set_kernel_attributes();
             if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute (fc32) failed: %s", hipGetErrorString(e)); }
         }
@@ -730,7 +732,7 @@ static int fc_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int 
     const float* init = iv0 == 0 ? h->d_x0 + (size_t)c0 * ns : d_sol + ((size_t)c0 * h->cfg.n_save + iv0) * ns;
     const size_t stride = iv0 == 0 ? ns : (size_t)h->cfg.n_save * ns;
     Timed tm(h, K_FORWARD);
-    hipError_t e = fc_launch_forward(h->m, h->d_fc_imgf, h->d_fc_bias, init, stride, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
+    hipError_t e = fc_launch_forward(h->m, h->fc_cw, h->d_fc_imgf, h->d_fc_bias, init, stride, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
                                      iv0, iv1, tape_iv0, h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
                                      with_tape ? h->d_dwtape : nullptr, with_tape ? h->d_fc_masks : nullptr, with_tape ? h->d_fc_switch : nullptr, nc,
                                      h->stream);
@@ -764,7 +766,7 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
         return rt_forward_range(h, d_sol, false, 0, h->n_col);
     }
     if (h->use_fc) {
-        hipError_t e = fc_launch_pack(h->m, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        hipError_t e = fc_launch_pack(h->m, h->fc_cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
         if (e != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(e));
         return fc_forward_range(h, d_sol, false, 0, h->n_col);
     }
@@ -871,11 +873,12 @@ static int fc_plan_tapes(colnde_handle* h) {
     if (R != fc_record_row_floats(m.Nz)) return fail("fc32: record layout mismatch (%zu vs %zu floats per column)", R, fc_record_row_floats(m.Nz));
     const bool ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE;
     // bytes of tape per column and save interval
-    const size_t per_col_iv = (size_t)h->cfg.substeps * m.nst * (R * sizeof(float) + fc_mask_words() * sizeof(unsigned int) / 32 + (ca ? sizeof(unsigned long long) : 0));
+    const int cw = h->fc_cw;
+    const size_t per_col_iv = (size_t)h->cfg.substeps * m.nst * (R * sizeof(float) + fc_mask_words() * sizeof(unsigned int) / cw + (ca ? sizeof(unsigned long long) : 0));
     const int n32 = (h->n_col + 31) / 32 * 32;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const size_t margin = ((size_t)3 << 30) + (size_t)(n32 / 32 * 8 + 4096) * (m.n_params + 8) * sizeof(float) + (size_t)n32 * m.Nz * sizeof(float);
+    const size_t margin = ((size_t)3 << 30) + (size_t)(n32 / cw * 8 + 4096) * (m.n_params + 8) * sizeof(float) + (size_t)n32 * m.Nz * sizeof(float);
     const size_t budget = free_b > margin ? free_b - margin : 0;
     const size_t fit = budget / (per_col_iv * n_iv);                 // columns whose whole-axis tapes fit
     int block = 0, seg = n_iv;
@@ -906,16 +909,16 @@ static int fc_plan_tapes(colnde_handle* h) {
     h->fc_nblocks = (n32 + block - 1) / block;
     h->fc_seg = seg;
     h->fc_nseg = (n_iv + seg - 1) / seg;
-    const size_t tiles_b = (size_t)block / 32;
+    const size_t tiles_b = (size_t)block / cw;                                  // (block is a multiple of 32)
     const size_t stage_recs = (size_t)seg * h->cfg.substeps * m.nst;          // (tile, stage) records per tile held by the tapes
-    const size_t n_rec = tiles_b * 2 * stage_recs;
+    const size_t n_rec = tiles_b * (cw / 16) * stage_recs;                     // records are tile16's: 16 columns each
     std::vector<DwMacro> mac;
     build_dw_macros(h, n_rec, mac);
-    h->fc_rows = (n32 / 32) * h->fc_nseg + h->fc_nblocks * h->fc_nseg * h->dw_slices;
+    h->fc_rows = (n32 / cw) * h->fc_nseg + h->fc_nblocks * h->fc_nseg * h->dw_slices;
     const int stride = m.n_params + 8;
     hipError_t e = hipMalloc((void**)&h->d_dwtape, n_rec * CT * R * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_fc_masks, tiles_b * stage_recs * fc_mask_words() * sizeof(unsigned int));
-    if (e == hipSuccess && ca) e = hipMalloc((void**)&h->d_fc_switch, tiles_b * stage_recs * fc_switch_words() * sizeof(unsigned long long));
+    if (e == hipSuccess && ca) e = hipMalloc((void**)&h->d_fc_switch, tiles_b * stage_recs * fc_switch_words(cw) * sizeof(unsigned long long));
     if (e == hipSuccess && h->fc_nseg > 1) e = hipMalloc((void**)&h->d_fc_lam, (size_t)n32 * m.Nz * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_macros, mac.size() * sizeof(DwMacro));
     if (e == hipSuccess) e = hipMemcpy(h->d_macros, mac.data(), mac.size() * sizeof(DwMacro), hipMemcpyHostToDevice);
@@ -1083,15 +1086,16 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         LossWeights lw;
         loss_weights(h, scalings, &lw);
         const size_t ns = h->m.ns;
-        hipError_t e = fc_launch_pack(h->m, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        hipError_t e = fc_launch_pack(h->m, h->fc_cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
         if (e != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(e));
         HIPCHK(hipMemsetAsync(h->d_slab, 0, (size_t)h->fc_rows * stride * sizeof(float), h->stream));
-        const int n_wg = (h->n_col + 31) / 32, n_iv = h->cfg.n_save - 1, nseg = h->fc_nseg;
+        const int cw = h->fc_cw;
+        const int n_wg = (h->n_col + cw - 1) / cw, n_iv = h->cfg.n_save - 1, nseg = h->fc_nseg;
         const size_t gemm_rows0 = (size_t)n_wg * nseg;                      // slab: [tile][segment] adjoint rows, then [block][segment][slice] GEMM rows
         for (int b = 0; b < h->fc_nblocks; b++) {
             const int c0 = b * h->fc_block, nc = std::min(h->fc_block, h->n_col - c0);
             if (nc <= 0) break;
-            const size_t tiles_b = ((size_t)nc + 31) / 32;
+            const size_t tiles_b = ((size_t)nc + cw - 1) / cw;
             // time segments: the states at the save points first (tape-less), then segment by segment from the end of the axis
             // (that first pass tapes the LAST segment on its way, which is the first one the backward sweep needs)
             if (nseg > 1 && fc_forward_range(h, h->d_sol, true, c0, nc, 0, n_iv, (nseg - 1) * h->fc_seg)) return 1;
@@ -1100,15 +1104,15 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                 if (!(nseg > 1 && sg == nseg - 1) && fc_forward_range(h, h->d_sol, true, c0, nc, iv0, iv1)) return 1;
                 {
                     Timed tm(h, K_ADJOINT);
-                    e = fc_launch_adjoint(h->m, h->d_fc_imgb, h->d_times, h->cfg.n_save, iv0, iv1, h->cfg.substeps, h->d_sol + (size_t)c0 * h->cfg.n_save * ns,
+                    e = fc_launch_adjoint(h->m, h->fc_cw, h->d_fc_imgb, h->d_times, h->cfg.n_save, iv0, iv1, h->cfg.substeps, h->d_sol + (size_t)c0 * h->cfg.n_save * ns,
                                           h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_dwtape, h->d_fc_masks, h->d_fc_switch, lw.w[2],
                                           nseg > 1 ? h->d_fc_lam + (size_t)c0 * h->m.Nz : nullptr,
-                                          h->d_slab + ((size_t)sg * n_wg + (size_t)(c0 / 32)) * stride, nc, h->stream);
+                                          h->d_slab + ((size_t)sg * n_wg + (size_t)(c0 / cw)) * stride, nc, h->stream);
                     if (e != hipSuccess) return fail("fc32 adjoint launch failed: %s", hipGetErrorString(e));
                 }
                 {
                     Timed tm(h, K_DW1);
-                    e = launch_dw_gemm(h->d_dwtape, tiles_b * 2 * (size_t)(iv1 - iv0) * h->cfg.substeps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros,
+                    e = launch_dw_gemm(h->d_dwtape, tiles_b * (cw / 16) * (size_t)(iv1 - iv0) * h->cfg.substeps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros,
                                        h->n_macros, h->dw_slices, h->d_slab + (gemm_rows0 + ((size_t)b * nseg + sg) * h->dw_slices) * stride, stride, h->stream);
                     if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
                 }
@@ -1220,10 +1224,11 @@ extern "C" int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights
     HIPCHK(hipSetDevice(h->device));
     if (h->use_fc && h->m.model == COLNDE_MODEL_FREE_CONVECTION) {
         // the reference's forcing network IS the fc32 shape (32-128-128-31 in double_gyre_nn.jl): the 32-column engine's sections, one evaluation
-        hipError_t ef = fc_launch_pack(h->m, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        const int cw = fc_tile_width(n_columns);                 // (the images are packed per call: this call's own tile width)
+        hipError_t ef = fc_launch_pack(h->m, cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
         if (ef != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(ef));
         Timed tm(h, K_INFER);
-        ef = fc_launch_infer(h->m, h->d_fc_imgf, h->d_fc_bias, d_T, d_top_flux, (float)h->m.Nz / Lz, d_out, n_columns, h->stream);
+        ef = fc_launch_infer(h->m, cw, h->d_fc_imgf, h->d_fc_bias, d_T, d_top_flux, (float)h->m.Nz / Lz, d_out, n_columns, h->stream);
         if (ef != hipSuccess) return fail("fc32 infer launch failed: %s", hipGetErrorString(ef));
         return 0;
     }

@@ -9,21 +9,24 @@ size_t fc_image_floats(int Nz);          // floats of one A-operand image (forwa
 size_t fc_bias_floats(int Nz);
 size_t fc_record_row_floats(int Nz);     // = dwtape_row_floats(m): the records are tile16's delta-tape records
 static inline size_t fc_mask_words() { return 512; }     // relu-derivative bits per 32-column tile and stage: [layer 2][wave 4][lane 64] dwords
-static inline size_t fc_switch_words() { return 32; }    // ConvectiveAdjustmentNDE: the switch pattern of a stage, one 64-bit word per column
+static inline size_t fc_switch_words(int cw) { return (size_t)cw; }   // ConvectiveAdjustmentNDE: the switch pattern of a stage, one 64-bit word per column
 hipError_t fc_set_kernel_attributes();
-hipError_t fc_launch_pack(const DevModel& m, const float* w, float* imgf, float* imgb, float* bias, hipStream_t stream);
+// cw = columns per workgroup tile (32: v_mfma_f32_32x32x2_f32, the throughput shape; 16: v_mfma_f32_16x16x4_f32, half the matrix work per stage for
+// problems that cannot fill 32-column tiles on every CU); the operand images depend on it
+int fc_tile_width(int n_col);
+hipError_t fc_launch_pack(const DevModel& m, int cw, const float* w, float* imgf, float* imgb, float* bias, hipStream_t stream);
 // Save intervals [iv_begin, iv_end) from x0 (column stride x0_stride floats).  dwtape == nullptr: plain forward solve.  Otherwise, from interval
 // tape_iv0 on (iv_begin <= tape_iv0 < iv_end; records numbered from its first step), the stage inputs
-// and hidden activations go into the records [tile32][step of this launch][stage][2 x 16 columns][R], the relu bits into masks [..][512] and
-// (ConvectiveAdjustmentNDE) the switch pattern into swtape [..][32].  Stages per step: m.nst (4, or the RKC2 stage count when m.rkc is set).
-hipError_t fc_launch_forward(const DevModel& m, const float* imgf, const float* bias, const float* x0, size_t x0_stride, const float* bcs,
+// and hidden activations go into the records [tile32][step of this launch][stage][cw/16 records of 16 columns][R], the relu bits into masks [..][512] and
+// (ConvectiveAdjustmentNDE) the switch pattern into swtape [..][cw].  Stages per step: m.nst (4, or the RKC2 stage count when m.rkc is set).
+hipError_t fc_launch_forward(const DevModel& m, int cw, const float* imgf, const float* bias, const float* x0, size_t x0_stride, const float* bcs,
                              const float* save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float* sol, float* dwtape,
                              unsigned int* masks, unsigned long long* swtape, int n_col, hipStream_t stream);
-// slab: one row of n_params + 8 floats per 32-column tile (bias gradients and the squared-error sum; the weight gradients are the dW GEMM's).
+// slab: one row of n_params + 8 floats per tile (bias gradients and the squared-error sum; the weight gradients are the dW GEMM's).
 // lam_io [columns padded to 32][Nz]: carries λ between the time segments of a segmented gradient pass (null when one launch covers the axis).
-hipError_t fc_launch_adjoint(const DevModel& m, const float* imgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
+hipError_t fc_launch_adjoint(const DevModel& m, int cw, const float* imgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
                              const float* sol, const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape,
                              float w_loss, float* lam_io, float* slab, int n_col, hipStream_t stream);
 // compute_neural_network_forcing! (double_gyre_nn.jl:149-168): T [n_col][Nz] model units, top_flux [n_col], out = -dz(wT) on cell centres
-hipError_t fc_launch_infer(const DevModel& m, const float* imgf, const float* bias, const float* T, const float* top_flux, float inv_dz,
+hipError_t fc_launch_infer(const DevModel& m, int cw, const float* imgf, const float* bias, const float* T, const float* top_flux, float inv_dz,
                            float* out, int n_col, hipStream_t stream);

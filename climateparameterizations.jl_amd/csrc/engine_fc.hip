@@ -51,13 +51,20 @@ extern __shared__ float fc_smem[];
 // address space and turns every load into a flat_load, which counts against lgkmcnt as well.)
 #define FC_OPAQUE_ZERO(z) asm volatile("" : "+s"(z))
 
-template <int NZ>
+// CW = columns per workgroup tile = N of the MFMA: 32 (v_mfma_f32_32x32x2_f32, the throughput shape) or 16 (v_mfma_f32_16x16x4_f32: half the
+// matrix work per stage for problems that cannot fill 32-column tiles on every CU — the latency sizes, up to 4,096 columns).  Everything else is the
+// same code: lane = (column n = lane % CW, k/row quad hq = lane / CW); a group is four MFMAs over KG = 256/CW consecutive k; an accumulator holds
+// NQ = CW²/256 quads of four consecutive output rows: rows 8q + 4hq + e (CW = 32) or 4hq + e (CW = 16) of the row tile, column n.
+template <int NZ, int CW = 32>
 struct Fc {
+    static_assert(CW == 32 || CW == 16, "tile width");
     static constexpr int H = 4 * NZ, NO = NZ - 1;
     static constexpr int LDX = NZ + 4, LDH = H + 4;              // LDS row strides: 16-byte aligned rows, stride/4 odd => conflict-free ds_read_b128
-    static constexpr int MT = H / 32, JH = MT / 4;               // row tiles of a hidden layer; jobs per wave
-    static constexpr int S_IN = NZ / 8, S_H = H / 8;             // groups of 8 k per chain: K = NZ, K = 4 NZ
-    static constexpr int MT3 = NZ / 32, KS3 = 4 / MT3, G3 = S_H / KS3;   // narrow layer (M = NZ): row tiles, K splits, groups per job
+    static constexpr int KG = 256 / CW, NQ = CW * CW / 256, ACCN = 4 * NQ;   // k per group; accumulator quads (4 / 1); accumulator floats
+    static constexpr int MT = H / CW, JH = MT / 4;               // row tiles of a hidden layer; jobs per wave
+    static constexpr int S_IN = NZ / KG, S_H = H / KG;           // groups per chain: K = NZ, K = 4 NZ
+    static constexpr int MT3 = NZ / CW, KS3 = MT3 >= 4 ? 1 : 4 / MT3, G3 = S_H / KS3;   // narrow layer (M = NZ): row tiles, K splits, groups per job
+    static_assert(MT3 * KS3 == 4 && JH >= 1, "four jobs of the narrow layer, one per wave");
     static constexpr int F1 = 0, F1_SZ = MT * S_IN * 256;
     static constexpr int F2 = F1 + F1_SZ, F2_SZ = MT * S_H * 256;
     static constexpr int F3 = F2 + F2_SZ, F3_SZ = MT3 * S_H * 256;
@@ -66,17 +73,20 @@ struct Fc {
     static constexpr int P = JH * S_IN + JH * S_H + G3;          // groups per stage and wave
     static constexpr int ACT4 = 2 * H + NZ;                      // dwtape_act4: (2H + NZ - 1) rounded up to 4
     static constexpr int R = NZ + 2 * ACT4;                      // floats per column of a delta-tape record (dwtape_row_floats)
-    static constexpr int OWN = 32 * NZ / 256;                    // state items (column, level) per thread
+    static constexpr int OWN = CW * NZ / 256;                    // state items (column, level) per thread
     static_assert(P % FC_PF == 0, "the ring must close over one stage");
+    typedef float acc_t __attribute__((ext_vector_type(ACCN)));
+    // first row (within the row tile) of accumulator quad q for this lane's hq
+    __device__ static constexpr int qrow(int q, int hq) { return (CW == 32 ? 8 * q : 0) + 4 * hq; }
 };
 
 // stream position -> layer section (0: K = NZ hidden, 1: K = 4NZ hidden, 2: the narrow layer) and offset in float4 units from the wave's base
-template <int NZ> __host__ __device__ constexpr int fc_sec(int p) {
-    p %= Fc<NZ>::P;
-    return p < Fc<NZ>::JH * Fc<NZ>::S_IN ? 0 : (p < Fc<NZ>::JH * (Fc<NZ>::S_IN + Fc<NZ>::S_H) ? 1 : 2);
+template <int NZ, int CW> __host__ __device__ constexpr int fc_sec(int p) {
+    p %= Fc<NZ, CW>::P;
+    return p < Fc<NZ, CW>::JH * Fc<NZ, CW>::S_IN ? 0 : (p < Fc<NZ, CW>::JH * (Fc<NZ, CW>::S_IN + Fc<NZ, CW>::S_H) ? 1 : 2);
 }
-template <int NZ> __host__ __device__ constexpr int fc_off(int p) {
-    using S = Fc<NZ>;
+template <int NZ, int CW> __host__ __device__ constexpr int fc_off(int p) {
+    using S = Fc<NZ, CW>;
     p %= S::P;
     if (p < S::JH * S::S_IN) return (4 * (p / S::S_IN) * S::S_IN + p % S::S_IN) * 64;
     p -= S::JH * S::S_IN;
@@ -87,24 +97,32 @@ template <int NZ> __host__ __device__ constexpr int fc_off(int p) {
 // One section of the wave's stream: NJ jobs (output row tiles) of NG groups each, starting at stream position P0.  Per group: four
 // MFMAs fed by one ring slot (A: four k-steps of this lane's weight row) and one 16-byte LDS read (B: the same four k of column n);
 // the slot is refilled with the group FC_PF positions ahead — possibly the next layer's or the next stage's.
-template <int NZ, int P0, int NJ, int NG, class Epi>
+template <int NZ, int CW, int P0, int NJ, int NG, class Epi>
 __device__ __forceinline__ void fc_section(f32x4 (&ring)[FC_PF], const f32x4* const (&base)[3], int lane, const float* brow, Epi&& epi) {
+    using S = Fc<NZ, CW>;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-        fc16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        typename S::acc_t acc = (typename S::acc_t)(0.0f);
         f32x4 b[2];
         b[0] = *reinterpret_cast<const f32x4*>(brow);
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const int p = P0 + j * NG + g;
-            if (g + 1 < NG) b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(brow + 8 * (g + 1));
+            if (g + 1 < NG) b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(brow + S::KG * (g + 1));
             const f32x4 a = ring[p % FC_PF];
-            ring[p % FC_PF] = (base[fc_sec<NZ>(p + FC_PF)] + fc_off<NZ>(p + FC_PF))[lane];
+            ring[p % FC_PF] = (base[fc_sec<NZ, CW>(p + FC_PF)] + fc_off<NZ, CW>(p + FC_PF))[lane];
             const f32x4 bv = b[g & 1];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc, 0, 0, 0);
+            if constexpr (CW == 32) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv.w, acc, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         epi(j, acc);
@@ -113,16 +131,16 @@ __device__ __forceinline__ void fc_section(f32x4 (&ring)[FC_PF], const f32x4* co
 
 // ------------------------------------------------------------------------------------------------
 // operand images.  Flux.destructure: W_l[o][i] (out o, in i) at w_off[l] + i*no + o, b_l[o] at b_off[l] + o.
-//   forward  section (rows = outputs):  A[row = mt*32 + (lane&31)][k = 8S + 4(lane>>5) + j] = W_l[row][k]
-//   backward section (rows = inputs):   A[row = it*32 + (lane&31)][k = 8S + 4(lane>>5) + j] = W_l[k][row]      (zero beyond the matrix)
+//   forward  section (rows = outputs):  A[row = mt*CW + lane%CW][k = KG*S + 4(lane/CW) + j] = W_l[row][k]
+//   backward section (rows = inputs):   A[row = it*CW + lane%CW][k = KG*S + 4(lane/CW) + j] = W_l[k][row]      (zero beyond the matrix)
 // image[section][tile][S][lane][j]; backward sections in the order they are used: W3ᵀ (K = NZ), W2ᵀ, W1ᵀ (the narrow one).
 // ------------------------------------------------------------------------------------------------
 struct FcOffsets { int w[3], b[3]; };
 
-template <int NZ>
+template <int NZ, int CW>
 __global__ void __launch_bounds__(256) fc_pack_kernel(FcOffsets o, const float* __restrict__ w, float* __restrict__ imgf, float* __restrict__ imgb,
                                                       float* __restrict__ bias) {
-    using S = Fc<NZ>;
+    using S = Fc<NZ, CW>;
     const int total = 2 * S::IMG + S::BIAS;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         if (idx >= 2 * S::IMG) {
@@ -141,7 +159,7 @@ __global__ void __launch_bounds__(256) fc_pack_kernel(FcOffsets o, const float* 
         const int nS = sec == 0 ? S::S_IN : S::S_H;
         const int j = r & 3, lane = (r >> 2) & 63, blk = r >> 8;
         const int tile = blk / nS, Sg = blk - tile * nS;
-        const int row = tile * 32 + (lane & 31), k = 8 * Sg + 4 * (lane >> 5) + j;
+        const int row = tile * CW + (lane & (CW - 1)), k = S::KG * Sg + 4 * (lane / CW) + j;
         float v = 0.0f;
         if (fwd) {
             // section 0: W1 (NZ -> H), 1: W2 (H -> H), 2: W3 (H -> NO)
@@ -171,7 +189,7 @@ __global__ void __launch_bounds__(256) fc_pack_kernel(FcOffsets o, const float* 
 // ------------------------------------------------------------------------------------------------
 typedef unsigned long long u64;
 
-template <int NZ, bool TAPE, bool CA, bool RKC>
+template <int NZ, int CW, bool TAPE, bool CA, bool RKC>
 __global__ void __launch_bounds__(256, 2)
 fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, const float* __restrict__ x0, size_t x0_stride,
                   const float* __restrict__ bcs, const float* __restrict__ save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float CN,
@@ -181,16 +199,16 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
     // of the gradient path — the state the tape-less pass saved at save point iv_begin; restarting there is exact: the saved state IS xn).
     // Only the intervals from tape_iv0 on are taped (the records are numbered from its first step): the tape-less pass of a time-segmented
     // gradient tapes its LAST segment on the way, which that segment's own pass would otherwise have to repeat.
-    using S = Fc<NZ>;
+    using S = Fc<NZ, CW>;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31, h = lane >> 5;
+    const int n = lane & (CW - 1), h = lane / CW;               // column of the tile; k / row quad
     float* X = fc_smem;                          // [32][LDX]   stage input
-    float* A1 = X + 32 * S::LDX;                 // [32][LDH]   relu(W1 x + b1)
-    float* A2 = A1 + 32 * S::LDH;                // [32][LDH]   relu(W2 a1 + b2)
+    float* A1 = X + CW * S::LDX;                 // [32][LDH]   relu(W1 x + b1)
+    float* A2 = A1 + CW * S::LDH;                // [32][LDH]   relu(W2 a1 + b2)
     float* PART = A1;                            // [KS3][32][NZ] partial sums of the last layer (a1 is dead by then)
-    float* BL = A2 + 32 * S::LDH;                // [2H + NZ] biases (a global load in an epilogue would be waited for with vmcnt(0): the ring too)
+    float* BL = A2 + CW * S::LDH;                // [2H + NZ] biases (a global load in an epilogue would be waited for with vmcnt(0): the ring too)
     for (int q = tid; q < S::BIAS; q += 256) BL[q] = bias[q];
-    const int col0 = blockIdx.x * 32;
+    const int col0 = blockIdx.x * CW;
     FC_OWNER_INDEX();
 
     const f32x4* base[3];
@@ -199,7 +217,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
     base[2] = reinterpret_cast<const f32x4*>(imgf + S::F3) + ((w % S::MT3) * S::S_H + (w / S::MT3) * S::G3) * 64;
     f32x4 ring[FC_PF];
 #pragma unroll
-    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ>(q)] + fc_off<NZ>(q))[lane];
+    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ, CW>(q)] + fc_off<NZ, CW>(q))[lane];
 
     float xn[S::OWN], vst[S::OWN], kv[S::OWN], bcb[S::OWN], bct[S::OWN];
 #pragma unroll
@@ -228,7 +246,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
         FC_OPAQUE_ZERO(zero);
         const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
         const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
-        float* rec = tp ? dwtape + ri * ((size_t)32 * S::R) : nullptr;
+        float* rec = tp ? dwtape + ri * ((size_t)CW * S::R) : nullptr;
         u32* mrec = tp ? masks + ri * 512 + w * 64 + lane : nullptr;
         // ---- stage input (owner layout) -> LDS rows, tape
 #pragma unroll
@@ -238,13 +256,13 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
         }
         FC_BARRIER();
         // ---- hidden layers: z = W a + b on 32x32x2 MFMA, relu, rows to LDS (next layer's B operand) and to the tape
-        auto hidden = [&](int l /* 1, 2 */, float* dstrows, int j, const fc16& acc) {
+        auto hidden = [&](int l /* 1, 2 */, float* dstrows, int j, const typename S::acc_t& acc) {
             const int mt = w + 4 * j;
-            const float* bl = BL + (l - 1) * S::H + mt * 32 + 4 * h;
             u32 bits = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + 8 * q);
+            for (int q = 0; q < S::NQ; q++) {
+                const int f = mt * CW + S::qrow(q, h);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(BL + (l - 1) * S::H + f);
                 f32x4 a;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -252,7 +270,6 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
                     a[e] = fmaxf(z, 0.0f);
                     bits |= (z > 0.0f ? 1u : 0u) << (4 * q + e);
                 }
-                const int f = mt * 32 + 8 * q + 4 * h;
                 *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + f) = a;
                 if (tp) FC_STORE(a, reinterpret_cast<f32x4*>(rec + (size_t)n * S::R + NZ + (l - 1) * S::H + f));
             }
@@ -260,26 +277,26 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
         };
         {
             u32 mb = 0;
-            fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h,
-                                              [&](int j, const fc16& acc) { mb |= hidden(1, A1, j, acc) << (16 * j); });
+            fc_section<NZ, CW, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h,
+                                              [&](int j, const typename S::acc_t& acc) { mb |= hidden(1, A1, j, acc) << (S::ACCN * j); });
             if (tp) FC_STORE(mb, mrec);
         }
         FC_BARRIER();
         {
             u32 mb = 0;
-            fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h,
-                                                           [&](int j, const fc16& acc) { mb |= hidden(2, A2, j, acc) << (16 * j); });
+            fc_section<NZ, CW, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h,
+                                                           [&](int j, const typename S::acc_t& acc) { mb |= hidden(2, A2, j, acc) << (S::ACCN * j); });
             if (tp) FC_STORE(mb, mrec + 256);
         }
         FC_BARRIER();
         // ---- output layer: row tile w % MT3, K part w / MT3; partial sums to LDS
-        fc_section<NZ, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, A2 + n * S::LDH + (w / S::MT3) * S::G3 * 8 + 4 * h,
-            [&](int, const fc16& acc) {
-                float* pr = PART + ((w / S::MT3) * 32 + n) * NZ + (w % S::MT3) * 32 + 4 * h;
+        fc_section<NZ, CW, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, A2 + n * S::LDH + (w / S::MT3) * S::G3 * S::KG + 4 * h,
+            [&](int, const typename S::acc_t& acc) {
+                float* pr = PART + ((w / S::MT3) * CW + n) * NZ + (w % S::MT3) * CW;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < S::NQ; q++) {
                     const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(pr + 8 * q) = v;
+                    *reinterpret_cast<f32x4*>(pr + S::qrow(q, h)) = v;
                 }
             });
         FC_BARRIER();
@@ -289,7 +306,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
         for (int r = 0; r < S::OWN; r++) {
             float o = b3v;
 #pragma unroll
-            for (int ks = 0; ks < S::KS3; ks++) o += PART[(ks * 32 + oc[r]) * NZ + oi];
+            for (int ks = 0; ks < S::KS3; ks++) o += PART[(ks * CW + oc[r]) * NZ + oi];
             const float olo = __shfl_up(o, 1);                                // NN output of face i (lane i - 1 holds it)
             float wlo = oi == 0 ? bcb[r] : olo;
             float whi = oi == NZ - 1 ? bct[r] : o;
@@ -304,7 +321,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
                     // the switch pattern of the stage, one bit per face, for the pullback
                     const u64 bal = __ballot(on);
                     const u64 mine = NZ == 64 ? bal : (lane < 32 ? (bal & 0xffffffffull) : (bal >> 32));
-                    if (oi == 0) swtape[ri * 32 + oc[r]] = mine;
+                    if (oi == 0) swtape[ri * CW + oc[r]] = mine;
                 }
             }
             kv[r] = -CN * (whi - wlo);
@@ -391,18 +408,18 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
 // tiles (gridDim.x workgroups, tile += gridDim.x) so that the A-operand ring keeps streaming from one tile to the next.
 //   T̂ = T_scaling(19.65 + T/20) (:156-158), wT = enforce_fluxes(inv(wT_scaling)(NN(T̂)), 0, surface_flux) (:160), forcing = -∂z wT (:135)
 // ------------------------------------------------------------------------------------------------
-template <int NZ>
+template <int NZ, int CW>
 __global__ void __launch_bounds__(256, 2)
 fc_infer_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, const float* __restrict__ T, const float* __restrict__ top_flux,
                 float mu_T, float inv_sig_T, float sig_wT, float mu_wT, float inv_dz, float* __restrict__ out, int n_col) {
-    using S = Fc<NZ>;
+    using S = Fc<NZ, CW>;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31, h = lane >> 5;
+    const int n = lane & (CW - 1), h = lane / CW;               // column of the tile; k / row quad
     float* X = fc_smem;
-    float* A1 = X + 32 * S::LDX;
-    float* A2 = A1 + 32 * S::LDH;
+    float* A1 = X + CW * S::LDX;
+    float* A2 = A1 + CW * S::LDH;
     float* PART = A1;
-    float* BL = A2 + 32 * S::LDH;
+    float* BL = A2 + CW * S::LDH;
     for (int q = tid; q < S::BIAS; q += 256) BL[q] = bias[q];
     FC_OWNER_INDEX();
     const f32x4* base[3];
@@ -411,16 +428,16 @@ fc_infer_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, 
     base[2] = reinterpret_cast<const f32x4*>(imgf + S::F3) + ((w % S::MT3) * S::S_H + (w / S::MT3) * S::G3) * 64;
     f32x4 ring[FC_PF];
 #pragma unroll
-    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ>(q)] + fc_off<NZ>(q))[lane];
+    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ, CW>(q)] + fc_off<NZ, CW>(q))[lane];
     const float b3v = oi < S::NO ? bias[2 * S::H + oi] : 0.0f;
     asm volatile("" :: "v"(b3v));
-    const int n_tiles = (n_col + 31) / 32;
+    const int n_tiles = (n_col + CW - 1) / CW;
 #pragma nounroll
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int zero = 0;
         FC_OPAQUE_ZERO(zero);
         const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
-        const int col0 = tile * 32;
+        const int col0 = tile * CW;
         float tf[S::OWN];
 #pragma unroll
         for (int r = 0; r < S::OWN; r++) {
@@ -429,29 +446,29 @@ fc_infer_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, 
             tf[r] = top_flux[col];
         }
         FC_BARRIER();
-        auto hidden = [&](int l, float* dstrows, int j, const fc16& acc) {
+        auto hidden = [&](int l, float* dstrows, int j, const typename S::acc_t& acc) {
             const int mt = w + 4 * j;
-            const float* bl = BL + (l - 1) * S::H + mt * 32 + 4 * h;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + 8 * q);
+            for (int q = 0; q < S::NQ; q++) {
+                const int f = mt * CW + S::qrow(q, h);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(BL + (l - 1) * S::H + f);
                 f32x4 a;
 #pragma unroll
                 for (int e = 0; e < 4; e++) a[e] = fmaxf(acc[4 * q + e] + bq[e], 0.0f);
-                *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + mt * 32 + 8 * q + 4 * h) = a;
+                *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + f) = a;
             }
         };
-        fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h, [&](int j, const fc16& acc) { hidden(1, A1, j, acc); });
+        fc_section<NZ, CW, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h, [&](int j, const typename S::acc_t& acc) { hidden(1, A1, j, acc); });
         FC_BARRIER();
-        fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h, [&](int j, const fc16& acc) { hidden(2, A2, j, acc); });
+        fc_section<NZ, CW, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h, [&](int j, const typename S::acc_t& acc) { hidden(2, A2, j, acc); });
         FC_BARRIER();
-        fc_section<NZ, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, A2 + n * S::LDH + (w / S::MT3) * S::G3 * 8 + 4 * h,
-            [&](int, const fc16& acc) {
-                float* pr = PART + ((w / S::MT3) * 32 + n) * NZ + (w % S::MT3) * 32 + 4 * h;
+        fc_section<NZ, CW, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, A2 + n * S::LDH + (w / S::MT3) * S::G3 * S::KG + 4 * h,
+            [&](int, const typename S::acc_t& acc) {
+                float* pr = PART + ((w / S::MT3) * CW + n) * NZ + (w % S::MT3) * CW;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < S::NQ; q++) {
                     const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(pr + 8 * q) = v;
+                    *reinterpret_cast<f32x4*>(pr + S::qrow(q, h)) = v;
                 }
             });
         FC_BARRIER();
@@ -459,7 +476,7 @@ fc_infer_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, 
         for (int r = 0; r < S::OWN; r++) {
             float o = b3v;
 #pragma unroll
-            for (int ks = 0; ks < S::KS3; ks++) o += PART[(ks * 32 + oc[r]) * NZ + oi];
+            for (int ks = 0; ks < S::KS3; ks++) o += PART[(ks * CW + oc[r]) * NZ + oi];
             const float wT = sig_wT * o + mu_wT;                                   // face oi + 1
             const float below = __shfl_up(wT, 1);                                  // face oi
             const float lo = oi == 0 ? 0.0f : below;
@@ -478,7 +495,7 @@ fc_infer_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, 
 // ------------------------------------------------------------------------------------------------
 struct FcGrad { int b[3]; int n_params; };
 
-template <int NZ, bool CA, bool RKC>
+template <int NZ, int CW, bool CA, bool RKC>
 __global__ void __launch_bounds__(256, 2)
 fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save_times, int n_save, int iv_begin, int iv_end, int substeps, float CN,
                   float caKN, int nst, const float* __restrict__ rkc, const float* __restrict__ sol, const float* __restrict__ truth,
@@ -486,14 +503,14 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
                   float* __restrict__ slab, FcGrad go, int n_col) {
     // Save intervals [iv_begin, iv_end), backwards.  lam_io [columns][NZ] (or null: one launch covers the axis) carries λ from one time
     // segment to the one before it: read unless this is the last segment of the axis, written unless it is the first.
-    using S = Fc<NZ>;
+    using S = Fc<NZ, CW>;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31, h = lane >> 5;
+    const int n = lane & (CW - 1), h = lane / CW;               // column of the tile; k / row quad
     float* DZ2 = fc_smem;                        // [32][LDH]
-    float* DZ1 = DZ2 + 32 * S::LDH;              // [32][LDH]
+    float* DZ1 = DZ2 + CW * S::LDH;              // [32][LDH]
     float* DZ3 = DZ1;                            // [32][LDX]   dead before dz1 is written
     float* XBP = DZ2;                            // [KS3][32][NZ] partial sums of W1ᵀ dz1 (dz2 is dead by then)
-    const int col0 = blockIdx.x * 32;
+    const int col0 = blockIdx.x * CW;
     FC_OWNER_INDEX();
 
     const f32x4* base[3];
@@ -502,7 +519,7 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
     base[2] = reinterpret_cast<const f32x4*>(imgb + S::F3) + ((w % S::MT3) * S::S_H + (w / S::MT3) * S::G3) * 64;
     f32x4 ring[FC_PF];
 #pragma unroll
-    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ>(q)] + fc_off<NZ>(q))[lane];
+    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ, CW>(q)] + fc_off<NZ, CW>(q))[lane];
 
     float lam[S::OWN], xb[S::OWN], kb[S::OWN], db3[S::OWN];
     u32 swp = 0;                                 // switch bits of this thread's items: bit 2r = face oi, bit 2r + 1 = face oi + 1 of item r
@@ -526,7 +543,7 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
         FC_OPAQUE_ZERO(zero);
         const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
         const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
-        float* rec = dwtape + ri * ((size_t)32 * S::R);
+        float* rec = dwtape + ri * ((size_t)CW * S::R);
         const u32* mrec = masks + ri * 512 + w * 64 + lane;
         const u32 m1 = FC_LOAD(mrec), m2 = FC_LOAD(mrec + 256);
         // ---- physics pullback: dz3[i] = C Nz (k̄[i+1] - k̄[i]) on the Nz-1 interior faces; CA: x̄ += Dᶠᵀ(switch ∘ (-K) ∘ that)
@@ -547,28 +564,28 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
             db3[r] += dz;
         }
         FC_BARRIER();
-        auto hidden = [&](int l /* 2, 1: layer whose dz this is */, float* dstrows, u32 bits, int j, const fc16& acc) {
+        auto hidden = [&](int l /* 2, 1: layer whose dz this is */, float* dstrows, u32 bits, int j, const typename S::acc_t& acc) {
             const int mt = w + 4 * j;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < S::NQ; q++) {
                 f32x4 d;
 #pragma unroll
-                for (int e = 0; e < 4; e++) d[e] = ((bits >> (16 * j + 4 * q + e)) & 1u) ? acc[4 * q + e] : 0.0f;
-                const int f = mt * 32 + 8 * q + 4 * h;
+                for (int e = 0; e < 4; e++) d[e] = ((bits >> (S::ACCN * j + 4 * q + e)) & 1u) ? acc[4 * q + e] : 0.0f;
+                const int f = mt * CW + S::qrow(q, h);
                 *reinterpret_cast<f32x4*>(dstrows + n * S::LDH + f) = d;
                 FC_STORE(d, reinterpret_cast<f32x4*>(rec + (size_t)n * S::R + NZ + S::ACT4 + (l - 1) * S::H + f));
             }
         };
         // ---- dz2 = relu'(z2) ∘ W3ᵀ dz3
-        fc_section<NZ, 0, S::JH, S::S_IN>(ring, sb, lane, DZ3 + n * S::LDX + 4 * h,
-                                          [&](int j, const fc16& acc) { hidden(2, DZ2, m2, j, acc); });
+        fc_section<NZ, CW, 0, S::JH, S::S_IN>(ring, sb, lane, DZ3 + n * S::LDX + 4 * h,
+                                          [&](int j, const typename S::acc_t& acc) { hidden(2, DZ2, m2, j, acc); });
         FC_BARRIER();
         // bias gradients: hidden unit tid's column sum of the finished dz rows, straight from LDS (16 accumulator registers per row tile
         // and layer — 64 at Nz = 64 — would otherwise ride along in every lane)
         auto colsum = [&](const float* rows) {
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 32; c += 4) {
+            for (int c = 0; c < CW; c += 4) {
                 a0 += rows[(c + 0) * S::LDH + tid];
                 a1 += rows[(c + 1) * S::LDH + tid];
                 a2 += rows[(c + 2) * S::LDH + tid];
@@ -578,18 +595,18 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
         };
         if (S::H == 256 || tid < S::H) db2 += colsum(DZ2);
         // ---- dz1 = relu'(z1) ∘ W2ᵀ dz2
-        fc_section<NZ, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, DZ2 + n * S::LDH + 4 * h,
-                                                       [&](int j, const fc16& acc) { hidden(1, DZ1, m1, j, acc); });
+        fc_section<NZ, CW, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, DZ2 + n * S::LDH + 4 * h,
+                                                       [&](int j, const typename S::acc_t& acc) { hidden(1, DZ1, m1, j, acc); });
         FC_BARRIER();
         if (S::H == 256 || tid < S::H) db1 += colsum(DZ1);
         // ---- x̄ = W1ᵀ dz1: row tile w % MT3, K part w / MT3
-        fc_section<NZ, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, DZ1 + n * S::LDH + (w / S::MT3) * S::G3 * 8 + 4 * h,
-            [&](int, const fc16& acc) {
-                float* pr = XBP + ((w / S::MT3) * 32 + n) * NZ + (w % S::MT3) * 32 + 4 * h;
+        fc_section<NZ, CW, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, DZ1 + n * S::LDH + (w / S::MT3) * S::G3 * S::KG + 4 * h,
+            [&](int, const typename S::acc_t& acc) {
+                float* pr = XBP + ((w / S::MT3) * CW + n) * NZ + (w % S::MT3) * CW;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < S::NQ; q++) {
                     const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(pr + 8 * q) = v;
+                    *reinterpret_cast<f32x4*>(pr + S::qrow(q, h)) = v;
                 }
             });
         FC_BARRIER();
@@ -597,7 +614,7 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
         for (int r = 0; r < S::OWN; r++) {
             float v = xph[r];
 #pragma unroll
-            for (int ks = 0; ks < S::KS3; ks++) v += XBP[(ks * 32 + oc[r]) * NZ + oi];
+            for (int ks = 0; ks < S::KS3; ks++) v += XBP[(ks * CW + oc[r]) * NZ + oi];
             xb[r] = v;
         }
         // (the next evaluation writes DZ3 = DZ1's rows: every wave's reads of DZ1 ended before the barrier above; XBP = DZ2's rows
@@ -608,7 +625,7 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
             const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
             swp = 0;
 #pragma unroll
-            for (int r = 0; r < S::OWN; r++) swp |= (u32)((swtape[ri * 32 + oc[r]] >> oi) & 3ull) << (2 * r);
+            for (int r = 0; r < S::OWN; r++) swp |= (u32)((swtape[ri * CW + oc[r]] >> oi) & 3ull) << (2 * r);
         }
     };
 
@@ -724,79 +741,90 @@ bool fc_supported(const DevModel& m, int stepper) {
     return m.acts[0] == COLNDE_ACT_RELU && m.acts[1] == COLNDE_ACT_RELU && m.acts[2] == COLNDE_ACT_IDENTITY;
 }
 
-size_t fc_image_floats(int Nz) { return Nz == 64 ? Fc<64>::IMG : Fc<32>::IMG; }
+size_t fc_image_floats(int Nz) { return Nz == 64 ? Fc<64>::IMG : Fc<32>::IMG; }        // (the same for both tile widths)
 size_t fc_bias_floats(int Nz) { return Nz == 64 ? Fc<64>::BIAS : Fc<32>::BIAS; }
 size_t fc_record_row_floats(int Nz) { return Nz == 64 ? Fc<64>::R : Fc<32>::R; }
 
-template <int NZ> static size_t fc_lds_fwd() { return (size_t)(32 * Fc<NZ>::LDX + 2 * 32 * Fc<NZ>::LDH + Fc<NZ>::BIAS) * sizeof(float); }
-template <int NZ> static size_t fc_lds_adj() { return (size_t)(2 * 32 * Fc<NZ>::LDH) * sizeof(float); }
+template <int NZ, int CW> static size_t fc_lds_fwd() { return (size_t)(CW * Fc<NZ, CW>::LDX + 2 * CW * Fc<NZ, CW>::LDH + Fc<NZ, CW>::BIAS) * sizeof(float); }
+template <int NZ, int CW> static size_t fc_lds_adj() { return (size_t)(2 * CW * Fc<NZ, CW>::LDH) * sizeof(float); }
 
-// the instantiated (model, stepper) pairs: FreeConvectionNDE x RK4; ConvectiveAdjustmentNDE x {RK4, RKC2}
-#define FC_FOR_EACH_FWD(M) M(64, true, false, false) M(64, false, false, false) M(32, true, false, false) M(32, false, false, false) \
-                           M(64, true, true, false) M(64, false, true, false) M(32, true, true, false) M(32, false, true, false)     \
-                           M(64, true, true, true) M(64, false, true, true) M(32, true, true, true) M(32, false, true, true)
-#define FC_FOR_EACH_ADJ(M) M(64, false, false) M(32, false, false) M(64, true, false) M(32, true, false) M(64, true, true) M(32, true, true)
+// the instantiated (levels, tile width) x (model, stepper) combinations: FreeConvectionNDE x RK4; ConvectiveAdjustmentNDE x {RK4, RKC2}
+#define FC_FOR_EACH_SHAPE(M, ...) M(64, 32, __VA_ARGS__) M(32, 32, __VA_ARGS__) M(64, 16, __VA_ARGS__) M(32, 16, __VA_ARGS__)
+#define FC_FOR_EACH_FWD(M) FC_FOR_EACH_SHAPE(M, true, false, false) FC_FOR_EACH_SHAPE(M, false, false, false) \
+                           FC_FOR_EACH_SHAPE(M, true, true, false) FC_FOR_EACH_SHAPE(M, false, true, false)   \
+                           FC_FOR_EACH_SHAPE(M, true, true, true) FC_FOR_EACH_SHAPE(M, false, true, true)
+#define FC_FOR_EACH_ADJ(M) FC_FOR_EACH_SHAPE(M, false, false) FC_FOR_EACH_SHAPE(M, true, false) FC_FOR_EACH_SHAPE(M, true, true)
 
 hipError_t fc_set_kernel_attributes() {
     hipError_t e;
-#define FC_ATTR_F(N, T, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_forward_kernel<N, T, C, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<N>())) != hipSuccess) return e;
-#define FC_ATTR_A(N, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_adjoint_kernel<N, C, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_adj<N>())) != hipSuccess) return e;
+#define FC_ATTR_F(N, W, T, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_forward_kernel<N, W, T, C, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<N, W>())) != hipSuccess) return e;
+#define FC_ATTR_A(N, W, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_adjoint_kernel<N, W, C, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_adj<N, W>())) != hipSuccess) return e;
+#define FC_ATTR_I(N, W, X) if ((e = hipFuncSetAttribute((const void*)(fc_infer_kernel<N, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<N, W>())) != hipSuccess) return e;
     FC_FOR_EACH_FWD(FC_ATTR_F)
-    if ((e = hipFuncSetAttribute((const void*)(fc_infer_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<64>())) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)(fc_infer_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<32>())) != hipSuccess) return e;
     FC_FOR_EACH_ADJ(FC_ATTR_A)
+    FC_FOR_EACH_SHAPE(FC_ATTR_I, 0)
 #undef FC_ATTR_F
 #undef FC_ATTR_A
+#undef FC_ATTR_I
     return hipSuccess;
 }
 
-hipError_t fc_launch_infer(const DevModel& m, const float* imgf, const float* bias, const float* T, const float* top_flux, float inv_dz,
-                           float* out, int n_col, hipStream_t stream) {
-    if (n_col < 1) return hipErrorInvalidValue;
-    const int n_tiles = (n_col + 31) / 32;
-    const dim3 grid(n_tiles < 512 ? n_tiles : 512), block(256);                  // two workgroups per CU, each walking over its tiles
-    if (m.Nz == 64) hipLaunchKernelGGL(fc_infer_kernel<64>, grid, block, fc_lds_fwd<64>(), stream, imgf, bias, T, top_flux, m.mu_T, 1.0f / m.sig_T,
-                                       m.sig_wT, m.mu_wT, inv_dz, out, n_col);
-    else hipLaunchKernelGGL(fc_infer_kernel<32>, grid, block, fc_lds_fwd<32>(), stream, imgf, bias, T, top_flux, m.mu_T, 1.0f / m.sig_T, m.sig_wT,
-                            m.mu_wT, inv_dz, out, n_col);
-    return hipGetLastError();
+// tile width for a problem of n_col columns: 16 while 32-column tiles could not put a workgroup on every CU twice over (COLNDE_FC_CW=16|32 forces)
+int fc_tile_width(int n_col) {
+    const char* e = getenv("COLNDE_FC_CW");
+    if (e && (atoi(e) == 16 || atoi(e) == 32)) return atoi(e);
+    return n_col <= 4096 ? 16 : 32;
 }
 
-hipError_t fc_launch_pack(const DevModel& m, const float* w, float* imgf, float* imgb, float* bias, hipStream_t stream) {
+hipError_t fc_launch_pack(const DevModel& m, int cw, const float* w, float* imgf, float* imgb, float* bias, hipStream_t stream) {
     FcOffsets o;
     for (int l = 0; l < 3; l++) { o.w[l] = m.w_off[l]; o.b[l] = m.b_off[l]; }
-    if (m.Nz == 64) hipLaunchKernelGGL(fc_pack_kernel<64>, dim3(256), dim3(256), 0, stream, o, w, imgf, imgb, bias);
-    else hipLaunchKernelGGL(fc_pack_kernel<32>, dim3(128), dim3(256), 0, stream, o, w, imgf, imgb, bias);
-    return hipGetLastError();
+    bool launched = false;
+#define FC_PACK(N, W, X) if (!launched && m.Nz == N && cw == W) { hipLaunchKernelGGL((fc_pack_kernel<N, W>), dim3(N == 64 ? 256 : 128), dim3(256), 0, stream, o, w, imgf, imgb, bias); launched = true; }
+    FC_FOR_EACH_SHAPE(FC_PACK, 0)
+#undef FC_PACK
+    return launched ? hipGetLastError() : hipErrorInvalidValue;
 }
 
-hipError_t fc_launch_forward(const DevModel& m, const float* imgf, const float* bias, const float* x0, size_t x0_stride, const float* bcs,
+hipError_t fc_launch_infer(const DevModel& m, int cw, const float* imgf, const float* bias, const float* T, const float* top_flux, float inv_dz,
+                           float* out, int n_col, hipStream_t stream) {
+    if (n_col < 1) return hipErrorInvalidValue;
+    const int n_tiles = (n_col + cw - 1) / cw;
+    const dim3 grid(n_tiles < 512 ? n_tiles : 512), block(256);                  // two workgroups per CU, each walking over its tiles
+    bool launched = false;
+#define FC_INF(N, W, X) if (!launched && m.Nz == N && cw == W) { hipLaunchKernelGGL((fc_infer_kernel<N, W>), grid, block, (fc_lds_fwd<N, W>()), stream, imgf, bias, T, top_flux, m.mu_T, 1.0f / m.sig_T, m.sig_wT, m.mu_wT, inv_dz, out, n_col); launched = true; }
+    FC_FOR_EACH_SHAPE(FC_INF, 0)
+#undef FC_INF
+    return launched ? hipGetLastError() : hipErrorInvalidValue;
+}
+
+hipError_t fc_launch_forward(const DevModel& m, int cw, const float* imgf, const float* bias, const float* x0, size_t x0_stride, const float* bcs,
                              const float* save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float* sol, float* dwtape,
                              unsigned int* masks, unsigned long long* swtape, int n_col, hipStream_t stream) {
     if (n_col < 1 || iv_begin < 0 || iv_end > n_save - 1 || iv_begin >= iv_end || tape_iv0 < iv_begin || tape_iv0 >= iv_end) return hipErrorInvalidValue;
-    const dim3 grid((n_col + 31) / 32), block(256);
+    const dim3 grid((n_col + cw - 1) / cw), block(256);
     const float CN = m.C_fc * (float)m.Nz, caKN = m.ca_K * (float)m.Nz;
     const bool tape = dwtape != nullptr, ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE, rk = m.rkc != nullptr;
     if (tape && (!masks || (ca && !swtape))) return hipErrorInvalidValue;
     if (rk && !ca) return hipErrorInvalidValue;
     bool launched = false;
-#define FC_FWD(N, T, C, K)                                                                                                                        \
-    if (!launched && m.Nz == N && tape == T && ca == C && rk == K) {                                                                              \
-        hipLaunchKernelGGL((fc_forward_kernel<N, T, C, K>), grid, block, fc_lds_fwd<N>(), stream, imgf, bias, x0, x0_stride, bcs, save_times, n_save, \
-                           iv_begin, iv_end, tape_iv0, substeps, CN, caKN, m.nst, m.rkc, sol, dwtape, masks, swtape, n_col);                      \
-        launched = true;                                                                                                                          \
+#define FC_FWD(N, W, T, C, K)                                                                                                                        \
+    if (!launched && m.Nz == N && cw == W && tape == T && ca == C && rk == K) {                                                                      \
+        hipLaunchKernelGGL((fc_forward_kernel<N, W, T, C, K>), grid, block, (fc_lds_fwd<N, W>()), stream, imgf, bias, x0, x0_stride, bcs, save_times, n_save, \
+                           iv_begin, iv_end, tape_iv0, substeps, CN, caKN, m.nst, m.rkc, sol, dwtape, masks, swtape, n_col);                         \
+        launched = true;                                                                                                                             \
     }
     FC_FOR_EACH_FWD(FC_FWD)
 #undef FC_FWD
     return launched ? hipGetLastError() : hipErrorInvalidValue;
 }
 
-hipError_t fc_launch_adjoint(const DevModel& m, const float* imgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
+hipError_t fc_launch_adjoint(const DevModel& m, int cw, const float* imgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
                              const float* sol, const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape,
                              float w_loss, float* lam_io, float* slab, int n_col, hipStream_t stream) {
     if (n_col < 1 || !dwtape || !masks || iv_begin < 0 || iv_end > n_save - 1 || iv_begin >= iv_end) return hipErrorInvalidValue;
     if ((iv_begin > 0 || iv_end < n_save - 1) && !lam_io) return hipErrorInvalidValue;
-    const dim3 grid((n_col + 31) / 32), block(256);
+    const dim3 grid((n_col + cw - 1) / cw), block(256);
     const float CN = m.C_fc * (float)m.Nz, caKN = m.ca_K * (float)m.Nz;
     const bool ca = m.model == COLNDE_MODEL_CONV_ADJ_NDE, rk = m.rkc != nullptr;
     if ((ca && !swtape) || (rk && !ca)) return hipErrorInvalidValue;
@@ -804,11 +832,11 @@ hipError_t fc_launch_adjoint(const DevModel& m, const float* imgb, const float* 
     for (int l = 0; l < 3; l++) go.b[l] = m.b_off[l];
     go.n_params = m.n_params;
     bool launched = false;
-#define FC_ADJ(N, C, K)                                                                                                                           \
-    if (!launched && m.Nz == N && ca == C && rk == K) {                                                                                           \
-        hipLaunchKernelGGL((fc_adjoint_kernel<N, C, K>), grid, block, fc_lds_adj<N>(), stream, imgb, save_times, n_save, iv_begin, iv_end, substeps, \
-                           CN, caKN, m.nst, m.rkc, sol, truth, dwtape, masks, swtape, w_loss, lam_io, slab, go, n_col);                           \
-        launched = true;                                                                                                                          \
+#define FC_ADJ(N, W, C, K)                                                                                                                           \
+    if (!launched && m.Nz == N && cw == W && ca == C && rk == K) {                                                                                   \
+        hipLaunchKernelGGL((fc_adjoint_kernel<N, W, C, K>), grid, block, (fc_lds_adj<N, W>()), stream, imgb, save_times, n_save, iv_begin, iv_end, substeps, \
+                           CN, caKN, m.nst, m.rkc, sol, truth, dwtape, masks, swtape, w_loss, lam_io, slab, go, n_col);                              \
+        launched = true;                                                                                                                             \
     }
     FC_FOR_EACH_ADJ(FC_ADJ)
 #undef FC_ADJ

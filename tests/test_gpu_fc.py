@@ -14,8 +14,10 @@ from tests.test_gpu_parity import _record, _rel, FC_SOL_ATOL, FC_LOSS_RTOL, FC_G
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("cw", [16, 32])
 @pytest.mark.parametrize("Nz,ncol", [(32, 1), (32, 19), (32, 64), (32, 97), (64, 5), (64, 32), (64, 45), (64, 130)])
-def test_fc32_against_oracle_and_tile16(Nz, ncol):
+def test_fc32_against_oracle_and_tile16(Nz, ncol, cw, monkeypatch):
+    monkeypatch.setenv("COLNDE_FC_CW", str(cw))       # both tile widths at every size (default: 16 columns up to 4,096, 32 above)
     p = synthetic.free_convection_problem(ncol, Nz=Nz, n_save=5, substeps=2, t_end=0.01)
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
     sc = O.default_loss_scalings(p.cfg)
@@ -36,7 +38,7 @@ def test_fc32_against_oracle_and_tile16(Nz, ncol):
         if eng == 0:
             assert plan["engine"] == ENGINE_FC32 and plan["dw_taped"] and plan["n_blocks"] == 1 and plan["block_columns"] == (ncol + 31) // 32 * 32
     sol_g, tot_g, grad_g = res[0]
-    _record("fc32/%d/%d" % (Nz, ncol), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g),
+    _record("fc32/cw%d/%d/%d" % (cw, Nz, ncol), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g),
             sol_abs_vs_tile16=np.abs(sol_g - res[ENGINE_TILE16][0]).max(), grad_rel_vs_tile16=_rel(grad_g, res[ENGINE_TILE16][2].astype(np.float64)))
     assert np.abs(sol_g - sol).max() < FC_SOL_ATOL
     assert np.isclose(tot_g, tot, rtol=FC_LOSS_RTOL)
@@ -51,8 +53,9 @@ def test_fc32_against_oracle_and_tile16(Nz, ncol):
     assert _rel(grad_g, res[ENGINE_TILE16][2].astype(np.float64)) < 0.25 * FC_GRAD_REL
 
 
+@pytest.mark.parametrize("cw", [16, 32])
 @pytest.mark.parametrize("Nz", [32, 64])
-def test_fc32_column_blocks_are_additive(Nz, monkeypatch):
+def test_fc32_column_blocks_are_additive(Nz, cw, monkeypatch):
     """COLNDE_FC_BLOCK=32: 75 columns run forward -> adjoint -> dW GEMM in three passes through tapes sized for one 32-column tile."""
     p = synthetic.free_convection_problem(75, Nz=Nz, n_save=5, substeps=2, t_end=0.01)
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
@@ -62,6 +65,7 @@ def test_fc32_column_blocks_are_additive(Nz, monkeypatch):
         nde.set_problem(p.x0, p.bcs, truth)
         one = nde.loss_grad(p.weights, sc)
     monkeypatch.setenv("COLNDE_FC_BLOCK", "32")
+    monkeypatch.setenv("COLNDE_FC_CW", str(cw))
     with colnde.ColumnNDE(p.cfg, 75) as nde:
         nde.set_problem(p.x0, p.bcs, truth)
         blk = nde.loss_grad(p.weights, sc)
@@ -107,10 +111,12 @@ def test_fc32_selection_and_refusals(monkeypatch):
         assert nde.engine == ENGINE_TILE16
 
 
+@pytest.mark.parametrize("cw", [16, 32])
 @pytest.mark.parametrize("Nz,ncol", [(32, 19), (32, 70), (64, 45)])
-def test_fc32_conv_adj_nde_rk4_against_oracle_and_tile16(Nz, ncol):
+def test_fc32_conv_adj_nde_rk4_against_oracle_and_tile16(Nz, ncol, cw, monkeypatch):
     """ConvectiveAdjustmentNDE (convective_adjustment_nde.jl:33-48) on the fc32 engine, sub-stepped RK4, from a profile with an inverted
     layer so that the min(0, K dT/dz) switch is live: the exact discrete adjoint (every stage's own switch pattern, taped as bits)."""
+    monkeypatch.setenv("COLNDE_FC_CW", str(cw))
     p = synthetic.free_convection_problem(ncol, Nz=Nz, n_save=5, substeps=20 * (Nz // 32) ** 2, convective_adjustment=True, t_end=0.01)
     x0 = p.x0.copy()
     x0[:, Nz // 2:Nz // 2 + 6] = x0[:, Nz // 2:Nz // 2 + 6][:, ::-1]
@@ -130,7 +136,7 @@ def test_fc32_conv_adj_nde_rk4_against_oracle_and_tile16(Nz, ncol):
         res[eng] = (sol_g, tot_g, grad_g)
     sol_g, tot_g, grad_g = res[0]
     e32 = (np.abs(sol32 - sol).max(), abs(tot32 - tot) / tot, _rel(g32, g))
-    _record("fc32/ca_rk4/%d/%d" % (Nz, ncol), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g),
+    _record("fc32/ca_rk4/cw%d/%d/%d" % (cw, Nz, ncol), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g),
             grad_rel_f32=_rel(grad_g, g32.astype(np.float64)), grad_rel_oracle32_vs_64=e32[2], grad_rel_vs_tile16=_rel(grad_g, res[ENGINE_TILE16][2].astype(np.float64)))
     # layers sitting on the kink make float32 part from float64: the yardstick is the float32 oracle's own distance
     assert np.abs(sol_g - sol).max() < 3 * e32[0] + 2 * FC_SOL_ATOL
@@ -138,10 +144,12 @@ def test_fc32_conv_adj_nde_rk4_against_oracle_and_tile16(Nz, ncol):
     assert _rel(grad_g, g) < 3 * e32[2] + FC_GRAD_REL
 
 
+@pytest.mark.parametrize("cw", [16, 32])
 @pytest.mark.parametrize("Nz,ncol,case", [(32, 37, "stratified"), (64, 33, "stratified"), (64, 5, "inverted")])
-def test_fc32_conv_adj_nde_rkc2_against_oracle_and_tile16(Nz, ncol, case):
+def test_fc32_conv_adj_nde_rkc2_against_oracle_and_tile16(Nz, ncol, case, cw, monkeypatch):
     """ConvectiveAdjustmentNDE under the stabilised RKC2 stepper (the configs[3] half the reference integrates with ROCK4) on the fc32
     engine: the oracle's RKC2 recurrence and its one-switch-pattern-per-step pullback, as in tile16 (tests/test_gpu_rkc.py)."""
+    monkeypatch.setenv("COLNDE_FC_CW", str(cw))
     p = synthetic.free_convection_problem(ncol, Nz=Nz, n_save=9, substeps=2, convective_adjustment=True, t_end=0.06)
     cfg = p.cfg.with_(stepper="rkc2")
     x0 = p.x0.copy()
@@ -162,7 +170,7 @@ def test_fc32_conv_adj_nde_rkc2_against_oracle_and_tile16(Nz, ncol, case):
         res[eng] = (sol_g, tot_g, grad_g)
     sol_g, tot_g, grad_g = res[0]
     e32 = (np.abs(sol32 - sol).max(), abs(tot32 - tot) / tot, _rel(g32, g))
-    _record("fc32/ca_rkc2/%d/%s" % (Nz, case), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g),
+    _record("fc32/ca_rkc2/cw%d/%d/%s" % (cw, Nz, case), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g),
             sol_abs_oracle32_vs_64=e32[0], loss_rel_oracle32_vs_64=e32[1], grad_rel_oracle32_vs_64=e32[2],
             sol_abs_vs_tile16=np.abs(sol_g - res[ENGINE_TILE16][0]).max(), grad_rel_vs_tile16=_rel(grad_g, res[ENGINE_TILE16][2].astype(np.float64)))
     assert np.isfinite(sol_g).all() and np.isfinite(grad_g).all()
@@ -171,10 +179,12 @@ def test_fc32_conv_adj_nde_rkc2_against_oracle_and_tile16(Nz, ncol, case):
     assert _rel(grad_g, g) < 5 * e32[2] + FC_GRAD_REL
 
 
+@pytest.mark.parametrize("cw", [16, 32])
 @pytest.mark.parametrize("nx,ny", [(1, 1), (16, 9), (33, 31), (256, 256)])
-def test_fc32_inference_forcing_against_oracle_and_tile16(nx, ny):
+def test_fc32_inference_forcing_against_oracle_and_tile16(nx, ny, cw, monkeypatch):
     """`compute_neural_network_forcing!` (double_gyre_nn.jl:149-168; BASELINE configs[4]'s 256 x 256 grid included) on the fc32 sections: a
     workgroup walks over 32-column tiles with the A-operand ring streaming across them; against the float64 oracle and against tile16."""
+    monkeypatch.setenv("COLNDE_FC_CW", str(cw))
     cfg, T, top, w = synthetic.inference_problem(nx, ny)
     n = nx * ny
     ref = O.infer_forcing(cfg, T[:4096], top[:4096], w, 1000.0)
@@ -188,12 +198,14 @@ def test_fc32_inference_forcing_against_oracle_and_tile16(nx, ny):
     assert _rel(res[0], res[ENGINE_TILE16].astype(np.float64)) < 1e-6
 
 
+@pytest.mark.parametrize("cw", [16, 32])
 @pytest.mark.parametrize("model,seg,block", [("fc", 3, None), ("fc", 1, None), ("ca_rk4", 2, None), ("ca_rkc2", 3, None), ("fc", 2, 32)])
-def test_fc32_time_segmented_tapes_equal_the_single_pass(model, seg, block, monkeypatch):
+def test_fc32_time_segmented_tapes_equal_the_single_pass(model, seg, block, cw, monkeypatch):
     """When the tapes of all columns do not fit, fc32 cuts the TIME axis instead of the columns (every CU keeps its two workgroups): a tape-less
     forward pass saves the states at the save points, then each segment — from the last to the first — is re-run with tapes from its saved state,
     back-propagated (λ handed on through a device buffer) and contracted.  Restarting at a save point is exact, so the segmented gradient must
     equal the single-pass one to summation order, for every stepper and with column blocks on top (COLNDE_FC_SEG / COLNDE_FC_BLOCK force the cuts)."""
+    monkeypatch.setenv("COLNDE_FC_CW", str(cw))
     ca = model != "fc"
     p = synthetic.free_convection_problem(75, Nz=32, n_save=8, substeps=24 if model == "ca_rk4" else 2, convective_adjustment=ca, t_end=0.02)
     cfg = p.cfg.with_(stepper="rkc2") if model == "ca_rkc2" else p.cfg
