@@ -36,9 +36,10 @@ enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it 
        COLNDE_ENGINE_GENERIC = 1,   /* tile16: 16-column MFMA tiles staged through LDS, any layer sizes / model */
        COLNDE_ENGINE_MFMA = 2,      /* regtile: 32 columns per wavefront resident in registers (static 96-50-20-31 wind-mixing
                                        shape; colnde_create fails if the configuration is not covered) */
-       COLNDE_ENGINE_FC32 = 3 };    /* fc32: 32-column v_mfma_f32_32x32x2_f32 tiles with compile-time shapes for FreeConvectionNDE with the
+       COLNDE_ENGINE_FC32 = 3 };    /* fc32: 32-column v_mfma_f32_32x32x2_f32 tiles (16-column v_mfma_f32_16x16x4_f32 tiles up to 4,096 columns)
+                                       with compile-time shapes for FreeConvectionNDE (RK4) and ConvectiveAdjustmentNDE (RK4, RKC2) with the
                                        reference's network Dense(Nz,4Nz,relu), Dense(4Nz,4Nz,relu), Dense(4Nz,Nz-1)
-                                       (free_convection/train_free_convection_nde.jl:119-121), Nz = 32 | 64, RK4; AUTO picks it for that
+                                       (free_convection/train_free_convection_nde.jl:119-121), Nz = 32 | 64; AUTO picks it for that
                                        shape; colnde_create fails if it is requested for anything else */
 
 enum { COLNDE_STEPPER_RK4 = 0,      /* classical RK4, `substeps` per save interval (what the bench measures) */
