@@ -246,6 +246,98 @@ def other_configs(dev, budget_s=120.0):
     return out
 
 
+def free_convection_workload(args, world, rank, local_rank, dev, comm, dist):
+    """BASELINE configs[3] as an N-GPU run: every rank holds `--columns` (default 16,384 = 65,536 / 4) columns of the 64-level FreeConvectionNDE
+    (64-256-256-63 relu, 129 save points, 4 RK4 sub-steps: fc32 engine), one SUM all-reduce of [grad(98,623); 6 terms; total; 0] per iteration.
+    Same timing contract as the headline: W warm-up steps, K timed steps between barriers, MAX over ranks, rank 0 prints one JSON line."""
+    import torch
+    import colnde
+    from colnde import synthetic
+    ncol = args.columns
+    p = synthetic.free_convection_problem(ncol, Nz=64, seed=synthetic.SEED + rank)
+    pw = synthetic.free_convection_problem(1, Nz=64, n_save=2, seed=synthetic.SEED)          # replicated weights: identical on every rank
+    nde = colnde.ColumnNDE(p.cfg, ncol, device=local_rank)
+    nde.set_global_columns(ncol * world)
+    x0, bcs = torch.from_numpy(p.x0).to(dev), torch.from_numpy(p.bcs).to(dev)
+    w, wt = torch.from_numpy(pw.weights).to(dev), torch.from_numpy(pw.weights_truth).to(dev)
+    nde.set_problem(x0, bcs)
+    truth = nde.forward(wt)
+    nde.set_problem(x0, bcs, truth)
+    out = torch.empty(nde.n_params + 8, dtype=torch.float32, device=dev)
+    sc = [0, 0, 1, 0, 0, 0]
+    sync_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def reduce_(t, op):
+        if comm is not None:
+            comm.allreduce(t, op)
+        elif dist is not None:
+            dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op])
+
+    def step():
+        nde.loss_grad(w, sc, out=out)
+        if comm is not None:
+            comm.allreduce_result(nde, out)
+        elif dist is not None:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        reduce_(sync_buf, "sum")
+        torch.cuda.synchronize()
+
+    spread = None
+    if comm is not None or dist is not None:
+        from colnde.distributed import weights_in_sync
+        ok, spread = weights_in_sync(w, lambda t: reduce_(t, "max"))
+        if not ok:
+            raise SystemExit("bench.py: the ranks' weight vectors differ (checksum spread %.3e)" % spread)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    nde.set_profiling(True)
+    nde.reset_kernel_times()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    te = torch.tensor([time.perf_counter() - t0], dtype=torch.float32, device=dev)
+    reduce_(te, "max")
+    torch.cuda.synchronize()
+    elapsed = float(te.item())
+    km = {k: nde.kernel_time(k)[0] / max(nde.kernel_time(k)[1], 1) for k in ("forward", "adjoint", "dw1", "reduce")}
+    res = out.cpu().numpy()
+    if rank == 0:
+        cs = ncol * world * p.cfg.n_steps
+        mlp = 2 * (64 * 256 + 256 * 256 + 256 * 63)
+        flop = 3 * 4 * mlp                                                  # forward + dX + dW per column-timestep (SURVEY §8d)
+        per_gpu_tf = flop * cs / (elapsed / args.steps) / 1e12 / world
+        dom = max(("forward", "adjoint", "dw1"), key=lambda k: km[k])
+        dom_tf = 4 * mlp * ncol * p.cfg.n_steps / (km[dom] * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "column-timesteps/sec (fwd+adjoint), 64-level free-convection NDE (BASELINE configs[3])",
+            "value": cs * args.steps / elapsed, "unit": "column-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "free_convection NDE training (BASELINE configs[3]: 65536 columns x 64 levels on 4 GPUs): %d columns/GPU x 64 levels x 129 save "
+                                   "points x 4 RK4 sub-steps, FreeConvectionNDE, 64-256-256-63 relu, single MSE loss" % ncol,
+                       "columns_per_gpu": ncol, "levels": 64, "rk4_steps": p.cfg.n_steps, "n_params": p.cfg.n_params, "parallelism": "columns sharded x%d" % world,
+                       "exchange": "none (one rank)" if (comm is None and dist is None) else ("colnde_comm (RCCL behind the C ABI)" if comm is not None else "torch.distributed nccl (RCCL)")},
+            "roofline": {"kernel": {"forward": "fc_forward_kernel", "adjoint": "fc_adjoint_kernel", "dw1": "dw_gemm_lds_kernel"}[dom], "bound": "mfma",
+                         "achieved": dom_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": km[dom], "kernel_ms": km,
+                         "whole_step": {"algorithmic_flop_per_column_timestep": flop, "achieved": per_gpu_tf, "unit": "TFLOP/s per GPU",
+                                        "frac": per_gpu_tf / PEAK_FP32_MFMA_TFLOPS},
+                         "plan": nde.plan()},
+            "multi_gpu": None if spread is None else {"allreduce_floats": nde.n_params + 8, "weights_checksum_spread_over_ranks": spread},
+            "cpu_baseline": None, "loss_total": float(res[nde.n_params + 6]), "grad_l2": float(np.linalg.norm(res[:nde.n_params])),
+        }), flush=True)
+    nde.close()
+    if comm is not None:
+        barrier()
+        comm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def launcher_command(n_gpus, argv):
     """The command `python bench.py --gpus N ...` turns itself into: one rank per GPU under torch.distributed.run.  `--standalone`
     lets the launcher bind its own rendezvous port (no probe-then-reuse race); `--local-addr 127.0.0.1` because the box's hostname
@@ -273,11 +365,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--columns", type=int, default=32768, help="columns per GPU (weak scaling); 32768 = one 32-column wavefront per SIMD")
+    ap.add_argument("--columns", type=int, default=None, help="columns per GPU (weak scaling); default 32768 (wind_mixing: one 32-column wavefront per SIMD) or 16384 (free_convection)")
     ap.add_argument("--frames", type=int, default=289, help="saved frames (2-day suite: 289)")
     ap.add_argument("--substeps", type=int, default=2)
     ap.add_argument("--global-columns", type=int, default=0, help="N > 1: a GLOBAL column count dealt over the ranks in contiguous, possibly "
                     "ragged shards (colnde.distributed.shard_columns) instead of --columns per GPU: strong scaling, exercises uneven shards")
+    ap.add_argument("--workload", choices=["wind_mixing", "free_convection"], default="wind_mixing",
+                    help="wind_mixing (default): the headline, BASELINE's metric.  free_convection: BASELINE configs[3] on N GPUs — FreeConvectionNDE, --columns "
+                         "(default 16384) columns per GPU x 64 levels x 512 RK4 steps, one RCCL all-reduce of the 98,631-float result buffer per iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the block that times the other BASELINE configs after the headline (N = 1 only)")
     args = ap.parse_args()
@@ -326,6 +421,11 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+
+    if args.columns is None:
+        args.columns = 32768 if args.workload == "wind_mixing" else 16384
+    if args.workload == "free_convection":
+        return free_convection_workload(args, world, rank, local_rank, dev, comm, dist)
 
     ncol = args.columns
     n_global = ncol * world

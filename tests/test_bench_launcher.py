@@ -64,3 +64,13 @@ def test_visible_gpu_count_reads_the_kfd_topology_and_the_visibility_lists(tmp_p
     assert visible_gpu_count(str(root), env={"HIP_VISIBLE_DEVICES": "0,1,2,3,4,5,6,7"}) == 4   # a list cannot add devices
     assert visible_gpu_count(str(tmp_path / "absent"), env={}) is None                          # no driver here: the ranks find out
     assert visible_gpu_count(str(tmp_path / "absent"), env={"HIP_VISIBLE_DEVICES": ""}) == 0
+
+
+def test_workload_switch_reaches_the_ranks_and_the_default_stays_the_headline():
+    """`--workload free_convection` (BASELINE configs[3] on N GPUs) is passed through to every rank; without it bench.py parses to the
+    wind-mixing headline."""
+    import bench
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--workload", "free_convection", "--steps", "2"])
+    assert cmd[-4:] == ["--workload", "free_convection", "--steps", "2"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    src = open(bench.__file__).read()
+    assert 'choices=["wind_mixing", "free_convection"], default="wind_mixing"' in src
