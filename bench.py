@@ -604,6 +604,32 @@ def main():
             "loss_total": float(res[nde.n_params + 6]),
             "grad_l2": float(np.linalg.norm(res[:nde.n_params])),
         }
+        line["roofline"]["dw1_kernel"]["mode"] = "bf16x3 exact split (COLNDE_DW_SPLIT=1)" if os.environ.get("COLNDE_DW_SPLIT", "0") not in ("", "0") else "f32 MFMA"
+        if world == 1 and regtile and not args.no_configs and os.environ.get("COLNDE_DW_SPLIT", "0") in ("", "0"):
+            # opt-in variant, outside the timed region: the same step with dW1 contracted on the bf16 pipe from exact three-way operand splits
+            # (rt_dw1_split_kernel); the default above is the exact-f32 MFMA kernel
+            g32 = out[:nde.n_params].clone()
+            os.environ["COLNDE_DW_SPLIT"] = "1"
+            try:
+                step()
+                torch.cuda.synchronize()
+                nde.set_profiling(True)
+                nde.reset_kernel_times()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t_split = (time.perf_counter() - t0) / 3
+                ms_dw1s, n_dw1s = nde.kernel_time("dw1")
+                gs = out[:nde.n_params]
+                line["opt_in"] = {"dw1_split_bf16x3": {
+                    "switch": "COLNDE_DW_SPLIT=1", "ms_per_step": t_split * 1e3, "value": colsteps_per_step / t_split,
+                    "dw1_kernel_avg_ms": ms_dw1s / max(n_dw1s, 1),
+                    "gradient_rel_l2_vs_f32_mfma": float((gs.double() - g32.double()).norm() / g32.double().norm()),
+                    "note": "operands split exactly into three bf16 each, six v_mfma_f32_32x32x16_bf16 products, f32 accumulation; not the default"}}
+            finally:
+                nde.set_profiling(False)
+                os.environ["COLNDE_DW_SPLIT"] = "0"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(prob, scal)
         else:

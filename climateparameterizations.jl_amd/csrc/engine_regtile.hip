@@ -1127,6 +1127,148 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// dW1 / db1 on the bf16 matrix pipe with EXACT three-way operand splitting (COLNDE_DW_SPLIT=1; opt-in)
+//
+// A float has 24 significant bits = three bf16 (8 bits each): x = x_h + x_m + x_l exactly, by truncation (x_h = the top half of the
+// word, r = x - x_h is exact, x_m = the top half of r, x_l = r - x_m has at most 8 significant bits).  A product a b is then the nine
+// products of the parts, each EXACT in fp32 (8 x 8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the six of them down to
+// 2^-16 are kept (hh, hm, mh, hl, lh, mm), the three dropped ones are below 2^-23 |a b| together — the size of ONE fp32 rounding of
+// the product, which the fp32 MFMA chain commits at every accumulation anyway.  Six 32-cycle instructions cover 16 k-steps that cost
+// eight 64-cycle v_mfma_f32_32x32x2_f32: 192 cycles instead of 512.
+//
+// Same tapes, same LDS-DMA gather and the same [col][row] tiles as rt_dw1_kernel.  The unit is HALF an item (16 columns = one
+// k-block): lane (row j, kh) contracts k = 8 kh + c with column c of quarter 2 H + kh, i.e. it reads eight floats of ONE quarter
+// buffer (conflict-free, stride 32) per tile, splits them in registers (5.5 vector operations per value, issued under the MFMAs) and
+// feeds 90 MFMAs.  Ring of four quarter buffers as before: the two quarters of half H + 2 are fetched into the slots of half H as soon
+// as its operands are in registers.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Bf3 { u32x4 h, m, l; };
+
+__device__ __forceinline__ Bf3 bf3_split8(const float* x) {
+    Bf3 o;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const float a = x[2 * p], b = x[2 * p + 1];
+        const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+        const float la = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), lb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+        // (hi16(b) << 16) | hi16(a): element 2p in the low half
+        o.h[p] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+        o.m[p] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+        o.l[p] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+    }
+    return o;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// c += A B over one 16-deep k-block, fp32-grade: smallest products first
+__device__ __forceinline__ f32x16 mfma_bf3(const Bf3& a, const Bf3& b, f32x16 c) {
+    c = mfma_bf(a.m, b.m, c);
+    c = mfma_bf(a.l, b.h, c);
+    c = mfma_bf(a.h, b.l, c);
+    c = mfma_bf(a.m, b.h, c);
+    c = mfma_bf(a.h, b.m, c);
+    c = mfma_bf(a.h, b.h, c);
+    return c;
+}
+
+__global__ void __launch_bounds__(256)
+rt_dw1_split_kernel(DevModel m, const float* __restrict__ tape, const float* __restrict__ tape2, long n_items,
+                    float* __restrict__ slab_rows) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    float* buf = rt_smem + wave * RT_DW1_LDS;
+    const long gw = (long)blockIdx.x * RT_WAVES + wave, GW = (long)gridDim.x * RT_WAVES;
+    f32x16 gW1[5][3];
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) gW1[mt][q] = (f32x16)(0.0f);
+    float b1acc[5] = {0, 0, 0, 0, 0};
+    const int NQ = gw < n_items ? 4 * (int)((n_items - gw + GW - 1) / GW) : 0;       // this wave's quarters
+    const int soff = ((lane >> 1) & 3) * 256 + ((lane & 1) * 32 + (lane >> 3)) * 4;  // the gather of rt_dw1_kernel
+    auto issue = [&](int Q, int ring) {
+        const int Qc = Q < NQ ? Q : NQ - 1;
+        const size_t item = (size_t)(gw + (long)(Qc >> 2) * GW);
+        const float* sx = tape + item * 3072 + soff + (Qc & 3) * 32;
+        const float* sz = tape2 + item * RT_TAPE2 + soff + (Qc & 3) * 32;
+#pragma unroll
+        for (int T = 0; T < 3; T++) __builtin_amdgcn_global_load_lds(sx + T * 1024, buf + ring * 2048 + T * 256, 16, 0, RT_DMA_AUX);
+#pragma unroll
+        for (int T = 0; T < 5; T++) __builtin_amdgcn_global_load_lds(sz + T * 1024, buf + ring * 2048 + (3 + T) * 256, 16, 0, RT_DMA_AUX);
+    };
+    const float* rd = buf + h * 2048 + j;        // lane half kh reads the quarter buffer (slot0 + kh)
+    float raw[2][8][8];                          // [set][tile][column of the quarter]
+    auto read_half = [&](int set, int slot0) {
+#pragma unroll
+        for (int T = 0; T < 8; T++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) raw[set][T][c] = rd[slot0 * 2048 + T * 256 + c * 32];
+    };
+    // Pipeline: while half H is multiplied, half H + 1 sits in registers (read at the top of H) and halves H + 2, H + 3 are in flight —
+    // a half's two slots are refilled as soon as its operands have been read (the whole ring is in flight during the MFMAs).
+    if (NQ > 0) {
+        issue(0, 0);
+        issue(1, 1);
+        issue(2, 2);
+        issue(3, 3);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        read_half(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue(4, 0);
+        issue(5, 1);
+    }
+    for (int Qb = 0; Qb < NQ; Qb += 4) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int cur = u;
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // half H + 1 has landed (H + 2 may still be in flight)
+            read_half(cur ^ 1, 2 * (u ^ 1));
+            __builtin_amdgcn_sched_barrier(0);
+            Bf3 X[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) X[q] = bf3_split8(raw[cur][q]);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... and is in registers: its slots take half H + 3
+            issue(Qb + 2 * u + 6, 2 * (u ^ 1));
+            issue(Qb + 2 * u + 7, 2 * (u ^ 1) + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 5; mt++) {
+                const Bf3 Z = bf3_split8(raw[cur][3 + mt]);
+#pragma unroll
+                for (int q = 0; q < 3; q++) gW1[mt][q] = mfma_bf3(Z, X[q], gW1[mt][q]);
+                const float* z = raw[cur][3 + mt];
+                b1acc[mt] += ((z[0] + z[1]) + (z[2] + z[3])) + ((z[4] + z[5]) + (z[6] + z[7]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* out = slab_rows + (size_t)gw * (m.n_params + 8);
+#pragma unroll
+    for (int mt = 0; mt < 5; mt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int G = mt * 16 + r;
+            if (G < 75) {
+                const int n = G / 25, f = 2 * (G % 25) + h;
+#pragma unroll
+                for (int q = 0; q < 3; q++) out[n * m.net_size + m.w_off[0] + (q * 32 + j) * 50 + f] = gW1[mt][q][r];
+            }
+        }
+        const float s1 = b1acc[mt] + swap32(b1acc[mt], h);
+        const int r_j = (j & 3) + 4 * (j >> 3), h_j = (j >> 2) & 1;
+        const int G = mt * 16 + r_j;
+        if (h == 0 && G < 75) out[(G / 25) * m.net_size + m.b_off[0] + 2 * (G % 25) + h_j] = s1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward solve on 16-column wave tiles (v_mfma_f32_16x16x4_f32), TWO wavefronts per SIMD
 //
 // Same idea as rt_forward_kernel with half the per-wave state: lane (j = lane & 15, g = lane >> 4) holds rows 4g..4g+3 of
@@ -3028,6 +3170,7 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true, true>));
     RT_SETATTR(rt_dw1_kernel);
+    RT_SETATTR(rt_dw1_split_kernel);
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
@@ -3223,8 +3366,13 @@ hipError_t rt_launch_dw1(const DevModel& m, const float* tape, const float* tape
                          hipStream_t stream) {
     const long items = (long)rt_n_wtiles(n_col) * n_steps * 4;
     const int waves = rt_dw1_waves(n_col, n_steps);
-    hipLaunchKernelGGL(rt_dw1_kernel, dim3(waves / RT_WAVES), dim3(64 * RT_WAVES), RT_WAVES * RT_DW1_LDS * sizeof(float), stream, m, tape,
-                       tape2, items, slab_rows);
+    const char* es = getenv("COLNDE_DW_SPLIT");      // 1: dW1 on the bf16 pipe with exact three-way operand splitting (opt-in)
+    if (es && atoi(es) != 0)
+        hipLaunchKernelGGL(rt_dw1_split_kernel, dim3(waves / RT_WAVES), dim3(64 * RT_WAVES), RT_WAVES * RT_DW1_LDS * sizeof(float), stream, m,
+                           tape, tape2, items, slab_rows);
+    else
+        hipLaunchKernelGGL(rt_dw1_kernel, dim3(waves / RT_WAVES), dim3(64 * RT_WAVES), RT_WAVES * RT_DW1_LDS * sizeof(float), stream, m, tape,
+                           tape2, items, slab_rows);
     return hipGetLastError();
 }
 

@@ -366,7 +366,8 @@ def test_regtile_engine_against_oracle(name):
 
 
 @pytest.mark.parametrize("env", [{"COLNDE_RT_ZTAPE": "0"}, {"COLNDE_RT_FWD": "32"}, {"COLNDE_RT_BLOCK": "32"},
-                                 {"COLNDE_RT_BLOCK": "64", "COLNDE_RT_ZTAPE": "0"}])
+                                 {"COLNDE_RT_BLOCK": "64", "COLNDE_RT_ZTAPE": "0"}, {"COLNDE_DW_SPLIT": "1"},
+                                 {"COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}])
 def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
     """The variants behind environment switches: no Z1 tape (the adjoint recomputes layer 1), the 32-column forward kernel
     (one wave per SIMD; implies no Z1 tape), and the column-blocked gradient path that problems larger than the free HBM
@@ -386,6 +387,36 @@ def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
     assert np.abs(sol_g - sol).max() < SOL_ATOL
     np.testing.assert_allclose(terms_g, terms, rtol=LOSS_RTOL, atol=1e-12)
     assert _rel(grad_g, g) < GRAD_REL
+
+
+def test_dw1_on_the_bf16_pipe_with_exact_operand_splitting_is_float32_grade(monkeypatch):
+    """COLNDE_DW_SPLIT=1: rt_dw1_split_kernel contracts the same two tapes with six v_mfma_f32_32x32x16_bf16 products of the exact
+    three-way bf16 splits of both operands instead of v_mfma_f32_32x32x2_f32.  Same handle, same tapes: the layer-1 weight gradient of
+    the two kernels differs by float32 round-off only (stated: 2e-6 relative L2 — the dropped cross terms are below 2^-23 per product),
+    everything else in the gradient is bit-identical, and against the float64 oracle the split kernel is as close as the fp32 one
+    (within 1.5x; both are recorded)."""
+    from colnde.nde import ENGINE_REGTILE
+    p = synthetic.wind_mixing_problem(200, n_frames=25, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, _ = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        monkeypatch.setenv("COLNDE_DW_SPLIT", "0")
+        _, _, g32 = nde.loss_grad(p.weights, sc)
+        monkeypatch.setenv("COLNDE_DW_SPLIT", "1")
+        _, _, gsp = nde.loss_grad(p.weights, sc)
+    net = p.cfg.n_params // 3
+    l1 = np.zeros(p.cfg.n_params, bool)
+    for n in range(3):
+        l1[n * net:n * net + 96 * 50 + 50] = True            # Flux.destructure: W1 (50 x 96), b1 (50) lead each net's block
+    np.testing.assert_array_equal(gsp[~l1], g32[~l1])
+    d = _rel(gsp[l1], g32[l1].astype(np.float64))
+    e32, esp = _rel(g32[l1], g[l1]), _rel(gsp[l1], g[l1])
+    _record("test_dw1_split", split_vs_fp32=d, fp32_vs_oracle=e32, split_vs_oracle=esp)
+    assert d < 2e-6
+    assert esp < max(1.5 * e32, 2e-6)
+    assert _rel(gsp, g) < GRAD_REL
 
 
 # ---- the net-split kernels of the latency points (engine AUTO up to 8,192 columns of the regtile shape) -----------------
