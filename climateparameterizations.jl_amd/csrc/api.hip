@@ -441,7 +441,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     ALLOC(h->d_w, m.n_params, float);
     ALLOC(h->d_wf, (size_t)h->pk.pf_net * m.n_nets, float);
     ALLOC(h->d_wb, (size_t)h->pk.pb_net * m.n_nets, float);
-    ALLOC(h->d_wimg, RT_IMG_FLOATS, float);
+    ALLOC(h->d_wimg, RT_IMG_ALLOC, float);
     if (h->use_fc) {
         ALLOC(h->d_fc_imgf, fc_image_floats(m.Nz), float);
         ALLOC(h->d_fc_imgb, fc_image_floats(m.Nz), float);

@@ -19,6 +19,12 @@
 #define RT_B2C (RT_B1C + 160)                      // [64]        n*20+f, tail zero
 #define RT_B3C (RT_B2C + 64)                       // [96]        n*32+face (face 0 -> 0)
 #define RT_IMG_FLOATS (RT_B3C + 96)
+// behind it in the same allocation: the forward nets as bf16 A operands of v_mfma_f32_16x16x32_bf16, three planes (exact split) per group,
+// [48 groups][3 planes][64 lanes][8 bf16] (COLNDE_FWD_SPLIT=1; rt16_forward_kernel<ACT, true>)
+#define RT_SIMG_OFF ((RT_IMG_FLOATS + 3) & ~3)
+#define RT_SIMG_GROUPS 48
+#define RT_SIMG_WORDS (RT_SIMG_GROUPS * 3 * 64 * 4)
+#define RT_IMG_ALLOC (RT_SIMG_OFF + RT_SIMG_WORDS)
 
 bool rt_supported(const DevModel& m);
 size_t rt_forward_lds_bytes();

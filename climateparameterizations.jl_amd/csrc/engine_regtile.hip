@@ -332,6 +332,46 @@ __global__ void rt_pack_kernel(DevModel m, const float* __restrict__ w, float* _
     }
 }
 
+
+// The forward nets as A operands of v_mfma_f32_16x16x32_bf16 (COLNDE_FWD_SPLIT=1), made from the fp32 image: group G, plane p, lane (i = lane & 15,
+// kg = lane >> 4), element e = the weight that multiplies the B element e of lane (column, kg) — see rt16_forward_kernel<ACT, true>:
+//   layer 1, G = 3 t + q            : row of quad Q = 4 t + (i & 3), feature 4 (Q % 13) + (i >> 2) of net Q / 13; input 32 q + level(kg, e),
+//                                     level = e < 4 ? 4 kg + e : 16 + 4 kg + (e - 4)          (the two D tiles of a 32-level variable)
+//   layer 2, G = 30 + 4 n + 2 u + c : output 4 (4 u + (i & 3)) + (i >> 2) (< 20) of net n; input feature 4 (8 c + e) + kg (< 50)
+//   layer 3, G = 42 + 2 n + v       : face 16 v + i (>= 1) of net n; input feature 4 e + kg (e < 5)
+// everything else is zero.  The three planes are the exact truncation split of the fp32 weight.
+__global__ void rt_pack_split_kernel(const float* __restrict__ img, unsigned* __restrict__ simg) {
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < RT_SIMG_GROUPS * 64 * 4; x += gridDim.x * blockDim.x) {
+        const int G = x >> 8, lane = (x >> 2) & 63, pr = x & 3;           // pr: the pair of elements (2 pr, 2 pr + 1)
+        const int i = lane & 15, kg = lane >> 4, g_i = i >> 2, r_i = i & 3;
+        float v[2];
+#pragma unroll
+        for (int z = 0; z < 2; z++) {
+            const int e = 2 * pr + z;
+            float w = 0.0f;
+            if (G < 30) {
+                const int t = G / 3, q = G - 3 * t, Q = 4 * t + r_i, f = 4 * (Q % 13) + g_i;
+                const int lev = e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4);
+                if (Q < 39 && f < 50) w = img[RT_W1C + ((Q / 13) * 50 + f) * RT_LD1 + 32 * q + lev];
+            } else if (G < 42) {
+                const int y = G - 30, n = y >> 2, u = (y >> 1) & 1, c = y & 1;
+                const int Q2 = 4 * u + r_i, qq = 8 * c + e, f = 4 * qq + kg;
+                if (Q2 < 5 && qq < 13 && f < 50) w = img[RT_W2C + (n * 20 + 4 * Q2 + g_i) * RT_LD2 + f];
+            } else {
+                const int y = G - 42, n = y >> 1, vv = y & 1, face = 16 * vv + i;
+                if (face >= 1 && e < 5) w = img[RT_W3C + (n * 31 + face - 1) * RT_LD3 + 4 * e + kg];
+            }
+            v[z] = w;
+        }
+        const float r0 = v[0] - __uint_as_float(__float_as_uint(v[0]) & 0xffff0000u), r1 = v[1] - __uint_as_float(__float_as_uint(v[1]) & 0xffff0000u);
+        const float l0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), l1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        unsigned* o = simg + (size_t)G * 3 * 256 + lane * 4 + pr;
+        o[0] = (__float_as_uint(v[1]) & 0xffff0000u) | (__float_as_uint(v[0]) >> 16);
+        o[256] = (__float_as_uint(r1) & 0xffff0000u) | (__float_as_uint(r0) >> 16);
+        o[512] = (__float_as_uint(l1) & 0xffff0000u) | (__float_as_uint(l0) >> 16);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward solve (classical RK4); stage inputs -> tape in register-image order
 //   tape[((tile*n_steps + step)*4 + stage)*3072 + (q*4 + g)*256 + lane*4 + e] = X[q][4g + e]
@@ -1287,6 +1327,27 @@ __device__ __forceinline__ f32x4t mfma16t(float a, float b, f32x4t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+__device__ __forceinline__ f32x4t mfma16_bf(u32x4 a, u32x4 b, f32x4t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// c += A B over one 32-deep k-block from the exact three-way splits of both operands (see rt_dw1_split_kernel)
+__device__ __forceinline__ f32x4t mfma16_bf3(const Bf3& a, const Bf3& b, f32x4t c) {
+    c = mfma16_bf(a.m, b.m, c);
+    c = mfma16_bf(a.l, b.h, c);
+    c = mfma16_bf(a.h, b.l, c);
+    c = mfma16_bf(a.m, b.h, c);
+    c = mfma16_bf(a.h, b.m, c);
+    c = mfma16_bf(a.h, b.h, c);
+    return c;
+}
+__device__ __forceinline__ Bf3 rt16_ldA(const u32x4* simg, int G, int lane) {
+    Bf3 a;
+    a.h = simg[(G * 3 + 0) * 64 + lane];
+    a.m = simg[(G * 3 + 1) * 64 + lane];
+    a.l = simg[(G * 3 + 2) * 64 + lane];
+    return a;
+}
+
 __device__ __forceinline__ float rot_dn16(float x, int lane) { return __shfl(x, (lane + 48) & 63); }   // from lane - 16
 __device__ __forceinline__ float rot_up16(float x, int lane) { return __shfl(x, (lane + 16) & 63); }   // from lane + 16
 
@@ -1337,13 +1398,25 @@ __device__ __forceinline__ f32x4t rt16_chain(const float* wl, f32x4t acc, AF aid
     return acc;
 }
 
-template <int ACT>
+template <int ACT, bool SPLIT = false>
 __global__ void __launch_bounds__(512)
 rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
                     const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
                     float* __restrict__ tape, float* __restrict__ tapez, int n_col) {
     float* wl = rt_smem;
-    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
+    const float* bl = wl;                                 // biases: bl[RT_B1C ...]
+    const u32x4* simg = reinterpret_cast<const u32x4*>(rt_smem);
+    if constexpr (SPLIT) {
+        // LDS: the bf16 operand image (RT_SIMG_WORDS words, behind the fp32 image in the same allocation) and the fp32 bias tail
+        const unsigned* src = reinterpret_cast<const unsigned*>(wimg + RT_SIMG_OFF);
+        unsigned* dst = reinterpret_cast<unsigned*>(rt_smem);
+        for (int e = threadIdx.x; e < RT_SIMG_WORDS / 4; e += blockDim.x)
+            reinterpret_cast<u32x4*>(dst)[e] = reinterpret_cast<const u32x4*>(src)[e];
+        for (int e = threadIdx.x; e < RT_IMG_FLOATS - RT_B1C; e += blockDim.x) wl[RT_SIMG_WORDS + e] = wimg[RT_B1C + e];
+        bl = wl + RT_SIMG_WORDS - RT_B1C;
+    } else {
+        for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -1431,6 +1504,68 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                 RT_STAMP(0);
                 // ---- three MLPs -------------------------------------------------------------------------------------
                 f32x4t A1[10];
+                // operand addresses stay (lane base + immediate): left loop-invariant, all ~150 of them are computed outside the time loop and spilled
+                int lz = lane;
+                if constexpr (SPLIT) asm volatile("" : "+v"(lz));
+                if constexpr (SPLIT) {
+                    // k-block (= variable) outer, output tile inner: one variable's B planes live at a time, ten independent accumulation chains
+#pragma unroll
+                    for (int t = 0; t < 10; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int Q = 4 * t + r;
+                            A1[t][r] = Q < 39 ? bl[RT_B1C + (Q / 13) * 50 + min(4 * (Q % 13) + g, 49)] : 0.0f;
+                        }
+                    Bf3 Apf = rt16_ldA(simg, 0, lz);
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        // B operand of the 32-deep k-block: the variable's eight levels of this lane, split exactly into three bf16 planes
+                        const float x8[8] = {Xs[q].t[0][0], Xs[q].t[0][1], Xs[q].t[0][2], Xs[q].t[0][3], Xs[q].t[1][0], Xs[q].t[1][1], Xs[q].t[1][2], Xs[q].t[1][3]};
+                        const Bf3 XB = bf3_split8(x8);
+#pragma unroll
+                        for (int t = 0; t < 10; t++) {
+                            const Bf3 Ac = Apf;
+                            const int nx = q * 10 + t + 1;                                        // the group after (q, t) in this order
+                            if (nx < 30) Apf = rt16_ldA(simg, 3 * (nx % 10) + nx / 10, lz);
+                            auto finish = [&](int tt) {        // tile tt is complete: tape store, activation
+                                if (tz) {
+                                    float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
+#pragma unroll
+                                    for (int r = 0; r < 4; r++) {
+                                        const int Q = 4 * tt + r, qq = Q % 13;
+                                        if (Q < 39 && (qq < 12 || g < 2)) oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = A1[tt][r];
+                                    }
+                                }
+                                // (side-effect-free arithmetic is not ordered against the scheduling fences when the block is linearised: the empty
+                                //  asm statements pin the activation's inputs below the products' issue point and its results above the closing fence)
+#pragma unroll
+                                for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
+                                A1[tt] = rt_act4<ACT>(A1[tt]);
+#pragma unroll
+                                for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
+                            };
+                            if (q == 2) RT_SCHED_HARD();
+                            __builtin_amdgcn_s_setprio(1);
+                            A1[t] = mfma16_bf3(Ac, XB, A1[t]);
+                            __builtin_amdgcn_s_setprio(0);
+                            if (q == 2) {
+                                // the last k-block finishes the tiles one by one: tile t - 1's tape store and activation are issued BETWEEN tile t's
+                                // six products (one wave issues in order: left to the scheduler, all activations sink behind all MFMAs)
+                                if (t > 0) {
+                                    finish(t - 1);
+#pragma unroll
+                                    for (int u = 0; u < 6; u++) {
+                                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                        __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);
+                                    }
+                                }
+                                RT_SCHED_HARD();
+                                if (t == 9) finish(9);
+                            } else
+                                RT_SCHED_FENCE();
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int t = 0; t < 10; t++) {
                     f32x4t acc;
@@ -1457,24 +1592,57 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
                     f32x4t A2[2];
+                    Bf3 HB[2];
+                    if constexpr (SPLIT) {
+                        // net n's 13 quads of layer-1 activations as two 32-deep k-blocks (element e of block c: quad 8 c + e; three zero slots)
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            float a8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; e++) a8[e] = 8 * c + e < 13 ? A1[(13 * n + 8 * c + e) >> 2][(13 * n + 8 * c + e) & 3] : 0.0f;
+                            HB[c] = bf3_split8(a8);
+                        }
+                    }
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         f32x4t acc;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) acc[r] = (4 * u + r < 5) ? wl[RT_B2C + n * 20 + 4 * (4 * u + r) + g] : 0.0f;
+                        for (int r = 0; r < 4; r++) acc[r] = (4 * u + r < 5) ? bl[RT_B2C + n * 20 + 4 * (4 * u + r) + g] : 0.0f;
+                        if constexpr (SPLIT) {
+                            const Bf3 Aa = rt16_ldA(simg, 30 + 4 * n + 2 * u, lz), Ab = rt16_ldA(simg, 30 + 4 * n + 2 * u + 1, lz);
+                            __builtin_amdgcn_s_setprio(1);
+                            acc = mfma16_bf3(Aa, HB[0], acc);
+                            acc = mfma16_bf3(Ab, HB[1], acc);
+                            __builtin_amdgcn_s_setprio(0);
+                            RT_SCHED_FENCE();
+                        } else {
                         const int base = a2b[u] + n * 20 * RT_LD2, basel = a2l[u] + n * 20 * RT_LD2;
                         acc = rt16_chain<13, 13>(wl, acc, [=](int k) { return k < 12 ? base + 4 * k : basel; },
                                                  [&](int k) { return A1[(13 * n + k) >> 2][(13 * n + k) & 3]; });
+                        }
                         A2[u] = rt_act4<ACT>(acc);
+                    }
+                    Bf3 GB;
+                    if constexpr (SPLIT) {
+                        const float a8[8] = {A2[0][0], A2[0][1], A2[0][2], A2[0][3], A2[1][0], 0.0f, 0.0f, 0.0f};
+                        GB = bf3_split8(a8);
                     }
 #pragma unroll
                     for (int v = 0; v < 2; v++) {
                         f32x4t acc;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) acc[r] = wl[RT_B3C + n * 32 + 16 * v + 4 * g + r];
+                        for (int r = 0; r < 4; r++) acc[r] = bl[RT_B3C + n * 32 + 16 * v + 4 * g + r];
+                        if constexpr (SPLIT) {
+                            const Bf3 Aa = rt16_ldA(simg, 42 + 2 * n + v, lz);
+                            __builtin_amdgcn_s_setprio(1);
+                            O[n].t[v] = mfma16_bf3(Aa, GB, acc);
+                            __builtin_amdgcn_s_setprio(0);
+                            RT_SCHED_FENCE();
+                        } else {
                         const int base = a3b[v] + n * 31 * RT_LD3;
                         O[n].t[v] = rt16_chain<5, 5>(wl, acc, [=](int k) { return base + 4 * k; },
                                                      [&](int k) { return A2[k >> 2][k & 3]; });
+                        }
                     }
                 }
                 RT_STAMP(2);
@@ -3127,12 +3295,18 @@ hipError_t rt_set_attributes() {
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_SWISH>);
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_TANH>);
     RT_SETATTR(rt_forward_kernel<COLNDE_ACT_LEAKYRELU>);
-    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_IDENTITY>);
-    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_RELU>);
-    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_MISH>);
-    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_SWISH>);
-    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_TANH>);
-    RT_SETATTR(rt16_forward_kernel<COLNDE_ACT_LEAKYRELU>);
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_IDENTITY, false>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_RELU, false>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_MISH, false>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_SWISH, false>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_TANH, false>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
+    RT_SETATTR((rt16_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_IDENTITY, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, false>));
@@ -3259,7 +3433,12 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
         int wpw = (n_wt16 + 255) / 256;
         wpw = wpw < 1 ? 1 : (wpw > RT16_WAVES ? RT16_WAVES : wpw);
         const dim3 grid((n_wt16 + wpw - 1) / wpw), block(64 * wpw);
-#define RT_FWD(A) hipLaunchKernelGGL(rt16_forward_kernel<A>, grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, tapez, n_col)
+        const char* esp = getenv("COLNDE_FWD_SPLIT");     // 1: the nets on the bf16 pipe with exact three-way operand splitting (opt-in)
+        const bool split = esp && atoi(esp) != 0;
+        const size_t lds_split = ((size_t)RT_SIMG_WORDS + (RT_IMG_FLOATS - RT_B1C)) * sizeof(float);
+        if (split) hipLaunchKernelGGL(rt_pack_split_kernel, dim3(48), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_SIMG_OFF);
+#define RT_FWD(A) do { if (split) hipLaunchKernelGGL((rt16_forward_kernel<A, true>), grid, block, lds_split, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, tapez, n_col); \
+                       else hipLaunchKernelGGL((rt16_forward_kernel<A, false>), grid, block, lds, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, tapez, n_col); } while (0)
         switch (m.acts[0]) {
             case COLNDE_ACT_IDENTITY: RT_FWD(COLNDE_ACT_IDENTITY); break;
             case COLNDE_ACT_RELU: RT_FWD(COLNDE_ACT_RELU); break;

@@ -367,7 +367,8 @@ def test_regtile_engine_against_oracle(name):
 
 @pytest.mark.parametrize("env", [{"COLNDE_RT_ZTAPE": "0"}, {"COLNDE_RT_FWD": "32"}, {"COLNDE_RT_BLOCK": "32"},
                                  {"COLNDE_RT_BLOCK": "64", "COLNDE_RT_ZTAPE": "0"}, {"COLNDE_DW_SPLIT": "1"},
-                                 {"COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}])
+                                 {"COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}, {"COLNDE_FWD_SPLIT": "1"},
+                                 {"COLNDE_FWD_SPLIT": "1", "COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "64"}])
 def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
     """The variants behind environment switches: no Z1 tape (the adjoint recomputes layer 1), the 32-column forward kernel
     (one wave per SIMD; implies no Z1 tape), and the column-blocked gradient path that problems larger than the free HBM
@@ -417,6 +418,33 @@ def test_dw1_on_the_bf16_pipe_with_exact_operand_splitting_is_float32_grade(monk
     assert d < 2e-6
     assert esp < max(1.5 * e32, 2e-6)
     assert _rel(gsp, g) < GRAD_REL
+
+
+@pytest.mark.parametrize("name", [None, "diurnal", "relu", "mpp_bc_faces", "weights/4"])
+def test_forward_nets_on_the_bf16_pipe_with_exact_operand_splitting_are_float32_grade(name, monkeypatch):
+    """COLNDE_FWD_SPLIT=1: rt16_forward_kernel<ACT, true> evaluates the three flux nets with v_mfma_f32_16x16x32_bf16 on the exact three-way
+    bf16 splits of weights (packed once) and activations (split in registers) — through the whole nonlinear solve, 2,304 stage evaluations at
+    the bench horizon.  Same handle: the trajectory differs from the fp32-MFMA kernel's by float32 round-off (stated: 2e-5 in scaled units,
+    the tolerance of the fp32 kernel itself against the oracle), and against the float64 oracle it is as close as the fp32 kernel (within 1.5x)."""
+    from colnde.nde import ENGINE_REGTILE
+    kw = VARIANTS[name] if name in VARIANTS else {}
+    # "weights/4": nets 25x larger than in the other cases, so that their output is a leading term of the tendency
+    p = synthetic.wind_mixing_problem(64, n_frames=289 if name is None else 33, weight_divisor=4.0 if name == "weights/4" else 1e2, **kw)
+    sol = O.solve(p.cfg, p.x0, p.bcs, p.weights)
+    assert np.isfinite(sol).all()
+    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        monkeypatch.setenv("COLNDE_FWD_SPLIT", "0")
+        s32 = nde.forward(p.weights)
+        monkeypatch.setenv("COLNDE_FWD_SPLIT", "1")
+        ssp = nde.forward(p.weights)
+    d = np.abs(ssp - s32).max()
+    e32, esp = np.abs(s32 - sol).max(), np.abs(ssp - sol).max()
+    _record("test_fwd_split/" + str(name), split_vs_fp32=d, fp32_vs_oracle=e32, split_vs_oracle=esp)
+    if name is None:
+        assert d > 0.0                               # (the switch did select the other kernel; on 64 steps the two can round to the same trajectory)
+    assert d < (LONG_SOL_ATOL if name is None else SOL_ATOL)
+    assert esp < max(1.5 * e32, 2e-6)
 
 
 # ---- the net-split kernels of the latency points (engine AUTO up to 8,192 columns of the regtile shape) -----------------
