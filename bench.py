@@ -242,6 +242,16 @@ def other_configs(dev, budget_s=120.0):
     guarded("free_convection_8_simulations_64_levels", lambda: fc(8, 64, False, 3, "free convection at a latency size: 8 simulations x 64 levels x 512 RK4 steps, fwd+adjoint (fc32 on 16-column tiles)"))
     guarded("free_convection_32_levels_16384", lambda: fc(16384, 32, False, 2, "free convection 32 levels (32-128-128-31 relu), 16384 columns x 512 RK4 steps, fwd+adjoint"))
     guarded("config4_shard_16384x64", lambda: fc(16384, 64, False, 2, "configs[3] one GPU's shard: FreeConvectionNDE, 16384 columns x 64 levels x 512 RK4 steps, 64-256-256-63 relu, fwd+adjoint"))
+    def fc_split():   # opt-in: the same shard with the dW GEMM on the bf16 pipe from exact three-way operand splits; plan-time switch
+        os.environ["COLNDE_DW_SPLIT"] = "1"
+        try:
+            r = fc(16384, 64, False, 2, "configs[3] one GPU's shard as above, COLNDE_DW_SPLIT=1: dw_gemm_split_kernel (fp32-grade, opt-in; forward and adjoint kernels unchanged)")
+        finally:
+            os.environ["COLNDE_DW_SPLIT"] = "0"
+        r["matrix_arithmetic"] = "dW GEMM: bf16 MFMA on exact three-way operand splits; forward/adjoint: f32 MFMA"
+        return r
+
+    guarded("config4_shard_16384x64_opt_in_dw_split", fc_split)
     guarded("config4_shard_16384x64_conv_adj_rkc2", lambda: fc(16384, 64, True, 1, "configs[3] one GPU's shard: ConvectiveAdjustmentNDE (K = 10), 16384 columns x 64 levels x 512 RKC2 steps, fwd+adjoint"))
     return out
 

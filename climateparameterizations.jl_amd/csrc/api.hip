@@ -85,6 +85,7 @@ struct colnde_handle {
     float* d_dwtape = nullptr;
     float* d_t16_ztape = nullptr;   // taped mode: hidden pre-activations written by the forward kernel (the adjoint skips its forward GEMMs)
     DwMacro* d_macros = nullptr;
+    DwSplitPlan dw_split;                       // COLNDE_DW_SPLIT=1 when the tapes are planned: the dW GEMM on the bf16 pipe (exact operand splitting)
     int n_macros = 0, dw_slices = 0, t16_rows = 0;
     int t16_block = 0, t16_nblocks = 0;   // taped mode: columns per pass (multiple of 16) — the tapes hold one block
     int *d_bias_zoff = nullptr, *d_bias_goff = nullptr;
@@ -488,6 +489,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
                     h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks, h->d_fc_switch, h->d_fc_lam};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    dw_split_free(h->dw_split);
     delete h;
 }
 
@@ -832,6 +834,7 @@ extern "C" int colnde_loss(colnde_handle* h, const float* weights, const float s
 static void build_dw_macros(colnde_handle* h, size_t n_rec, std::vector<DwMacro>& mac) {
     const DevModel& m = h->m;
     const size_t R = dwtape_row_floats(m);
+    std::vector<int> matrix_of;
     for (int net = 0; net < m.n_nets; net++)
         for (int l = 0; l < m.n_layers; l++) {
             const int ni = m.sizes[l], no = m.sizes[l + 1];
@@ -845,9 +848,13 @@ static void build_dw_macros(colnde_handle* h, size_t n_rec, std::vector<DwMacro>
                     d.g_off = net * m.net_size + m.w_off[l] + i0 * no + j0;
                     d.no = no;
                     mac.push_back(d);
+                    matrix_of.push_back(net * m.n_layers + l);
                 }
         }
     h->n_macros = (int)mac.size();
+    const char* esp = getenv("COLNDE_DW_SPLIT");
+    dw_split_free(h->dw_split);
+    if (esp && atoi(esp) != 0 && dw_gemm_lds_fits((int)R, h->n_macros)) (void)dw_split_build(mac, matrix_of, (int)R, h->dw_split);
     const int n_groups = (h->n_macros + 3) / 4;
     size_t slices = std::max<size_t>(8, ((size_t)2048 / n_groups + 7) / 8 * 8);
     slices = std::min(slices, std::max<size_t>(8, (n_rec / 8 + 7) / 8 * 8));
@@ -1112,6 +1119,10 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                 }
                 {
                     Timed tm(h, K_DW1);
+                    if (!h->dw_split.passes.empty())
+                        e = launch_dw_gemm_split(h->d_dwtape, tiles_b * (cw / 16) * (size_t)(iv1 - iv0) * h->cfg.substeps * h->m.nst, (int)dwtape_row_floats(h->m), h->dw_split,
+                                                 h->dw_slices, h->d_slab + (gemm_rows0 + ((size_t)b * nseg + sg) * h->dw_slices) * stride, stride, h->stream);
+                    else
                     e = launch_dw_gemm(h->d_dwtape, tiles_b * (cw / 16) * (size_t)(iv1 - iv0) * h->cfg.substeps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros,
                                        h->n_macros, h->dw_slices, h->d_slab + (gemm_rows0 + ((size_t)b * nseg + sg) * h->dw_slices) * stride, stride, h->stream);
                     if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
@@ -1159,7 +1170,10 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
             }
             {
                 Timed tm(h, K_DW1);
-                hipError_t e = launch_dw_gemm(h->d_dwtape, (size_t)tiles_b * n_steps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros,
+                hipError_t e = !h->dw_split.passes.empty()
+                    ? launch_dw_gemm_split(h->d_dwtape, (size_t)tiles_b * n_steps * h->m.nst, (int)dwtape_row_floats(h->m), h->dw_split,
+                                           h->dw_slices, h->d_slab + ((size_t)h->n_tiles + (size_t)b * h->dw_slices) * stride, stride, h->stream)
+                    : launch_dw_gemm(h->d_dwtape, (size_t)tiles_b * n_steps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros,
                                               h->dw_slices, h->d_slab + ((size_t)h->n_tiles + (size_t)b * h->dw_slices) * stride, stride, h->stream);
                 if (e != hipSuccess) return fail("dW GEMM launch failed: %s", hipGetErrorString(e));
             }

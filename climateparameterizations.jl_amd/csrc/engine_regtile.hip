@@ -18,6 +18,7 @@
 // Reference arithmetic: wind_mixing/src/NDE_training.jl:46-165 (NDE, predict_flux, predict_NDE).
 #include <cstdlib>
 #include "engine_regtile.h"
+#include "split_bf16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1182,40 +1183,6 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
 // feeds 90 MFMAs.  Ring of four quarter buffers as before: the two quarters of half H + 2 are fetched into the slots of half H as soon
 // as its operands are in registers.
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct Bf3 { u32x4 h, m, l; };
-
-__device__ __forceinline__ Bf3 bf3_split8(const float* x) {
-    Bf3 o;
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const float a = x[2 * p], b = x[2 * p + 1];
-        const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
-        const float la = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), lb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
-        // (hi16(b) << 16) | hi16(a): element 2p in the low half
-        o.h[p] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-        o.m[p] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
-        o.l[p] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
-    }
-    return o;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// c += A B over one 16-deep k-block, fp32-grade: smallest products first
-__device__ __forceinline__ f32x16 mfma_bf3(const Bf3& a, const Bf3& b, f32x16 c) {
-    c = mfma_bf(a.m, b.m, c);
-    c = mfma_bf(a.l, b.h, c);
-    c = mfma_bf(a.h, b.l, c);
-    c = mfma_bf(a.m, b.h, c);
-    c = mfma_bf(a.h, b.m, c);
-    c = mfma_bf(a.h, b.h, c);
-    return c;
-}
-
 __global__ void __launch_bounds__(256)
 rt_dw1_split_kernel(DevModel m, const float* __restrict__ tape, const float* __restrict__ tape2, long n_items,
                     float* __restrict__ slab_rows) {

@@ -1,5 +1,6 @@
 // engine_tile16.h — host/device interface of the MFMA tile engine.
 #pragma once
+#include <vector>
 #include "colnde_dev.h"
 
 struct PackInfo {
@@ -50,6 +51,15 @@ static inline size_t dwtape_row_floats(const DevModel& m) { return (size_t)dwtap
 bool dw_gemm_lds_fits(int row_floats, int n_macros);     // the LDS-staged dW kernel applies (else the L2-streaming one)
 hipError_t launch_dw_gemm(const float* dwtape, size_t n_records, int row_floats, const DwMacro* macros, int n_macros, int n_slices,
                           float* slab_rows, int slab_stride, hipStream_t stream);
+// dW GEMM on the bf16 pipe with exact three-way operand splitting (COLNDE_DW_SPLIT=1 when the plan is made; opt-in): the blocks are
+// dealt to passes by layer so that a pass's operand features (split ONCE per record into LDS planes) and its accumulators fit one workgroup
+struct DwSeg { int src, len, dst; };                                  // floats of a record row [src, src + len) -> compact features [dst, dst + len)
+struct DwPassDesc { DwSeg seg[8]; int n_seg, Fc, m0, n_macros, maxm, nit; };
+struct DwSplitPlan { std::vector<DwPassDesc> passes; DwMacro* d_macros = nullptr; };
+bool dw_split_build(const std::vector<DwMacro>& mac, const std::vector<int>& matrix_of, int row_floats, DwSplitPlan& plan);
+void dw_split_free(DwSplitPlan& plan);
+hipError_t launch_dw_gemm_split(const float* dwtape, size_t n_records, int row_floats, const DwSplitPlan& plan, int n_slices,
+                                float* slab_rows, int slab_stride, hipStream_t stream);
 hipError_t launch_reduce(const float* slab, int n_tiles, int n_params, int stride, const LossWeights& lw, float* out,
                          hipStream_t stream);
 hipError_t launch_infer(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* T,

@@ -19,6 +19,8 @@
 #include "colnde_dev.h"
 #include <cstdlib>
 #include "engine_tile16.h"
+#include "split_bf16.h"
+#include <algorithm>
 
 #define FWD_MAXR 12   // owner-thread register items per state array in the forward kernel: CT*ns <= FWD_MAXR*blockDim
 #define MAXB 4        // bias-gradient accumulators per thread: n_bias <= MAXB*blockDim
@@ -1459,6 +1461,269 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dW GEMM with exact three-way bf16 operand splitting (opt-in).  One workgroup of 8 waves per slice of records, as above, but the record
+// does not go to LDS as floats: every thread loads its share (two adjacent features x eight columns, 8-byte loads, two records ahead in
+// registers), splits the values and writes three bf16 planes [feature][column half][8 bf16] — MFMA-operand order, so a block's operands
+// are 12 ds_read_b128 per record and nothing is split twice.  Two plane buffers, ONE bare barrier per record (a wave that passed the
+// barrier of record r has finished the products of record r - 1, whose buffer record r + 1 overwrites).  A pass holds the operand
+// features of some layers only (compact order, DwPassDesc), so the planes and 2 x 64 accumulator registers per wave fit; the passes
+// together read each tape float once.
+// ------------------------------------------------------------------------------------------------
+#define DWS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+typedef float dws_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int MAXM, int NIT>
+__global__ void __launch_bounds__(512)
+dw_gemm_split_kernel(const float* __restrict__ dwtape, size_t n_records, int R, const DwMacro* __restrict__ macros, DwPassDesc ps,
+                     int n_slices, float* __restrict__ slab_rows, int stride) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = blockIdx.x;
+    const size_t per = (n_records + n_slices - 1) / n_slices;
+    const size_t r0 = (size_t)slice * per, r1 = r0 + per < n_records ? r0 + per : n_records;
+    if (r0 >= r1) return;                                  // (whole workgroup)
+    const int Fc = ps.Fc, FcP = Fc + 64;
+    u32x4* planes = reinterpret_cast<u32x4*>(smem);        // [2 buffers][3 planes][FcP features][2 column halves]
+    // pad features (read by the clamped tiles of narrow blocks, never stored) must be finite
+    for (int e = tid; e < 2 * 3 * 64 * 2; e += 512) {
+        const int kh = e & 1, f = (e >> 1) & 63, bp = e >> 7;
+        planes[((size_t)bp * FcP + Fc + f) * 2 + kh] = (u32x4)(0u);
+    }
+    // loader role: item `it` = (feature pair j, column half kh), j fastest (coalesced 8-byte loads)
+    int src_off[NIT], cfeat[NIT], ikh[NIT];
+    bool live[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int it = tid + 512 * k, np = Fc >> 1;
+        live[k] = it < Fc;
+        const int j = live[k] ? it % np : 0;
+        ikh[k] = live[k] ? it / np : 0;
+        cfeat[k] = 2 * j;
+        int so = 0;
+        for (int sg = 0; sg < ps.n_seg; sg++)
+            if (cfeat[k] >= ps.seg[sg].dst && cfeat[k] < ps.seg[sg].dst + ps.seg[sg].len) so = ps.seg[sg].src + cfeat[k] - ps.seg[sg].dst;
+        src_off[k] = so + 8 * ikh[k] * R;
+    }
+    const int f = lane & 31, kk = lane >> 5;
+    DwMacro mc[MAXM];
+    sp_f32x16 acc[MAXM][4];
+#pragma unroll
+    for (int q = 0; q < MAXM; q++) {
+        const int mi = wave + 8 * q;
+        if (mi < ps.n_macros) mc[q] = macros[ps.m0 + mi];
+        else { mc[q].a_feat = 0; mc[q].d_feat = 0; mc[q].ni_rem = 0; mc[q].no_rem = 0; mc[q].g_off = 0; mc[q].no = 1; }
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[q][t] = (sp_f32x16)(0.0f);
+    }
+    dws_f32x2 pre[2][NIT][8];
+    auto gl = [&](size_t r, dws_f32x2 (&dst)[NIT][8]) {
+        const size_t rc = r < r1 ? r : r1 - 1;             // past the end: the last record again (loaded, never used)
+        const float* rec = dwtape + rc * ((size_t)CT * R);
+#pragma unroll
+        for (int k = 0; k < NIT; k++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) dst[k][c] = *reinterpret_cast<const dws_f32x2*>(rec + src_off[k] + c * R);
+    };
+    auto sp = [&](const dws_f32x2 (&src)[NIT][8], int buf) {
+#ifdef DWS_NO_SPLIT
+        if (src[0][0][0] != 1.2345f) return;
+#endif
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            if (!live[k]) continue;
+#pragma unroll
+            for (int z = 0; z < 2; z++) {
+                float x8[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) x8[c] = src[k][c][z];
+                const Bf3 b = bf3_split8(x8);
+                u32x4* o = planes + ((size_t)(buf * 3) * FcP + cfeat[k] + z) * 2 + ikh[k];
+                o[0] = b.h;
+                o[(size_t)FcP * 2] = b.m;
+                o[(size_t)FcP * 4] = b.l;
+            }
+        }
+    };
+    auto ld = [&](int buf, int cf) {
+        const u32x4* o = planes + ((size_t)(buf * 3) * FcP + cf + f) * 2 + kk;
+        Bf3 b;
+        b.h = o[0];
+        b.m = o[(size_t)FcP * 2];
+        b.l = o[(size_t)FcP * 4];
+        return b;
+    };
+    // (wave-uniform) the wave's two blocks are full 64 x 64 blocks of the same output columns: their d operands are read once
+    const bool shared_d = MAXM == 2 && mc[0].ni_rem > 32 && mc[MAXM - 1].ni_rem > 32 && mc[0].no_rem > 32 && mc[MAXM - 1].no_rem > 32 &&
+                          mc[0].d_feat == mc[MAXM - 1].d_feat;
+    auto products = [&](int buf) {
+#ifdef DWS_NO_MFMA
+        return;
+#endif
+        if (MAXM == 2 && shared_d) {
+            // four a tiles against the same two d tiles: the next a tile is read while the current one is multiplied
+            const Bf3 d0 = ld(buf, mc[0].d_feat), d1 = ld(buf, mc[0].d_feat + 32);
+            Bf3 A = ld(buf, mc[0].a_feat);
+#pragma unroll
+            for (int t = 0; t < 2 * MAXM; t++) {
+                const Bf3 Ac = A;
+                if (t + 1 < 2 * MAXM) A = ld(buf, mc[(t + 1) >> 1].a_feat + 32 * ((t + 1) & 1));
+                acc[t >> 1][2 * (t & 1)] = mfma_bf3(Ac, d0, acc[t >> 1][2 * (t & 1)]);
+                acc[t >> 1][2 * (t & 1) + 1] = mfma_bf3(Ac, d1, acc[t >> 1][2 * (t & 1) + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < MAXM; q++) {
+            if (mc[q].ni_rem == 0) continue;               // (wave-uniform) an empty slot
+            const Bf3 a0 = ld(buf, mc[q].a_feat), d0 = ld(buf, mc[q].d_feat);
+            acc[q][0] = mfma_bf3(a0, d0, acc[q][0]);
+            if (mc[q].no_rem > 32) {
+                const Bf3 d1 = ld(buf, mc[q].d_feat + 32);
+                acc[q][1] = mfma_bf3(a0, d1, acc[q][1]);
+                if (mc[q].ni_rem > 32) {
+                    const Bf3 a1 = ld(buf, mc[q].a_feat + 32);
+                    acc[q][2] = mfma_bf3(a1, d0, acc[q][2]);
+                    acc[q][3] = mfma_bf3(a1, d1, acc[q][3]);
+                }
+            } else if (mc[q].ni_rem > 32) {
+                const Bf3 a1 = ld(buf, mc[q].a_feat + 32);
+                acc[q][2] = mfma_bf3(a1, d0, acc[q][2]);
+            }
+        }
+    };
+    // Between two barriers a wave multiplies record r (plane buffer r & 1) AND splits record r + 1 into the other buffer (free since the last
+    // barrier: everybody has finished record r - 1).  The two waves of a SIMD (w, w + 4) take the two jobs in opposite order, so that one's
+    // vector work and LDS round trips run under the other's MFMAs instead of both queueing for the matrix pipe at the same moment.
+    const size_t n = r1 - r0;
+    const bool split_first = (wave >> 2) & 1;
+    gl(r0, pre[0]);
+    gl(r0 + 1, pre[1]);
+    sp(pre[0], 0);
+    gl(r0 + 2, pre[0]);
+    DWS_BARRIER();
+    for (size_t i = 0; i < n; i += 2) {
+        if (split_first) { sp(pre[1], 1); gl(r0 + i + 3, pre[1]); products(0); }
+        else { products(0); sp(pre[1], 1); gl(r0 + i + 3, pre[1]); }
+        DWS_BARRIER();
+        if (i + 1 < n) {
+            if (split_first) { sp(pre[0], 0); gl(r0 + i + 4, pre[0]); products(1); }
+            else { products(1); sp(pre[0], 0); gl(r0 + i + 4, pre[0]); }
+            DWS_BARRIER();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXM; q++) {
+        if (mc[q].ni_rem == 0) continue;
+        float* out = slab_rows + (size_t)slice * stride + mc[q].g_off;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = 8 * (r >> 2) + 4 * kk + (r & 3);
+            if (i < mc[q].ni_rem && f < mc[q].no_rem) out[(size_t)i * mc[q].no + f] = acc[q][0][r];
+            if (i < mc[q].ni_rem && f + 32 < mc[q].no_rem) out[(size_t)i * mc[q].no + f + 32] = acc[q][1][r];
+            if (i + 32 < mc[q].ni_rem && f < mc[q].no_rem) out[(size_t)(i + 32) * mc[q].no + f] = acc[q][2][r];
+            if (i + 32 < mc[q].ni_rem && f + 32 < mc[q].no_rem) out[(size_t)(i + 32) * mc[q].no + f + 32] = acc[q][3][r];
+        }
+    }
+}
+
+// Deal the blocks to passes (first fit, largest layer first): a pass = the blocks of some (net, layer) groups whose operand features, merged
+// into at most 8 even-aligned segments of the record row, are at most 768 (two plane buffers in LDS) and whose blocks are at most 16.
+bool dw_split_build(const std::vector<DwMacro>& mac, const std::vector<int>& matrix_of, int R, DwSplitPlan& plan) {
+    struct Group { std::vector<int> idx; int feats; };
+    std::vector<Group> groups;                 // the blocks of one weight matrix (net, layer) stay together
+    for (int i = 0; i < (int)mac.size(); i++) {
+        if (groups.empty() || matrix_of[i] != matrix_of[groups.back().idx[0]]) groups.push_back(Group{{}, 0});
+        groups.back().idx.push_back(i);
+    }
+    auto segments = [&](const std::vector<int>& idx, std::vector<DwSeg>& segs) {
+        std::vector<std::pair<int, int>> iv;
+        for (int i : idx) {
+            iv.push_back({mac[i].a_feat & ~1, std::min(R, (mac[i].a_feat + mac[i].ni_rem + 1) & ~1)});
+            iv.push_back({mac[i].d_feat & ~1, std::min(R, (mac[i].d_feat + mac[i].no_rem + 1) & ~1)});
+        }
+        std::sort(iv.begin(), iv.end());
+        segs.clear();
+        int dst = 0;
+        for (auto& v : iv) {
+            if (!segs.empty() && v.first <= segs.back().src + segs.back().len) {
+                const int end = std::max(segs.back().src + segs.back().len, v.second);
+                dst += end - (segs.back().src + segs.back().len);
+                segs.back().len = end - segs.back().src;
+            } else {
+                segs.push_back(DwSeg{v.first, v.second - v.first, dst});
+                dst += v.second - v.first;
+            }
+        }
+        return dst;
+    };
+    for (auto& g : groups) { std::vector<DwSeg> sg; g.feats = segments(g.idx, sg); }
+    std::vector<int> order(groups.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[a].feats > groups[b].feats; });
+    std::vector<std::vector<int>> bins;        // macro indices per pass
+    for (int gi : order) {
+        bool placed = false;
+        for (auto& b : bins) {
+            std::vector<int> trial = b;
+            trial.insert(trial.end(), groups[gi].idx.begin(), groups[gi].idx.end());
+            std::vector<DwSeg> sg;
+            const int fc = segments(trial, sg);
+            if (fc <= 768 && sg.size() <= 8 && trial.size() <= 16) { b = trial; placed = true; break; }
+        }
+        if (!placed) {
+            std::vector<DwSeg> sg;
+            const int fc = segments(groups[gi].idx, sg);
+            if (fc > 768 || sg.size() > 8 || groups[gi].idx.size() > 16) return false;
+            bins.push_back(groups[gi].idx);
+        }
+    }
+    std::vector<DwMacro> all;
+    plan.passes.clear();
+    for (auto& b : bins) {
+        DwPassDesc pd{};
+        std::vector<DwSeg> sg;
+        pd.Fc = segments(b, sg);
+        pd.n_seg = (int)sg.size();
+        for (int i = 0; i < pd.n_seg; i++) pd.seg[i] = sg[i];
+        pd.m0 = (int)all.size();
+        pd.n_macros = (int)b.size();
+        pd.maxm = (pd.n_macros + 7) / 8;
+        pd.nit = (pd.Fc + 511) / 512;
+        auto compact = [&](int feat) {
+            for (auto& s : sg) if (feat >= s.src && feat < s.src + s.len) return s.dst + feat - s.src;
+            return 0;
+        };
+        for (int i : b) { DwMacro d = mac[i]; d.a_feat = compact(d.a_feat); d.d_feat = compact(d.d_feat); all.push_back(d); }
+        plan.passes.push_back(pd);
+    }
+    if ((R & 1) != 0) return false;            // 8-byte loads of feature pairs
+    if (hipMalloc((void**)&plan.d_macros, all.size() * sizeof(DwMacro)) != hipSuccess) { (void)hipGetLastError(); plan.passes.clear(); return false; }
+    if (hipMemcpy(plan.d_macros, all.data(), all.size() * sizeof(DwMacro), hipMemcpyHostToDevice) != hipSuccess) { dw_split_free(plan); return false; }
+    return true;
+}
+
+void dw_split_free(DwSplitPlan& plan) {
+    if (plan.d_macros) (void)hipFree(plan.d_macros);
+    plan.d_macros = nullptr;
+    plan.passes.clear();
+}
+
+hipError_t launch_dw_gemm_split(const float* dwtape, size_t n_records, int row_floats, const DwSplitPlan& plan, int n_slices,
+                                float* slab_rows, int slab_stride, hipStream_t stream) {
+    if (n_records == 0 || n_slices < 1 || plan.passes.empty()) return hipErrorInvalidValue;
+    for (const DwPassDesc& pd : plan.passes) {
+        const size_t lds = (size_t)2 * 3 * (pd.Fc + 64) * 2 * 16;
+#define DWS_LAUNCH(M, N) hipLaunchKernelGGL((dw_gemm_split_kernel<M, N>), dim3(n_slices), dim3(512), lds, stream, dwtape, n_records, row_floats, plan.d_macros, pd, n_slices, slab_rows, slab_stride)
+        if (pd.maxm <= 1) { if (pd.nit <= 1) DWS_LAUNCH(1, 1); else DWS_LAUNCH(1, 2); }
+        else { if (pd.nit <= 1) DWS_LAUNCH(2, 1); else DWS_LAUNCH(2, 2); }
+#undef DWS_LAUNCH
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 bool dw_gemm_lds_fits(int row_floats, int n_macros) {
     const char* e = getenv("COLNDE_T16_DWLDS");           // 0: always the L2-streaming kernel (testing aid)
     if (e && atoi(e) == 0) return false;
@@ -1748,6 +2013,7 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     SETATTR((adjoint_kernel<1, 1024, 2, false, true, true>));
     SETATTR((adjoint_kernel<1, 1024, 2, true, true, false>));
     SETATTR((adjoint_kernel<1, 1024, 2, true, true, true>));
+    SETATTR((dw_gemm_split_kernel<1, 1>)); SETATTR((dw_gemm_split_kernel<1, 2>)); SETATTR((dw_gemm_split_kernel<2, 1>)); SETATTR((dw_gemm_split_kernel<2, 2>));
     SETATTR((dw_gemm_lds_kernel<1, DW_NW, 1>)); SETATTR((dw_gemm_lds_kernel<1, DW_NW, 2>)); SETATTR((dw_gemm_lds_kernel<1, DW_NW, 4>));
     SETATTR((dw_gemm_lds_kernel<2, DW_NW, 1>)); SETATTR((dw_gemm_lds_kernel<2, DW_NW, 2>)); SETATTR((dw_gemm_lds_kernel<2, DW_NW, 4>));
     SETATTR((dw_gemm_lds_kernel<3, DW_NW, 1>)); SETATTR((dw_gemm_lds_kernel<3, DW_NW, 2>)); SETATTR((dw_gemm_lds_kernel<3, DW_NW, 4>));

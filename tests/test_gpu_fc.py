@@ -236,3 +236,35 @@ def test_fc32_time_segmented_tapes_equal_the_single_pass(model, seg, block, cw, 
     assert _rel(cut[2], one[2].astype(np.float64)) < 2e-6
     if not ca:
         assert np.isclose(cut[0], tot, rtol=FC_LOSS_RTOL) and _rel(cut[2], g) < FC_GRAD_REL
+
+
+@pytest.mark.parametrize("Nz,ncol,engine", [(64, 45, 0), (32, 70, 0), (64, 20, ENGINE_TILE16), (32, 33, ENGINE_TILE16)])
+def test_dw_gemm_on_the_bf16_pipe_with_exact_operand_splitting_is_float32_grade(Nz, ncol, engine, monkeypatch):
+    """COLNDE_DW_SPLIT=1 when the tapes are planned: `dw_gemm_split_kernel` contracts the same delta-tape records as `dw_gemm_lds_kernel`, in passes
+    by layer, with six bf16 MFMA products of the exact three-way splits of both operands (split once per record into LDS planes) in place of
+    v_mfma_f32_32x32x2_f32.  Same forward and adjoint kernels, same tapes: the weight gradient differs from the fp32 GEMM's by float32 round-off
+    (stated: 2e-6 relative L2), the bias gradients and the loss are bit-identical, and the gap to the float64 oracle is the same (within 1.5x)."""
+    p = synthetic.free_convection_problem(ncol, Nz=Nz, n_save=9, substeps=2, t_end=0.02)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(p.cfg)
+    tot, terms, g, _ = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("COLNDE_DW_SPLIT", mode)
+        with colnde.ColumnNDE(p.cfg, ncol, engine=engine) as nde:
+            nde.set_problem(p.x0, p.bcs, truth)
+            out[mode] = nde.loss_grad(p.weights, sc)
+            again = nde.loss_grad(p.weights, sc)
+        assert np.array_equal(again[2], out[mode][2])                   # bit-reproducible in either mode
+    (t32, _, g32), (tsp, _, gsp) = out["0"], out["1"]
+    assert t32 == tsp
+    H, off, wmask = 4 * Nz, 0, np.zeros(p.cfg.n_params, bool)
+    for n, is_w in ((Nz * H, True), (H, False), (H * H, True), (H, False), (H * (Nz - 1), True), (Nz - 1, False)):
+        wmask[off:off + n] = is_w
+        off += n
+    np.testing.assert_array_equal(gsp[~wmask], g32[~wmask])            # biases: column sums taken by the adjoint kernels, not by the GEMM
+    d = _rel(gsp[wmask], g32[wmask].astype(np.float64))
+    e32, esp = _rel(g32, g), _rel(gsp, g)
+    _record("dw_gemm_split/%d/%d/%d" % (Nz, ncol, engine), split_vs_fp32=d, fp32_vs_oracle=e32, split_vs_oracle=esp)
+    assert 0.0 < d < 2e-6
+    assert esp < max(1.5 * e32, 2e-6)
