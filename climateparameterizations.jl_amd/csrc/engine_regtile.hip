@@ -1365,6 +1365,37 @@ __device__ __forceinline__ f32x4t rt16_chain(const float* wl, f32x4t acc, AF aid
     return acc;
 }
 
+// rt16_chain with independent vector work (`fill`: the previous tile's tape store and activation) issued BETWEEN the MFMAs.  One wave issues in
+// order, and left to the instruction selector every activation of a layer sinks behind all of its chains (side-effect-free arithmetic is not
+// ordered against the scheduling fences when the block is linearised); here the filler's inputs and results are pinned with empty asm
+// statements and the region's issue order is prescribed: per MFMA one A-operand read (while any remain) and `NV` vector instructions.
+template <int N, int CH, int NV, class AF, class BF, class FF>
+__device__ __forceinline__ f32x4t rt16_chain_fill(const float* wl, f32x4t acc, AF aidx, BF bval, FF fill) {
+    float a[2][CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++)
+        if (u < N) a[0][u] = wl[aidx(u)];
+    RT_SCHED_HARD();
+    fill();
+#pragma unroll
+    for (int c = 0; c * CH < N; c++) {
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+            if ((c + 1) * CH + u < N) a[(c + 1) & 1][u] = wl[aidx((c + 1) * CH + u)];
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+            if (c * CH + u < N) acc = mfma16t(a[c & 1][u], bval(c * CH + u), acc);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS read (the next chunk's operands)
+        __builtin_amdgcn_sched_group_barrier(0x402, NV, 0);      // NV vector / transcendental instructions of the filler
+    }
+    RT_SCHED_HARD();
+    return acc;
+}
+
 template <int ACT, bool SPLIT = false>
 __global__ void __launch_bounds__(512)
 rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
@@ -1532,7 +1563,22 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                                 RT_SCHED_FENCE();
                         }
                     }
-                } else
+                } else {
+                auto finish1 = [&](int tt) {          // tile tt of layer 1 is complete: Z1 tape store, activation (pinned: see rt16_chain_fill)
+                    if (tz) {
+                        float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int Q = 4 * tt + r, qq = Q % 13;
+                            if (Q < 39 && (qq < 12 || g < 2)) oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = A1[tt][r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
+                    A1[tt] = rt_act4<ACT>(A1[tt]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
+                };
 #pragma unroll
                 for (int t = 0; t < 10; t++) {
                     f32x4t acc;
@@ -1542,17 +1588,19 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                         acc[r] = Q < 39 ? wl[RT_B1C + (Q / 13) * 50 + min(4 * (Q % 13) + g, 49)] : 0.0f;
                     }
                     const int base = a1b[t];
+#ifndef RT16_FWD_FILL     // (measured: 35.4 ms with the filler against 34.0-34.9 without — two waves per SIMD already overlap what can be overlapped; kept as an A/B switch)
                     acc = rt16_chain<24, 8>(wl, acc, [=](int k) { return base + (k >> 3) * 32 + ((k >> 2) & 1) * 16 + (k & 3); },
                                             [&](int k) { return Xs[k >> 3].t[(k >> 2) & 1][k & 3]; });
-                    if (tz) {
-                        float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int Q = 4 * t + r, qq = Q % 13;
-                            if (Q < 39 && (qq < 12 || g < 2)) oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = acc[r];
-                        }
-                    }
-                    A1[t] = rt_act4<ACT>(acc);
+                    A1[t] = acc;
+                    finish1(t);
+#else
+                    // tile t - 1's tape store and activation are issued between tile t's MFMAs
+                    acc = rt16_chain_fill<24, 8, 2>(wl, acc, [=](int k) { return base + (k >> 3) * 32 + ((k >> 2) & 1) * 16 + (k & 3); },
+                                                    [&](int k) { return Xs[k >> 3].t[(k >> 2) & 1][k & 3]; }, [&] { if (t > 0) finish1(t - 1); });
+                    A1[t] = acc;
+                    if (t == 9) finish1(9);
+#endif
+                }
                 }
                 RT_STAMP(1);
                 V16 O[3];
