@@ -233,8 +233,23 @@ def other_configs(dev, budget_s=120.0):
         finally:
             nde.close()
 
+    def with_split(fn, what):       # opt-in variants: the same case with the exact-split kernels switched on; never the default
+        def run():
+            os.environ["COLNDE_FWD_SPLIT"] = "1"
+            os.environ["COLNDE_DW_SPLIT"] = "1"
+            try:
+                r = fn()
+            finally:
+                os.environ["COLNDE_FWD_SPLIT"] = "0"
+                os.environ["COLNDE_DW_SPLIT"] = "0"
+            r["matrix_arithmetic"] = what
+            return r
+        return run
+
     guarded("config2_forward_4096", c2)
+    guarded("config2_forward_4096_opt_in_split", with_split(c2, "COLNDE_FWD_SPLIT=1: layers 1 and 2 of the net-split forward on bf16 MFMA from exact three-way operand splits (fp32-grade)"))
     guarded("config3_8_simulations", c3)
+    guarded("config3_8_simulations_opt_in_split", with_split(c3, "COLNDE_FWD_SPLIT=1 COLNDE_DW_SPLIT=1: net-split forward and the tape GEMM on bf16 MFMA from exact three-way operand splits; adjoint kernel unchanged"))
     guarded("config3_8_simulations_conv_adj_kappa10_rkc2", c3ca)
     guarded("config5_inference_65536", c5)
     guarded("implicit_steps_4M_columns", impl)

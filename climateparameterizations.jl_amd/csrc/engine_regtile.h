@@ -24,7 +24,15 @@
 #define RT_SIMG_OFF ((RT_IMG_FLOATS + 3) & ~3)
 #define RT_SIMG_GROUPS 48
 #define RT_SIMG_WORDS (RT_SIMG_GROUPS * 3 * 64 * 4)
-#define RT_IMG_ALLOC (RT_SIMG_OFF + RT_SIMG_WORDS)
+// ... and behind that, the same for the net-split forward kernel (rt16sh_forward_kernel<ACT, RICH, false, true>): layers 1 and 2 in the per-net tile
+// order of that kernel — [27 full layer-1 groups (net, tile 0..2, k-block)][12 layer-2 groups][the 8 live lanes of each net's quarter-filled
+// fourth layer-1 tile: (net, k-block, plane, 8 lanes)][one zero operand]; layer 3 stays on the fp32 image
+#define RT_SIMG2_OFF (RT_SIMG_OFF + RT_SIMG_WORDS)
+#define RT_SIMG2_L2 (27 * 768)                       // word offsets inside the image
+#define RT_SIMG2_T3 (RT_SIMG2_L2 + 12 * 768)
+#define RT_SIMG2_ZERO (RT_SIMG2_T3 + 27 * 8 * 4)
+#define RT_SIMG2_WORDS (RT_SIMG2_ZERO + 4)
+#define RT_IMG_ALLOC (RT_SIMG2_OFF + RT_SIMG2_WORDS)
 
 bool rt_supported(const DevModel& m);
 size_t rt_forward_lds_bytes();

@@ -373,6 +373,52 @@ __global__ void rt_pack_split_kernel(const float* __restrict__ img, unsigned* __
     }
 }
 
+// ... and for the net-split forward kernel (RT_SIMG2_*): layer 1 per net (tiles of that kernel: quad Q = 4 t + (i & 3) of the net's 13, feature
+// 4 Q + (i >> 2)), layer 2 as above, and the 8 live lanes of each net's fourth layer-1 tile (quad 12: features 48, 49 -> rows i = 0, 4)
+__global__ void rt_pack_split_ns_kernel(const float* __restrict__ img, unsigned* __restrict__ simg) {
+    auto put = [&](unsigned* o, int plane_stride, float v0, float v1) {
+        const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+        const float l0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), l1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        o[0] = (__float_as_uint(v1) & 0xffff0000u) | (__float_as_uint(v0) >> 16);
+        o[plane_stride] = (__float_as_uint(r1) & 0xffff0000u) | (__float_as_uint(r0) >> 16);
+        o[2 * plane_stride] = (__float_as_uint(l1) & 0xffff0000u) | (__float_as_uint(l0) >> 16);
+    };
+    const int n_full = 39 * 256, n_t3 = 9 * 8 * 4;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n_full + n_t3 + 4; x += gridDim.x * blockDim.x) {
+        if (x >= n_full + n_t3) { simg[RT_SIMG2_ZERO + x - n_full - n_t3] = 0u; continue; }
+        float v[2];
+        if (x < n_full) {
+            const int G = x >> 8, lane = (x >> 2) & 63, pr = x & 3;
+            const int i = lane & 15, kg = lane >> 4, g_i = i >> 2, r_i = i & 3;
+#pragma unroll
+            for (int z = 0; z < 2; z++) {
+                const int e = 2 * pr + z;
+                float w = 0.0f;
+                if (G < 27) {
+                    const int n = G / 9, t = (G / 3) % 3, q = G % 3, f = 4 * (4 * t + r_i) + g_i;
+                    const int lev = e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4);
+                    w = img[RT_W1C + (n * 50 + f) * RT_LD1 + 32 * q + lev];
+                } else {
+                    const int y = G - 27, n = y >> 2, u = (y >> 1) & 1, c = y & 1;
+                    const int Q2 = 4 * u + r_i, qq = 8 * c + e, f = 4 * qq + kg;
+                    if (Q2 < 5 && qq < 13 && f < 50) w = img[RT_W2C + (n * 20 + 4 * Q2 + g_i) * RT_LD2 + f];
+                }
+                v[z] = w;
+            }
+            put(simg + (size_t)G * 768 + lane * 4 + pr, 256, v[0], v[1]);
+        } else {
+            const int y = x - n_full, blk = y >> 5, l8 = (y >> 2) & 7, pr = y & 3;      // blk = n * 3 + q; l8 = g_i * 4 + kg
+            const int n = blk / 3, q = blk % 3, g_i = l8 >> 2, kg = l8 & 3;
+#pragma unroll
+            for (int z = 0; z < 2; z++) {
+                const int e = 2 * pr + z, lev = e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4);
+                v[z] = img[RT_W1C + (n * 50 + 48 + g_i) * RT_LD1 + 32 * q + lev];
+            }
+            put(simg + RT_SIMG2_T3 + (size_t)blk * 3 * 32 + l8 * 4 + pr, 32, v[0], v[1]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward solve (classical RK4); stage inputs -> tape in register-image order
 //   tape[((tile*n_steps + step)*4 + stage)*3072 + (q*4 + g)*256 + lane*4 + e] = X[q][4g + e]
@@ -2071,14 +2117,27 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 // The same solve with a FOURTH wavefront (the workgroup's idle SIMD) as helper: it evaluates the Richardson-number closure of all three variables
 // once per stage — the diffusive face fluxes go to LDS, the rich tape's nine pullback coefficients to HBM — while the three net waves run their
 // chains; a second bare barrier per stage (B) hands the fluxes over.  Every wave executes exactly the barriers (B) and (A) in every stage.
-template <int ACT, bool RICH, bool RKC = false>
+// SPLIT (COLNDE_FWD_SPLIT=1, RK4 only): layers 1 and 2 on v_mfma_f32_16x16x32_bf16 from exact three-way operand splits (rt16_forward_kernel<ACT, true>;
+// image RT_SIMG2_*: rt_pack_split_ns_kernel); layer 3 and the biases stay on the tail of the fp32 image
+template <int ACT, bool RICH, bool RKC = false, bool SPLIT = false>
 __global__ void __launch_bounds__(256)
 rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
                      const float* __restrict__ save_times, int n_save, int substeps, float* __restrict__ sol,
                      float* __restrict__ t16_tape, float* __restrict__ t16_ztape, int n_col) {
     float* wl = rt_smem;
-    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += 256) wl[e] = wimg[e];
+    const u32x4* simg = reinterpret_cast<const u32x4*>(rt_smem);
     f32x4v* ex = reinterpret_cast<f32x4v*>(rt_smem + ((RT_IMG_FLOATS + 3) & ~3));          // [2 buffers][3 variables][2 tiles][64 lanes]
+    if constexpr (SPLIT) {
+        // LDS: [bf16 operand image RT_SIMG2_WORDS][fp32 image from RT_W3C on: W3 and the biases][exchange][closure]
+        const u32x4* src = reinterpret_cast<const u32x4*>(wimg + RT_SIMG2_OFF);
+        u32x4* dst = reinterpret_cast<u32x4*>(rt_smem);
+        for (int e = threadIdx.x; e < RT_SIMG2_WORDS / 4; e += 256) dst[e] = src[e];
+        for (int e = threadIdx.x; e < RT_IMG_FLOATS - RT_W3C; e += 256) rt_smem[RT_SIMG2_WORDS + e] = wimg[RT_W3C + e];
+        wl = rt_smem + RT_SIMG2_WORDS - RT_W3C;                                            // wl[RT_W3C ...], wl[RT_B1C ...] as in the fp32 layout
+        ex = reinterpret_cast<f32x4v*>(rt_smem + RT_SIMG2_WORDS + ((RT_IMG_FLOATS - RT_W3C + 3) & ~3));
+    } else {
+        for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += 256) wl[e] = wimg[e];
+    }
     f32x4v* cl = ex + 2 * 384;                                                             // the helper wave's closure fluxes [3 variables][2 tiles][64 lanes]
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -2091,6 +2150,8 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
     const bool valid = col < n_col;
     const int colc = min(col, n_col - 1);
     const int i_ = lane & 15, g_i = i_ >> 2, r_i = i_ & 3;
+    const bool live3 = r_i == 0 && g_i < 2;            // (SPLIT) this lane holds a row of the net's fourth layer-1 tile
+    const int l83 = g_i * 4 + (lane >> 4);
     int a1b[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -2247,6 +2308,16 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                 const float top_raw = n == 2 ? rt_top_flux(m, bc5, ts + ca * dt) : bct;
                 RT_STAMP(0);
                 // ---- net n ----------------------------------------------------------------------------------------------
+                int lz = lane;
+                Bf3 XB[3];
+                if constexpr (SPLIT) {
+                    asm volatile("" : "+v"(lz));          // operand addresses stay (lane base + immediate): see rt16_forward_kernel
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const float x8[8] = {Xs[q].t[0][0], Xs[q].t[0][1], Xs[q].t[0][2], Xs[q].t[0][3], Xs[q].t[1][0], Xs[q].t[1][1], Xs[q].t[1][2], Xs[q].t[1][3]};
+                        XB[q] = bf3_split8(x8);
+                    }
+                }
                 f32x4t A1[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -2256,9 +2327,25 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                         const int Q = 4 * t + r;
                         acc[r] = Q < 13 ? wl[RT_B1C + n * 50 + min(4 * Q + g, 49)] : 0.0f;
                     }
+                    if constexpr (SPLIT) {
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            Bf3 A;
+                            if (t < 3) A = rt16_ldA(simg, (n * 3 + t) * 3 + q, lz);
+                            else {          // the net's fourth tile holds quad 12 alone: rows 0 and 4 (features 48, 49); every other lane reads the zero operand
+                                const int at = live3 ? RT_SIMG2_T3 / 4 + (n * 3 + q) * 24 + l83 + (lz - lane) : RT_SIMG2_ZERO / 4 + (lz - lane);
+                                A.h = simg[at]; A.m = simg[at + (live3 ? 8 : 0)]; A.l = simg[at + (live3 ? 16 : 0)];
+                            }
+                            acc = mfma16_bf3(A, XB[q], acc);
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                        RT_SCHED_FENCE();
+                    } else {
                     const int base = a1b[t];
                     acc = rt16_chain<24, 8>(wl, acc, [=](int k) { return base + (k >> 3) * 32 + ((k >> 2) & 1) * 16 + (k & 3); },
                                             [&](int k) { return Xs[k >> 3].t[(k >> 2) & 1][k & 3]; });
+                    }
                     if (oz) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -2277,14 +2364,34 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                 }
                 RT_STAMP(1);
                 f32x4t A2[2];
+                Bf3 HB[2];
+                if constexpr (SPLIT) {
+                    // the net's 13 quads of layer-1 activations as two 32-deep k-blocks (element e of block c: quad 8 c + e; three zero slots)
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        float a8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) a8[e] = 8 * c + e < 13 ? A1[(8 * c + e) >> 2][(8 * c + e) & 3] : 0.0f;
+                        HB[c] = bf3_split8(a8);
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     f32x4t acc;
 #pragma unroll
                     for (int r = 0; r < 4; r++) acc[r] = (4 * u + r < 5) ? wl[RT_B2C + n * 20 + 4 * (4 * u + r) + g] : 0.0f;
+                    if constexpr (SPLIT) {
+                        const Bf3 Aa = rt16_ldA(simg, 27 + (n * 2 + u) * 2, lz), Ab = rt16_ldA(simg, 27 + (n * 2 + u) * 2 + 1, lz);
+                        __builtin_amdgcn_s_setprio(1);
+                        acc = mfma16_bf3(Aa, HB[0], acc);
+                        acc = mfma16_bf3(Ab, HB[1], acc);
+                        __builtin_amdgcn_s_setprio(0);
+                        RT_SCHED_FENCE();
+                    } else {
                     const int base = a2b[u], basel = a2l[u];
                     acc = rt16_chain<13, 13>(wl, acc, [=](int k) { return k < 12 ? base + 4 * k : basel; },
                                              [&](int k) { return A1[k >> 2][k & 3]; });
+                    }
                     if (oz) {
 #pragma unroll
                         for (int r = 0; r < 4; r++)
@@ -3328,36 +3435,48 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, false, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true, false, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true, false, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true, false, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true, false, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true, false, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true, false, true>));
     RT_SETATTR(rt_dw1_kernel);
     RT_SETATTR(rt_dw1_split_kernel);
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
@@ -3476,9 +3595,15 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
     const size_t ldsh = lds + 384 * 16;
     const dim3 blockh(256);
     if (m.nst != 4 && !(m.rkc && use_helper)) return hipErrorInvalidValue;      // RKC2 lives in the four-wave kernels only
+    const char* esp = getenv("COLNDE_FWD_SPLIT");     // 1: layers 1 and 2 on the bf16 pipe with exact three-way operand splitting (opt-in; four-wave RK4 kernels)
+    const bool split = esp && atoi(esp) != 0 && use_helper && !m.rkc;
+    const size_t ldss = ((size_t)RT_SIMG2_WORDS + ((RT_IMG_FLOATS - RT_W3C + 3) & ~3)) * sizeof(float) + 3 * 384 * 16;
+    if (split) hipLaunchKernelGGL(rt_pack_split_ns_kernel, dim3(41), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_SIMG2_OFF);
 #define RT_FWDS(A)                                                                                                                              \
     do {                                                                                                                                        \
-        if (use_helper && rich && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        if (split && rich) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true, false, true>), grid, blockh, ldss, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else if (split) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false, false, true>), grid, blockh, ldss, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else if (use_helper && rich && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else if (use_helper && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else if (use_helper && rich) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else if (use_helper) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \

@@ -447,6 +447,38 @@ def test_forward_nets_on_the_bf16_pipe_with_exact_operand_splitting_are_float32_
     assert esp < max(1.5 * e32, 2e-6)
 
 
+@pytest.mark.parametrize("rich", ["0", "1"])
+def test_net_split_forward_on_the_bf16_pipe_with_exact_operand_splitting(rich, monkeypatch):
+    """COLNDE_FWD_SPLIT=1 under AUTO at a latency size: rt16sh_forward_kernel<ACT, RICH, false, true> (layers 1 and 2 of each net wave on
+    v_mfma_f32_16x16x32_bf16 from exact three-way splits, the per-net operand image of rt_pack_split_ns_kernel with its quarter-filled fourth
+    tile).  Same handle: trajectories within float32 round-off of the fp32-MFMA kernel and as close to the float64 oracle; the gradient taken
+    from the split forward's tapes (plain and rich) stays within the net-split tolerances."""
+    monkeypatch.setenv("COLNDE_T16_SPLIT_RICH", rich)
+    p = synthetic.wind_mixing_problem(40, n_frames=33, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        monkeypatch.setenv("COLNDE_FWD_SPLIT", "0")
+        s32 = nde.forward(p.weights)
+        t32, _, g32 = nde.loss_grad(p.weights, sc)
+        monkeypatch.setenv("COLNDE_FWD_SPLIT", "1")
+        ssp = nde.forward(p.weights)
+        tsp, terms_sp, gsp = nde.loss_grad(p.weights, sc)
+        plan = nde.plan()
+    assert plan["split_forward"] and plan["split_adjoint"]
+    d = np.abs(ssp - s32).max()
+    e32, esp = np.abs(s32 - sol).max(), np.abs(ssp - sol).max()
+    _record("test_net_split_fwd_split/rich" + rich, split_vs_fp32=d, fp32_vs_oracle=e32, split_vs_oracle=esp, grad_split_vs_fp32=_rel(gsp, g32.astype(np.float64)),
+            grad_split_vs_oracle=_rel(gsp, g), grad_fp32_vs_oracle=_rel(g32, g))
+    assert 0.0 < d < SOL_ATOL
+    assert esp < max(1.5 * e32, 2e-6)
+    np.testing.assert_allclose(terms_sp, terms, rtol=LOSS_RTOL, atol=1e-12)
+    assert _rel(gsp, g) < GRAD_REL
+    assert _rel(gsp, g) < max(1.5 * _rel(g32, g), 2e-6)
+
+
 # ---- the net-split kernels of the latency points (engine AUTO up to 8,192 columns of the regtile shape) -----------------
 @pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "diurnal", "conv_adj_branch", "swish", "raw", "dRi_small", "relu",
                                   "tanh", "leakyrelu"])
