@@ -629,15 +629,16 @@ def main():
             "loss_total": float(res[nde.n_params + 6]),
             "grad_l2": float(np.linalg.norm(res[:nde.n_params])),
         }
-        split_env = [k for k in ("COLNDE_FWD_SPLIT", "COLNDE_DW_SPLIT") if os.environ.get(k, "0") not in ("", "0")]
+        split_env = [k for k in ("COLNDE_FWD_SPLIT", "COLNDE_ADJ_SPLIT", "COLNDE_DW_SPLIT") if os.environ.get(k, "0") not in ("", "0")]
         line["roofline"]["matrix_arithmetic"] = ("f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)" if not split_env else
                                                  "f32 MFMA except the kernels switched by %s: bf16 MFMA on exact three-way operand splits" % "+".join(split_env))
         if world == 1 and regtile and not args.no_configs and not split_env:
-            # opt-in variant, outside the timed region: the same step with the forward nets and the dW1 GEMM on the bf16 pipe from EXACT three-way
+            # opt-in variant, outside the timed region: the same step with the forward nets, the adjoint's W1^T products and the dW1 GEMM on the bf16 pipe from EXACT three-way
             # operand splits (rt16_forward_kernel<ACT, true>, rt_dw1_split_kernel).  The default above is fp32 MFMA throughout.
             g32 = out[:nde.n_params].clone()
             loss32 = float(out[nde.n_params + 6])
             os.environ["COLNDE_FWD_SPLIT"] = "1"
+            os.environ["COLNDE_ADJ_SPLIT"] = "1"
             os.environ["COLNDE_DW_SPLIT"] = "1"
             try:
                 step()
@@ -652,7 +653,7 @@ def main():
                 km = {k: nde.kernel_time(k)[0] / max(nde.kernel_time(k)[1], 1) for k in ("forward", "adjoint", "dw1")}
                 gs = out[:nde.n_params]
                 line["opt_in"] = {"exact_split_bf16x3": {
-                    "switch": "COLNDE_FWD_SPLIT=1 COLNDE_DW_SPLIT=1", "ms_per_step": t_split * 1e3, "value": colsteps_per_step / t_split,
+                    "switch": "COLNDE_FWD_SPLIT=1 COLNDE_ADJ_SPLIT=1 COLNDE_DW_SPLIT=1", "ms_per_step": t_split * 1e3, "value": colsteps_per_step / t_split,
                     "kernel_ms": km,
                     "gradient_rel_l2_vs_f32_mfma": float((gs.double() - g32.double()).norm() / g32.double().norm()),
                     # the layer-1 blocks alone (W1, b1 lead each net's third of the vector): with the bench's weights/1e5 they are ~1e-10 of the whole
@@ -662,11 +663,13 @@ def main():
                     "layer1_gradient_rel_l2_vs_f32_mfma": float(sum(((gs[n * (nde.n_params // 3):n * (nde.n_params // 3) + 4850].double() - g32[n * (nde.n_params // 3):n * (nde.n_params // 3) + 4850].double()) ** 2).sum() for n in range(3)).sqrt()
                                                                 / sum((g32[n * (nde.n_params // 3):n * (nde.n_params // 3) + 4850].double() ** 2).sum() for n in range(3)).sqrt()),
                     "loss_rel_vs_f32_mfma": abs(float(out[nde.n_params + 6]) - loss32) / abs(loss32),
-                    "note": "forward nets and dW1 GEMM: fp32 operands split exactly into three bf16 each, six bf16 MFMA products per k-block, f32 accumulation "
-                            "(error bound of one f32 rounding per product); the adjoint kernel is unchanged; NOT the default, not in `value`"}}
+                    "note": "forward nets, the adjoint's W1^T products and the dW1 GEMM: fp32 operands split exactly into three bf16 each, six bf16 MFMA products per "
+                            "k-block, f32 accumulation (error bound of one f32 rounding per product); the rest of the adjoint kernel stays on f32 MFMA; NOT the default, "
+                            "not in `value`"}}
             finally:
                 nde.set_profiling(False)
                 os.environ["COLNDE_FWD_SPLIT"] = "0"
+                os.environ["COLNDE_ADJ_SPLIT"] = "0"
                 os.environ["COLNDE_DW_SPLIT"] = "0"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(prob, scal)

@@ -32,7 +32,17 @@
 #define RT_SIMG2_T3 (RT_SIMG2_L2 + 12 * 768)
 #define RT_SIMG2_ZERO (RT_SIMG2_T3 + 27 * 8 * 4)
 #define RT_SIMG2_WORDS (RT_SIMG2_ZERO + 4)
-#define RT_IMG_ALLOC (RT_SIMG2_OFF + RT_SIMG2_WORDS)
+// ... and for the regtile adjoint's W1^T products (rt_adjoint_kernel<ACT, true, true>, COLNDE_ADJ_SPLIT=1): group G = 9 n + 3 c + q (net, 16-deep k-block of
+// the net's delta registers 8 c .. 8 c + 7, state tile), lane (state row m, kh), element i = W1[50 n + 2 (8 c + i) + kh][32 q + m]:
+// [27 groups][planes h, m][64 lanes][8 bf16] and the fp32 rows of features 48, 49 ([net][kh][96]) go to LDS in place of the fp32 W1,
+// [27 groups][plane l][64 lanes][8 bf16] stay in global memory (L2) and are fetched into registers
+#define RT_ASIMG_OFF (RT_SIMG2_OFF + RT_SIMG2_WORDS)
+#define RT_ASIMG_HM_WORDS (27 * 2 * 256)
+#define RT_ASIMG_LEFT (RT_ASIMG_HM_WORDS)                 // 576 floats
+#define RT_ASIMG_L (RT_ASIMG_LEFT + 576)                  // 27 * 256 words
+#define RT_ASIMG_WORDS (RT_ASIMG_L + 27 * 256)
+#define RT_ASIMG_LDS_FLOATS (RT_ASIMG_HM_WORDS + 576 + ((RT_IMG_FLOATS - RT_W2C + 3) & ~3))      // planes, leftover rows, fp32 image from W2 on
+#define RT_IMG_ALLOC (RT_ASIMG_OFF + RT_ASIMG_WORDS)
 
 bool rt_supported(const DevModel& m);
 size_t rt_forward_lds_bytes();

@@ -419,6 +419,26 @@ __global__ void rt_pack_split_ns_kernel(const float* __restrict__ img, unsigned*
     }
 }
 
+// ... and the regtile adjoint's W1^T operands (RT_ASIMG_*)
+__global__ void rt_pack_split_adj_kernel(const float* __restrict__ img, unsigned* __restrict__ simg) {
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < 27 * 256 + 576; x += gridDim.x * blockDim.x) {
+        if (x >= 27 * 256) {
+            const int y = x - 27 * 256, n = y / 192, kh = (y / 96) & 1, c = y % 96;
+            reinterpret_cast<float*>(simg)[RT_ASIMG_LEFT + y] = img[RT_W1C + (n * 50 + 48 + kh) * RT_LD1 + c];
+            continue;
+        }
+        const int G = x >> 8, lane = (x >> 2) & 63, pr = x & 3;
+        const int n = G / 9, c = (G / 3) % 3, q = G % 3, m = lane & 31, kh = lane >> 5;
+        const float v0 = img[RT_W1C + (n * 50 + 2 * (8 * c + 2 * pr) + kh) * RT_LD1 + 32 * q + m];
+        const float v1 = img[RT_W1C + (n * 50 + 2 * (8 * c + 2 * pr + 1) + kh) * RT_LD1 + 32 * q + m];
+        const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+        const float l0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), l1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        simg[(size_t)(G * 2) * 256 + lane * 4 + pr] = (__float_as_uint(v1) & 0xffff0000u) | (__float_as_uint(v0) >> 16);
+        simg[(size_t)(G * 2 + 1) * 256 + lane * 4 + pr] = (__float_as_uint(r1) & 0xffff0000u) | (__float_as_uint(r0) >> 16);
+        simg[RT_ASIMG_L + (size_t)G * 256 + lane * 4 + pr] = (__float_as_uint(l1) & 0xffff0000u) | (__float_as_uint(l0) >> 16);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward solve (classical RK4); stage inputs -> tape in register-image order
 //   tape[((tile*n_steps + step)*4 + stage)*3072 + (q*4 + g)*256 + lane*4 + e] = X[q][4g + e]
@@ -774,21 +794,33 @@ __host__ __device__ constexpr int rt_combo(int n, int mt) { return n == 0 ? mt :
 // tape of stage inputs (written by rt_forward_kernel):  [tile][step][stage][12 groups][64 lanes][4]
 // tape2 of layer-1 deltas (written here, read by rt_dw1_kernel): [tile][step][stage][20 groups][64 lanes][4]; element e of
 // group grp is stacked register G = 4 grp + e = 25 n + g (features 2g, 2g+1 of net n; G >= 75: never written, never used)
-template <int ACT, bool ZT>
+// SPLIT (COLNDE_ADJ_SPLIT=1; with the Z1 tape only): the W1^T products — 225 of the stage's 552 fp32 MFMAs — on v_mfma_f32_32x32x16_bf16 from exact three-way
+// operand splits (csrc/split_bf16.h): the h and m planes of W1^T take the fp32 W1's place in LDS, the l planes come from L2 into registers, the delta
+// registers are split per 16-deep k-block; features 48, 49 of a net (register 24) keep one fp32 k-step.
+template <int ACT, bool ZT, bool SPLIT = false>
 __global__ void __launch_bounds__(256)
 rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ bcs,
                   const float* __restrict__ save_times, int n_save, int substeps, const float* __restrict__ sol,
                   const float* __restrict__ truth, const float* __restrict__ tape, float* __restrict__ tape2,
                   const float* __restrict__ tapez /* layer-1 pre-activations taped by the forward kernel (ZT) */,
                   LossWeights lw, float* __restrict__ slab, int n_col) {
+    static_assert(!SPLIT || ZT, "the split W1^T operands replace the fp32 W1 in LDS: no layer-1 recomputation");
     float* wl = rt_smem;
-    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
+    if constexpr (SPLIT) {
+        // LDS: [h, m planes of W1^T][fp32 rows of features 48, 49][fp32 image from W2 on]; wl[RT_W2C ...] etc. as in the fp32 layout
+        const u32x4* src = reinterpret_cast<const u32x4*>(wimg + RT_ASIMG_OFF);
+        for (int e = threadIdx.x; e < (RT_ASIMG_HM_WORDS + 576) / 4; e += blockDim.x) reinterpret_cast<u32x4*>(rt_smem)[e] = src[e];
+        for (int e = threadIdx.x; e < RT_IMG_FLOATS - RT_W2C; e += blockDim.x) rt_smem[RT_ASIMG_HM_WORDS + 576 + e] = wimg[RT_W2C + e];
+        wl = rt_smem + RT_ASIMG_HM_WORDS + 576 - RT_W2C;
+    } else {
+        for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x * RT_WAVES + wave;
     if (tile * RT_COLS >= n_col) return;
-    float* lam = rt_smem + ((RT_IMG_FLOATS + 3) & ~3) + wave * (3072 + RT_TB);   // λ: [48][64] floats, wave-private (16-byte aligned base)
+    float* lam = rt_smem + (SPLIT ? RT_ASIMG_LDS_FLOATS : ((RT_IMG_FLOATS + 3) & ~3)) + wave * (3072 + RT_TB);   // λ: [48][64] floats, wave-private (16-byte aligned base)
     float* tb = lam + 3072;                                            // transposition tile [32 columns][36]
     const int col = tile * RT_COLS + j;
     const bool valid = col < n_col;
@@ -997,6 +1029,16 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         }
                     }
                     RT_STAMP(4);
+                    // (SPLIT) the nine l-plane operands of this net's W1^T products: from L2, behind the W2^T chains
+                    u32x4 Lr[9];
+                    if constexpr (SPLIT) {
+                        // (an opaque lane index per net: left loop-invariant, the 27 loads are hoisted out of the time loop and their 108 registers spilled)
+                        int lz = lane;
+                        asm volatile("" : "+v"(lz));
+                        const u32x4* lg = reinterpret_cast<const u32x4*>(wimg + RT_ASIMG_OFF + RT_ASIMG_L) + n * 9 * 64 + lz;
+#pragma unroll
+                        for (int u = 0; u < 9; u++) Lr[u] = lg[u * 64];
+                    }
                     // (5) dZ1 = (W2^T dZ2) .* act'(Z1), in place; taped for the streaming dW1 kernel
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
@@ -1006,6 +1048,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
                         for (int r = 0; r < 16; r++) D1[t][r] = da[r] * D1[t][r];     // dZ1 in place of act'(z1)
                     }
+                    auto store_delta = [&] {
                     // delta tape: register g of net n is stacked register G = 25 n + g, element G & 3 of 16-byte group G >> 2.  Whole groups
                     // leave with one store; the groups that straddle a net boundary (6: G 24 | 25..27, 12: G 48, 49 | 50, 51) wait in
                     // `carry` for the next net's first registers, so a stage writes 19 16-byte stores and no scattered dwords
@@ -1028,8 +1071,42 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         RT_NT_STORE4(dst + 12 * 256, ((f32x4v){carry[0], carry[1], D1[0][0], D1[0][1]})); // G 48, 49 | 50, 51
                         RT_NT_STORE4(dst + 18 * 256, ((f32x4v){D1[1][6], D1[1][7], D1[1][8], 0.0f}));     // G 72, 73, 74, pad
                     }
+                    };
+                    if constexpr (!SPLIT) store_delta();       // (SPLIT: behind the W1^T products — vmcnt is in order, and the l-plane loads must not queue behind these stores)
                     RT_STAMP(5);
                     // (6) x̄ += W1_n^T dZ1_n
+                    if constexpr (SPLIT) {
+                        const u32x4* hm = reinterpret_cast<const u32x4*>(rt_smem) + lane;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            float d8[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) d8[u] = D1[(8 * c + u) >> 4][(8 * c + u) & 15];
+                            const Bf3 Bc = bf3_split8(d8);
+#pragma unroll
+                            for (int q = 0; q < 3; q++) {
+                                const int G = n * 9 + c * 3 + q, slot = c * 3 + q;
+                                const u32x4 Ah = hm[(G * 2) * 64], Am = hm[(G * 2 + 1) * 64];
+                                // net n + 1's 25 activation pairs, spread over slots 2 .. 8 (as in the fp32 chain: not under the first chunks)
+                                if (ZT && n < 2 && slot >= 2) {
+                                    if (slot < 8) rt_act_pair4_at<ACT>(A1n, D1n, 4 * (slot - 2));
+                                    else rt_act_pair_at<ACT>(A1n, D1n, 24);
+                                }
+                                xb[q] = mfma_bf(Am, Bc.m, xb[q]);
+                                xb[q] = mfma_bf(Ah, Bc.l, xb[q]);
+                                xb[q] = mfma_bf(Am, Bc.h, xb[q]);
+                                xb[q] = mfma_bf(Ah, Bc.m, xb[q]);
+                                xb[q] = mfma_bf(Ah, Bc.h, xb[q]);
+                                xb[q] = mfma_bf(Lr[slot], Bc.h, xb[q]);          // the operand from L2 last
+                                RT_SCHED_FENCE();
+                            }
+                        }
+                        // register 24 (features 48, 49): one fp32 k-step per state tile
+                        const float* left = rt_smem + RT_ASIMG_LEFT + (n * 2 + h) * 96 + i_;
+#pragma unroll
+                        for (int q = 0; q < 3; q++) xb[q] = mfma32(left[q * 32], D1[1][8], xb[q]);
+                        store_delta();
+                    } else
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
                         const int base = b1T + q * 32 + n * 50 * RT_LD1;
@@ -3522,11 +3599,17 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, true, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, true, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, true, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_SWISH, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_SWISH, true, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_TANH, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_TANH, true, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
+    RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true, true>));
 #undef RT_SETATTR
     return hipSuccess;
 }
@@ -3661,9 +3744,14 @@ hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* 
     const int n_wtiles = rt_n_wtiles(n_col);
     const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
     const size_t lds = rt_adjoint_lds_bytes();
+    const char* esp = getenv("COLNDE_ADJ_SPLIT");      // 1 (with the Z1 tape): the W1^T products on the bf16 pipe with exact three-way operand splitting (opt-in)
+    const bool split = esp && atoi(esp) != 0 && tapez;
+    if (split) hipLaunchKernelGGL(rt_pack_split_adj_kernel, dim3(30), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_ASIMG_OFF);
 #define RT_ADJ(A)                                                                                                             \
     do {                                                                                                                      \
-        if (tapez) hipLaunchKernelGGL((rt_adjoint_kernel<A, true>), grid, block, lds, stream, m, wimg, bcs, save_times, n_save, \
+        if (split) hipLaunchKernelGGL((rt_adjoint_kernel<A, true, true>), grid, block, lds, stream, m, wimg, bcs, save_times, n_save, \
+                                      substeps, sol, truth, tape, tape2, tapez, lw, slab, n_col);                      \
+        else if (tapez) hipLaunchKernelGGL((rt_adjoint_kernel<A, true>), grid, block, lds, stream, m, wimg, bcs, save_times, n_save, \
                                       substeps, sol, truth, tape, tape2, tapez, lw, slab, n_col);                      \
         else hipLaunchKernelGGL((rt_adjoint_kernel<A, false>), grid, block, lds, stream, m, wimg, bcs, save_times, n_save,    \
                                 substeps, sol, truth, tape, tape2, tapez, lw, slab, n_col);                            \

@@ -368,7 +368,8 @@ def test_regtile_engine_against_oracle(name):
 @pytest.mark.parametrize("env", [{"COLNDE_RT_ZTAPE": "0"}, {"COLNDE_RT_FWD": "32"}, {"COLNDE_RT_BLOCK": "32"},
                                  {"COLNDE_RT_BLOCK": "64", "COLNDE_RT_ZTAPE": "0"}, {"COLNDE_DW_SPLIT": "1"},
                                  {"COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}, {"COLNDE_FWD_SPLIT": "1"},
-                                 {"COLNDE_FWD_SPLIT": "1", "COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "64"}])
+                                 {"COLNDE_FWD_SPLIT": "1", "COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "64"}, {"COLNDE_ADJ_SPLIT": "1"},
+                                 {"COLNDE_ADJ_SPLIT": "1", "COLNDE_FWD_SPLIT": "1", "COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}])
 def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
     """The variants behind environment switches: no Z1 tape (the adjoint recomputes layer 1), the 32-column forward kernel
     (one wave per SIMD; implies no Z1 tape), and the column-blocked gradient path that problems larger than the free HBM
@@ -444,6 +445,33 @@ def test_forward_nets_on_the_bf16_pipe_with_exact_operand_splitting_are_float32_
     if name is None:
         assert d > 0.0                               # (the switch did select the other kernel; on 64 steps the two can round to the same trajectory)
     assert d < (LONG_SOL_ATOL if name is None else SOL_ATOL)
+    assert esp < max(1.5 * e32, 2e-6)
+
+
+@pytest.mark.parametrize("name", [None, "diurnal", "relu", "conv_adj_branch", "weights/4"])
+def test_adjoint_w1t_products_on_the_bf16_pipe_with_exact_operand_splitting_are_float32_grade(name, monkeypatch):
+    """COLNDE_ADJ_SPLIT=1: rt_adjoint_kernel<ACT, true, true> forms x̄ += W1ᵀ δz1 — 225 of the stage's 552 MFMAs — with v_mfma_f32_32x32x16_bf16 on the exact
+    three-way splits (W1ᵀ planes h, m in LDS, l from L2; δz1 split in registers; features 48, 49 on one fp32 k-step).  x̄ feeds λ, so every later stage sees
+    the difference.  Same handle, same tapes: the gradient differs from the fp32-MFMA kernel's by float32 round-off (stated: 2e-6 relative L2 on 24–288 frames),
+    and against the float64 oracle it is as close (within 1.5x)."""
+    from colnde.nde import ENGINE_REGTILE
+    kw = VARIANTS[name] if name in VARIANTS else {}
+    p = synthetic.wind_mixing_problem(96, n_frames=145 if name is None else 25, weight_divisor=4.0 if name == "weights/4" else 1e2, **kw)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, _ = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        monkeypatch.setenv("COLNDE_ADJ_SPLIT", "0")
+        t32, _, g32 = nde.loss_grad(p.weights, sc)
+        monkeypatch.setenv("COLNDE_ADJ_SPLIT", "1")
+        tsp, _, gsp = nde.loss_grad(p.weights, sc)
+        again = nde.loss_grad(p.weights, sc)[2]
+    assert t32 == tsp and np.array_equal(again, gsp)
+    d = _rel(gsp, g32.astype(np.float64))
+    e32, esp = _rel(g32, g), _rel(gsp, g)
+    _record("test_adj_split/" + str(name), split_vs_fp32=d, fp32_vs_oracle=e32, split_vs_oracle=esp)
+    assert 0.0 < d < 2e-6
     assert esp < max(1.5 * e32, 2e-6)
 
 
