@@ -1072,7 +1072,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         RT_NT_STORE4(dst + 18 * 256, ((f32x4v){D1[1][6], D1[1][7], D1[1][8], 0.0f}));     // G 72, 73, 74, pad
                     }
                     };
+#ifndef RT_ABL_NO_TAPE2     // (ablation probe, results wrong: what the delta tape's stores cost the adjoint — DESIGN §6)
                     if constexpr (!SPLIT) store_delta();       // (SPLIT: behind the W1^T products — vmcnt is in order, and the l-plane loads must not queue behind these stores)
+#endif
                     RT_STAMP(5);
                     // (6) x̄ += W1_n^T dZ1_n
                     if constexpr (SPLIT) {
