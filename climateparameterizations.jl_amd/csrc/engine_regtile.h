@@ -41,7 +41,6 @@
 #define RT_ASIMG_LEFT (RT_ASIMG_HM_WORDS)                 // 576 floats
 #define RT_ASIMG_L (RT_ASIMG_LEFT + 576)                  // 27 * 256 words
 #define RT_ASIMG_WORDS (RT_ASIMG_L + 27 * 256)
-#define RT_ASIMG_LDS_FLOATS (RT_ASIMG_HM_WORDS + 576 + ((RT_IMG_FLOATS - RT_W2C + 3) & ~3))      // planes, leftover rows, fp32 image from W2 on
 #define RT_IMG_ALLOC (RT_ASIMG_OFF + RT_ASIMG_WORDS)
 
 bool rt_supported(const DevModel& m);

@@ -807,11 +807,12 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     static_assert(!SPLIT || ZT, "the split W1^T operands replace the fp32 W1 in LDS: no layer-1 recomputation");
     float* wl = rt_smem;
     if constexpr (SPLIT) {
-        // LDS: [h, m planes of W1^T][fp32 rows of features 48, 49][fp32 image from W2 on]; wl[RT_W2C ...] etc. as in the fp32 layout
+        // LDS: the h, m planes of W1^T and the fp32 rows of features 48, 49 take the fp32 W1's place (14,400 of its 14,552 floats); the fp32 image from
+        // W2 on stays where it is, so wl[RT_W2C ...] etc. are unchanged
+        static_assert(RT_ASIMG_HM_WORDS + 576 <= RT_W2C, "the split W1^T operands must fit the fp32 W1's place");
         const u32x4* src = reinterpret_cast<const u32x4*>(wimg + RT_ASIMG_OFF);
         for (int e = threadIdx.x; e < (RT_ASIMG_HM_WORDS + 576) / 4; e += blockDim.x) reinterpret_cast<u32x4*>(rt_smem)[e] = src[e];
-        for (int e = threadIdx.x; e < RT_IMG_FLOATS - RT_W2C; e += blockDim.x) rt_smem[RT_ASIMG_HM_WORDS + 576 + e] = wimg[RT_W2C + e];
-        wl = rt_smem + RT_ASIMG_HM_WORDS + 576 - RT_W2C;
+        for (int e = RT_W2C + threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
     } else {
         for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += blockDim.x) wl[e] = wimg[e];
     }
@@ -820,7 +821,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     const int j = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x * RT_WAVES + wave;
     if (tile * RT_COLS >= n_col) return;
-    float* lam = rt_smem + (SPLIT ? RT_ASIMG_LDS_FLOATS : ((RT_IMG_FLOATS + 3) & ~3)) + wave * (3072 + RT_TB);   // λ: [48][64] floats, wave-private (16-byte aligned base)
+    float* lam = rt_smem + ((RT_IMG_FLOATS + 3) & ~3) + wave * (3072 + RT_TB);   // λ: [48][64] floats, wave-private (16-byte aligned base)
     float* tb = lam + 3072;                                            // transposition tile [32 columns][36]
     const int col = tile * RT_COLS + j;
     const bool valid = col < n_col;
