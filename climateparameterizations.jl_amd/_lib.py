@@ -23,6 +23,8 @@ SYMBOLS = [
     ("colnde_n_params", ctypes.c_int, [_V]),
     ("colnde_engine", ctypes.c_int, [_V]),
     ("colnde_set_stream", ctypes.c_int, [_V, _V]),
+    ("colnde_set_matrix_arithmetic", ctypes.c_int, [_V, ctypes.c_int]),
+    ("colnde_matrix_arithmetic", ctypes.c_int, [_V]),
     ("colnde_set_global_columns", ctypes.c_int, [_V, ctypes.c_int64]),
     ("colnde_set_problem", ctypes.c_int, [_V, _V, _V, _V]),
     ("colnde_rhs", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),

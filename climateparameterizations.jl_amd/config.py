@@ -27,6 +27,10 @@ ACT_NAMES = {v: k for k, v in ACT_IDS.items()}
 
 COLNDE_MAX_LAYERS = 8
 STEPPER_IDS = {"rk4": 0, "rkc2": 1}      # colnde.h: COLNDE_STEPPER_*
+# colnde.h: COLNDE_MATRIX_* — how the Float32 Dense products run on the matrix pipe (both are f32 arithmetic): the exact three-way bf16
+# operand split with f32 accumulation where a split kernel exists (default), or f32 MFMA throughout
+MATRIX_ARITHMETIC_IDS = {"bf16x3_exact": 0, "f32_mfma": 1}
+MATRIX_ARITHMETIC_NAMES = {v: k for k, v in MATRIX_ARITHMETIC_IDS.items()}
 
 
 @dataclass(frozen=True)
@@ -203,10 +207,21 @@ class CConfig(ctypes.Structure):
         ("engine", ctypes.c_int32),
         ("stepper", ctypes.c_int32),
         ("rkc_stages", ctypes.c_int32),
+        ("matrix_arithmetic", ctypes.c_int32),
     ]
 
 
-def to_c_config(cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0):
+def matrix_arithmetic_id(ma) -> int:
+    if isinstance(ma, str):
+        if ma not in MATRIX_ARITHMETIC_IDS:
+            raise ValueError("matrix_arithmetic must be one of %s" % sorted(MATRIX_ARITHMETIC_IDS))
+        return MATRIX_ARITHMETIC_IDS[ma]
+    if int(ma) not in MATRIX_ARITHMETIC_NAMES:
+        raise ValueError("matrix_arithmetic must be one of %s" % sorted(MATRIX_ARITHMETIC_IDS))
+    return int(ma)
+
+
+def to_c_config(cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0, matrix_arithmetic=0):
     """Build a `colnde_config`; returns (struct, keepalive) — keep both alive during the call."""
     cfg.validate()
     c = CConfig()
@@ -228,4 +243,5 @@ def to_c_config(cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0
     c.save_times = times.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
     c.n_columns, c.device, c.engine = int(n_columns), int(device), int(engine)
     c.stepper, c.rkc_stages = STEPPER_IDS[cfg.stepper], int(cfg.rkc_stages)
+    c.matrix_arithmetic = matrix_arithmetic_id(matrix_arithmetic)
     return c, times

@@ -60,6 +60,8 @@ struct colnde_handle {
     bool adj_split = false;         // ... and the gradient by rt16s_adjoint_kernel + tile16's dW GEMM
     bool fwd_split = false;         // forward solves by the net-split kernels (rt16sh_forward_kernel: three net waves + a helper wave per tile)
     bool use_rt = false;            // register-resident tile engine (static 96-50-20-31 wind-mixing shape)
+    bool sp_fwd = true, sp_adj = true, sp_dw = true;   // matrix arithmetic of the forward-solve / adjoint / weight-gradient kernels: exact three-way bf16 split (true) or
+                                                      // f32 MFMA — cfg.matrix_arithmetic with the test overrides COLNDE_{FWD,ADJ,DW}_SPLIT (resolve_arithmetic)
     bool use_fc = false;            // 32-column free-convection engine (engine_fc.hip: Nz = 32 | 64, the reference's relu network, RK4)
     float *d_fc_imgf = nullptr, *d_fc_imgb = nullptr, *d_fc_bias = nullptr;
     unsigned int* d_fc_masks = nullptr;
@@ -85,7 +87,7 @@ struct colnde_handle {
     float* d_dwtape = nullptr;
     float* d_t16_ztape = nullptr;   // taped mode: hidden pre-activations written by the forward kernel (the adjoint skips its forward GEMMs)
     DwMacro* d_macros = nullptr;
-    DwSplitPlan dw_split;                       // COLNDE_DW_SPLIT=1 when the tapes are planned: the dW GEMM on the bf16 pipe (exact operand splitting)
+    DwSplitPlan dw_split;                       // the dW GEMM on the bf16 pipe (exact operand splitting), built with the tapes' plan whenever the records fit LDS; used when sp_dw
     int n_macros = 0, dw_slices = 0, t16_rows = 0;
     int t16_block = 0, t16_nblocks = 0;   // taped mode: columns per pass (multiple of 16) — the tapes hold one block
     int *d_bias_zoff = nullptr, *d_bias_goff = nullptr;
@@ -130,6 +132,8 @@ static int validate(const colnde_config* c) {
         return fail("unknown engine %d", c->engine);
     if (c->stepper != COLNDE_STEPPER_RK4 && c->stepper != COLNDE_STEPPER_RKC2) return fail("unknown stepper %d", c->stepper);
     if (c->rkc_stages != 0 && (c->rkc_stages < 2 || c->rkc_stages > 256)) return fail("rkc_stages = %d outside 2..256 (0 = automatic)", c->rkc_stages);
+    if (c->matrix_arithmetic != COLNDE_MATRIX_BF16X3_EXACT && c->matrix_arithmetic != COLNDE_MATRIX_F32_MFMA)
+        return fail("unknown matrix_arithmetic %d (COLNDE_MATRIX_BF16X3_EXACT = 0, COLNDE_MATRIX_F32_MFMA = 1)", c->matrix_arithmetic);
     return 0;
 }
 
@@ -307,6 +311,19 @@ static void build_tables(const DevModel& m, std::vector<TileDesc>* tiles, std::v
         }
 }
 
+// cfg.matrix_arithmetic, per kernel family; COLNDE_FWD_SPLIT / COLNDE_ADJ_SPLIT / COLNDE_DW_SPLIT = 0 | 1 override one family each (test aid:
+// isolates one kernel's arithmetic against the others').  Read here only — at creation and in colnde_set_matrix_arithmetic — never per call.
+static void resolve_arithmetic(colnde_handle* h) {
+    const bool split = h->cfg.matrix_arithmetic == COLNDE_MATRIX_BF16X3_EXACT;
+    auto ov = [split](const char* name) {
+        const char* e = getenv(name);
+        return (e && *e) ? atoi(e) != 0 : split;
+    };
+    h->sp_fwd = ov("COLNDE_FWD_SPLIT");
+    h->sp_adj = ov("COLNDE_ADJ_SPLIT");
+    h->sp_dw = ov("COLNDE_DW_SPLIT");
+}
+
 extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     if (!out) return fail("null out pointer");
     *out = nullptr;
@@ -331,6 +348,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     h->n_col_total = cfg->n_columns;
     h->n_tiles = (cfg->n_columns + CT - 1) / CT;
     h->min_substeps = colnde_min_substeps(cfg);
+    resolve_arithmetic(h);
     build_model(cfg, &h->m, &h->pk);
     h->m.nst = 4;
     h->m.rkc = nullptr;
@@ -501,6 +519,16 @@ extern "C" int colnde_set_stream(colnde_handle* h, void* s) {
     h->stream = (hipStream_t)s;
     return 0;
 }
+
+extern "C" int colnde_set_matrix_arithmetic(colnde_handle* h, int ma) {
+    if (!h) return fail("null handle");
+    if (ma != COLNDE_MATRIX_BF16X3_EXACT && ma != COLNDE_MATRIX_F32_MFMA)
+        return fail("unknown matrix_arithmetic %d (COLNDE_MATRIX_BF16X3_EXACT = 0, COLNDE_MATRIX_F32_MFMA = 1)", ma);
+    h->cfg.matrix_arithmetic = ma;
+    resolve_arithmetic(h);
+    return 0;
+}
+extern "C" int colnde_matrix_arithmetic(const colnde_handle* h) { return h ? h->cfg.matrix_arithmetic : -1; }
 
 extern "C" int colnde_set_global_columns(colnde_handle* h, int64_t n) {
     if (!h) return fail("null handle");
@@ -692,7 +720,7 @@ static int rt_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int 
     hipError_t e = rt_launch_forward(h->m, h->d_wimg, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
                                      h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
                                      with_tape ? h->d_rt_tape : nullptr, (with_tape && h->rt_ztape) ? h->d_rt_tapez : nullptr, nc,
-                                     h->rt_fwd32, h->stream);
+                                     h->rt_fwd32, h->sp_fwd, h->stream);
     if (e != hipSuccess) return fail("rt forward launch failed: %s", hipGetErrorString(e));
     return 0;
 }
@@ -713,7 +741,7 @@ static int t16_forward_range(colnde_handle* h, const float* d_weights, float* d_
         if (es == hipSuccess)
             es = rt_launch_forward_split(h->m, h->d_wimg, h->d_x0 + (size_t)c0 * ns, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
                                          h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
-                                         with_tape ? h->d_tape : nullptr, with_tape ? h->d_t16_ztape : nullptr, nc, with_tape && h->split_rich, h->fwd_helper, h->stream);
+                                         with_tape ? h->d_tape : nullptr, with_tape ? h->d_t16_ztape : nullptr, nc, with_tape && h->split_rich, h->fwd_helper, h->sp_fwd, h->stream);
         if (es != hipSuccess) return fail("split forward launch failed: %s", hipGetErrorString(es));
         return 0;
     }
@@ -852,9 +880,8 @@ static void build_dw_macros(colnde_handle* h, size_t n_rec, std::vector<DwMacro>
                 }
         }
     h->n_macros = (int)mac.size();
-    const char* esp = getenv("COLNDE_DW_SPLIT");
     dw_split_free(h->dw_split);
-    if (esp && atoi(esp) != 0 && dw_gemm_lds_fits((int)R, h->n_macros)) (void)dw_split_build(mac, matrix_of, (int)R, h->dw_split);
+    if (dw_gemm_lds_fits((int)R, h->n_macros)) (void)dw_split_build(mac, matrix_of, (int)R, h->dw_split);
     const int n_groups = (h->n_macros + 3) / 4;
     size_t slices = std::max<size_t>(8, ((size_t)2048 / n_groups + 7) / 8 * 8);
     slices = std::min(slices, std::max<size_t>(8, (n_rec / 8 + 7) / 8 * 8));
@@ -1070,13 +1097,13 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                 e = rt_launch_adjoint(h->m, h->d_wimg, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                       h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_rt_tape,
                                       h->d_rt_tape2, h->rt_ztape ? h->d_rt_tapez : nullptr, lw,
-                                      h->d_rt_slab + (size_t)(c0 / 32) * stride, nc, h->stream);
+                                      h->d_rt_slab + (size_t)(c0 / 32) * stride, nc, h->sp_adj, h->stream);
                 if (e != hipSuccess) return fail("rt adjoint launch failed: %s", hipGetErrorString(e));
             }
             {
                 Timed tm(h, K_DW1);
                 e = rt_launch_dw1(h->m, h->d_rt_tape, h->d_rt_tape2, nc, n_steps, h->d_rt_slab + ((size_t)n_wt + (size_t)b * n_dw) * stride,
-                                  h->stream);
+                                  h->sp_dw, h->stream);
                 if (e != hipSuccess) return fail("rt dW1 launch failed: %s", hipGetErrorString(e));
             }
         }
@@ -1119,7 +1146,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                 }
                 {
                     Timed tm(h, K_DW1);
-                    if (!h->dw_split.passes.empty())
+                    if (h->sp_dw && !h->dw_split.passes.empty())
                         e = launch_dw_gemm_split(h->d_dwtape, tiles_b * (cw / 16) * (size_t)(iv1 - iv0) * h->cfg.substeps * h->m.nst, (int)dwtape_row_floats(h->m), h->dw_split,
                                                  h->dw_slices, h->d_slab + (gemm_rows0 + ((size_t)b * nseg + sg) * h->dw_slices) * stride, stride, h->stream);
                     else
@@ -1170,7 +1197,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
             }
             {
                 Timed tm(h, K_DW1);
-                hipError_t e = !h->dw_split.passes.empty()
+                hipError_t e = (h->sp_dw && !h->dw_split.passes.empty())
                     ? launch_dw_gemm_split(h->d_dwtape, (size_t)tiles_b * n_steps * h->m.nst, (int)dwtape_row_floats(h->m), h->dw_split,
                                            h->dw_slices, h->d_slab + ((size_t)h->n_tiles + (size_t)b * h->dw_slices) * stride, stride, h->stream)
                     : launch_dw_gemm(h->d_dwtape, (size_t)tiles_b * n_steps * h->m.nst, (int)dwtape_row_floats(h->m), h->d_macros, h->n_macros,
@@ -1456,6 +1483,19 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
     info[0] = h->use_rt ? COLNDE_ENGINE_MFMA : (h->use_fc ? COLNDE_ENGINE_FC32 : COLNDE_ENGINE_GENERIC);
     // RKC2 on a model with a convective-adjustment switch: the gradient is the one-switch-pattern pullback (include/colnde.h)
     info[7] = (h->cfg.stepper == COLNDE_STEPPER_RKC2 && (h->m.model == COLNDE_MODEL_CONV_ADJ_NDE || (h->m.ca && !h->m.mpp))) ? 1 : 0;
+    // bits 1..3: which kernel families run the exact three-way bf16 split (where the engine has a split kernel for this shape)
+    bool bf_fwd = false, bf_adj = false, bf_dw = false;
+    if (h->use_rt) {
+        bf_fwd = h->sp_fwd && !h->rt_fwd32;
+        bf_adj = h->sp_adj && (h->d_rt_tape ? h->rt_ztape : !h->rt_fwd32);     // (needs the Z1 tape; before the tapes are planned: the expectation)
+        bf_dw = h->sp_dw;
+    } else if (h->use_fc) {
+        bf_dw = h->sp_dw && (h->d_dwtape ? !h->dw_split.passes.empty() : true);
+    } else {
+        bf_fwd = h->sp_fwd && h->fwd_split && h->fwd_helper && h->cfg.stepper == COLNDE_STEPPER_RK4;
+        bf_dw = h->sp_dw && h->t16_dwtape == 1 && !h->dw_split.passes.empty();
+    }
+    info[7] |= (bf_fwd ? 2 : 0) | (bf_adj ? 4 : 0) | (bf_dw ? 8 : 0);
     if (h->use_fc) {
         info[1] = h->fc_block;
         info[2] = h->fc_nblocks;

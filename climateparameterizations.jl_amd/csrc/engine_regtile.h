@@ -20,7 +20,7 @@
 #define RT_B3C (RT_B2C + 64)                       // [96]        n*32+face (face 0 -> 0)
 #define RT_IMG_FLOATS (RT_B3C + 96)
 // behind it in the same allocation: the forward nets as bf16 A operands of v_mfma_f32_16x16x32_bf16, three planes (exact split) per group,
-// [48 groups][3 planes][64 lanes][8 bf16] (COLNDE_FWD_SPLIT=1; rt16_forward_kernel<ACT, true>)
+// [48 groups][3 planes][64 lanes][8 bf16] (COLNDE_MATRIX_BF16X3_EXACT; rt16_forward_kernel<ACT, true>)
 #define RT_SIMG_OFF ((RT_IMG_FLOATS + 3) & ~3)
 #define RT_SIMG_GROUPS 48
 #define RT_SIMG_WORDS (RT_SIMG_GROUPS * 3 * 64 * 4)
@@ -32,7 +32,7 @@
 #define RT_SIMG2_T3 (RT_SIMG2_L2 + 12 * 768)
 #define RT_SIMG2_ZERO (RT_SIMG2_T3 + 27 * 8 * 4)
 #define RT_SIMG2_WORDS (RT_SIMG2_ZERO + 4)
-// ... and for the regtile adjoint's W1^T products (rt_adjoint_kernel<ACT, true, true>, COLNDE_ADJ_SPLIT=1): group G = 9 n + 3 c + q (net, 16-deep k-block of
+// ... and for the regtile adjoint's W1^T products (rt_adjoint_kernel<ACT, true, true>, COLNDE_MATRIX_BF16X3_EXACT): group G = 9 n + 3 c + q (net, 16-deep k-block of
 // the net's delta registers 8 c .. 8 c + 7, state tile), lane (state row m, kh), element i = W1[50 n + 2 (8 c + i) + kh][32 q + m]:
 // [27 groups][planes h, m][64 lanes][8 bf16] and the fp32 rows of features 48, 49 ([net][kh][96]) go to LDS in place of the fp32 W1,
 // [27 groups][plane l][64 lanes][8 bf16] stay in global memory (L2) and are fetched into registers
@@ -49,9 +49,9 @@ hipError_t rt_set_attributes();
 hipError_t rt_launch_pack(const DevModel& m, const float* w, float* wimg, hipStream_t stream);
 hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* x0, const float* bcs,
                              const float* save_times, int n_save, int substeps, float* sol, float* tape, float* tapez,
-                             int n_col, bool fwd32, hipStream_t stream);
+                             int n_col, bool fwd32, bool split, hipStream_t stream);
 hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const float* x0, const float* bcs, const float* save_times,
-                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, bool use_helper, hipStream_t stream);
+                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, bool use_helper, bool want_split, hipStream_t stream);
 size_t rt_split_rich_record_floats();   // floats per (tile, step, stage) of the net-split kernels' rich tape (which then takes the place of t16_ztape)
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
@@ -65,7 +65,7 @@ int rt_n_wtiles(int n_col);
 int rt_dw1_waves(int n_col, int n_steps);
 hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,
                              int substeps, const float* sol, const float* truth, const float* tape, float* tape2,
-                             const float* tapez, const LossWeights& lw, float* slab, int n_col, hipStream_t stream);
+                             const float* tapez, const LossWeights& lw, float* slab, int n_col, bool want_split, hipStream_t stream);
 hipError_t rt_launch_dw1(const DevModel& m, const float* tape, const float* tape2, int n_col, int n_steps, float* slab_rows,
-                         hipStream_t stream);
+                         bool split, hipStream_t stream);
 hipError_t rt_debug_read_stamps(unsigned long long* out8);

@@ -334,7 +334,7 @@ __global__ void rt_pack_kernel(DevModel m, const float* __restrict__ w, float* _
 }
 
 
-// The forward nets as A operands of v_mfma_f32_16x16x32_bf16 (COLNDE_FWD_SPLIT=1), made from the fp32 image: group G, plane p, lane (i = lane & 15,
+// The forward nets as A operands of v_mfma_f32_16x16x32_bf16 (COLNDE_MATRIX_BF16X3_EXACT), made from the fp32 image: group G, plane p, lane (i = lane & 15,
 // kg = lane >> 4), element e = the weight that multiplies the B element e of lane (column, kg) — see rt16_forward_kernel<ACT, true>:
 //   layer 1, G = 3 t + q            : row of quad Q = 4 t + (i & 3), feature 4 (Q % 13) + (i >> 2) of net Q / 13; input 32 q + level(kg, e),
 //                                     level = e < 4 ? 4 kg + e : 16 + 4 kg + (e - 4)          (the two D tiles of a 32-level variable)
@@ -794,7 +794,7 @@ __host__ __device__ constexpr int rt_combo(int n, int mt) { return n == 0 ? mt :
 // tape of stage inputs (written by rt_forward_kernel):  [tile][step][stage][12 groups][64 lanes][4]
 // tape2 of layer-1 deltas (written here, read by rt_dw1_kernel): [tile][step][stage][20 groups][64 lanes][4]; element e of
 // group grp is stacked register G = 4 grp + e = 25 n + g (features 2g, 2g+1 of net n; G >= 75: never written, never used)
-// SPLIT (COLNDE_ADJ_SPLIT=1; with the Z1 tape only): the W1^T products — 225 of the stage's 552 fp32 MFMAs — on v_mfma_f32_32x32x16_bf16 from exact three-way
+// SPLIT (COLNDE_MATRIX_BF16X3_EXACT; with the Z1 tape only): the W1^T products — 225 of the stage's 552 fp32 MFMAs — on v_mfma_f32_32x32x16_bf16 from exact three-way
 // operand splits (csrc/split_bf16.h): the h and m planes of W1^T take the fp32 W1's place in LDS, the l planes come from L2 into registers, the delta
 // registers are split per 16-deep k-block; features 48, 49 of a net (register 24) keep one fp32 k-step.
 template <int ACT, bool ZT, bool SPLIT = false>
@@ -1294,7 +1294,7 @@ rt_dw1_kernel(DevModel m, const float* __restrict__ tape, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// dW1 / db1 on the bf16 matrix pipe with EXACT three-way operand splitting (COLNDE_DW_SPLIT=1; opt-in)
+// dW1 / db1 on the bf16 matrix pipe with EXACT three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT, the default)
 //
 // A float has 24 significant bits = three bf16 (8 bits each): x = x_h + x_m + x_l exactly, by truncation (x_h = the top half of the
 // word, r = x - x_h is exact, x_m = the top half of r, x_l = r - x_m has at most 8 significant bits).  A product a b is then the nine
@@ -2197,7 +2197,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 // The same solve with a FOURTH wavefront (the workgroup's idle SIMD) as helper: it evaluates the Richardson-number closure of all three variables
 // once per stage — the diffusive face fluxes go to LDS, the rich tape's nine pullback coefficients to HBM — while the three net waves run their
 // chains; a second bare barrier per stage (B) hands the fluxes over.  Every wave executes exactly the barriers (B) and (A) in every stage.
-// SPLIT (COLNDE_FWD_SPLIT=1, RK4 only): layers 1 and 2 on v_mfma_f32_16x16x32_bf16 from exact three-way operand splits (rt16_forward_kernel<ACT, true>;
+// SPLIT (COLNDE_MATRIX_BF16X3_EXACT, RK4 only): layers 1 and 2 on v_mfma_f32_16x16x32_bf16 from exact three-way operand splits (rt16_forward_kernel<ACT, true>;
 // image RT_SIMG2_*: rt_pack_split_ns_kernel); layer 3 and the biases stay on the tail of the fp32 image
 template <int ACT, bool RICH, bool RKC = false, bool SPLIT = false>
 __global__ void __launch_bounds__(256)
@@ -3630,7 +3630,7 @@ bool rt_forward_is32() {
 
 hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* x0, const float* bcs,
                              const float* save_times, int n_save, int substeps, float* sol, float* tape, float* tapez,
-                             int n_col, bool fwd32, hipStream_t stream) {
+                             int n_col, bool fwd32, bool split, hipStream_t stream) {
     const size_t lds = rt_forward_lds_bytes();
     // COLNDE_RT_FWD=32 selects the one-wave-per-SIMD 32-column kernel (A/B aid); default: 16-column tiles, two waves per SIMD
     if (fwd32) {
@@ -3653,8 +3653,7 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
         int wpw = (n_wt16 + 255) / 256;
         wpw = wpw < 1 ? 1 : (wpw > RT16_WAVES ? RT16_WAVES : wpw);
         const dim3 grid((n_wt16 + wpw - 1) / wpw), block(64 * wpw);
-        const char* esp = getenv("COLNDE_FWD_SPLIT");     // 1: the nets on the bf16 pipe with exact three-way operand splitting (opt-in)
-        const bool split = esp && atoi(esp) != 0;
+        // split: the nets on the bf16 pipe with exact three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT)
         const size_t lds_split = ((size_t)RT_SIMG_WORDS + (RT_IMG_FLOATS - RT_B1C)) * sizeof(float);
         if (split) hipLaunchKernelGGL(rt_pack_split_kernel, dim3(48), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_SIMG_OFF);
 #define RT_FWD(A) do { if (split) hipLaunchKernelGGL((rt16_forward_kernel<A, true>), grid, block, lds_split, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, tape, tapez, n_col); \
@@ -3675,14 +3674,14 @@ hipError_t rt_launch_forward(const DevModel& m, const float* wimg, const float* 
 
 // the three-wavefronts-per-tile forward solve of the latency points; tapes (optional) in tile16's formats
 hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const float* x0, const float* bcs, const float* save_times,
-                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, bool use_helper, hipStream_t stream) {
+                                   int n_save, int substeps, float* sol, float* t16_tape, float* t16_ztape, int n_col, bool rich, bool use_helper, bool want_split, hipStream_t stream) {
     const size_t lds = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + 2 * 384 * 16;
     const dim3 grid((n_col + 15) / 16), block(192);
     const size_t ldsh = lds + 384 * 16;
     const dim3 blockh(256);
     if (m.nst != 4 && !(m.rkc && use_helper)) return hipErrorInvalidValue;      // RKC2 lives in the four-wave kernels only
-    const char* esp = getenv("COLNDE_FWD_SPLIT");     // 1: layers 1 and 2 on the bf16 pipe with exact three-way operand splitting (opt-in; four-wave RK4 kernels)
-    const bool split = esp && atoi(esp) != 0 && use_helper && !m.rkc;
+    // layers 1 and 2 on the bf16 pipe with exact three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT; four-wave RK4 kernels only)
+    const bool split = want_split && use_helper && !m.rkc;
     const size_t ldss = ((size_t)RT_SIMG2_WORDS + ((RT_IMG_FLOATS - RT_W3C + 3) & ~3)) * sizeof(float) + 3 * 384 * 16;
     if (split) hipLaunchKernelGGL(rt_pack_split_ns_kernel, dim3(41), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_SIMG2_OFF);
 #define RT_FWDS(A)                                                                                                                              \
@@ -3743,12 +3742,12 @@ hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const f
 
 hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* bcs, const float* save_times, int n_save,
                              int substeps, const float* sol, const float* truth, const float* tape, float* tape2,
-                             const float* tapez, const LossWeights& lw, float* slab, int n_col, hipStream_t stream) {
+                             const float* tapez, const LossWeights& lw, float* slab, int n_col, bool want_split, hipStream_t stream) {
     const int n_wtiles = rt_n_wtiles(n_col);
     const dim3 grid((n_wtiles + RT_WAVES - 1) / RT_WAVES), block(64 * RT_WAVES);
     const size_t lds = rt_adjoint_lds_bytes();
-    const char* esp = getenv("COLNDE_ADJ_SPLIT");      // 1 (with the Z1 tape): the W1^T products on the bf16 pipe with exact three-way operand splitting (opt-in)
-    const bool split = esp && atoi(esp) != 0 && tapez;
+    // with the Z1 tape: the W1^T products on the bf16 pipe with exact three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT)
+    const bool split = want_split && tapez;
     if (split) hipLaunchKernelGGL(rt_pack_split_adj_kernel, dim3(30), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_ASIMG_OFF);
 #define RT_ADJ(A)                                                                                                             \
     do {                                                                                                                      \
@@ -3773,11 +3772,10 @@ hipError_t rt_launch_adjoint(const DevModel& m, const float* wimg, const float* 
 }
 
 hipError_t rt_launch_dw1(const DevModel& m, const float* tape, const float* tape2, int n_col, int n_steps, float* slab_rows,
-                         hipStream_t stream) {
+                         bool split, hipStream_t stream) {
     const long items = (long)rt_n_wtiles(n_col) * n_steps * 4;
     const int waves = rt_dw1_waves(n_col, n_steps);
-    const char* es = getenv("COLNDE_DW_SPLIT");      // 1: dW1 on the bf16 pipe with exact three-way operand splitting (opt-in)
-    if (es && atoi(es) != 0)
+    if (split)      // dW1 on the bf16 pipe with exact three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT)
         hipLaunchKernelGGL(rt_dw1_split_kernel, dim3(waves / RT_WAVES), dim3(64 * RT_WAVES), RT_WAVES * RT_DW1_LDS * sizeof(float), stream, m,
                            tape, tape2, items, slab_rows);
     else

@@ -51,7 +51,7 @@ static inline size_t dwtape_row_floats(const DevModel& m) { return (size_t)dwtap
 bool dw_gemm_lds_fits(int row_floats, int n_macros);     // the LDS-staged dW kernel applies (else the L2-streaming one)
 hipError_t launch_dw_gemm(const float* dwtape, size_t n_records, int row_floats, const DwMacro* macros, int n_macros, int n_slices,
                           float* slab_rows, int slab_stride, hipStream_t stream);
-// dW GEMM on the bf16 pipe with exact three-way operand splitting (COLNDE_DW_SPLIT=1 when the plan is made; opt-in): the blocks are
+// dW GEMM on the bf16 pipe with exact three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT; the plan is built with the tapes whenever the records fit LDS): the blocks are
 // dealt to passes by layer so that a pass's operand features (split ONCE per record into LDS planes) and its accumulators fit one workgroup
 struct DwSeg { int src, len, dst; };                                  // floats of a record row [src, src + len) -> compact features [dst, dst + len)
 struct DwPassDesc { DwSeg seg[8]; int n_seg, Fc, m0, n_macros, maxm, nit; };

@@ -1462,7 +1462,7 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// dW GEMM with exact three-way bf16 operand splitting (opt-in).  One workgroup of 8 waves per slice of records, as above, but the record
+// dW GEMM with exact three-way bf16 operand splitting (COLNDE_MATRIX_BF16X3_EXACT).  One workgroup of 8 waves per slice of records, as above, but the record
 // does not go to LDS as floats: every thread loads its share (two adjacent features x eight columns, 8-byte loads, two records ahead in
 // registers), splits the values and writes three bf16 planes [feature][column half][8 bf16] — MFMA-operand order, so a block's operands
 // are 12 ds_read_b128 per record and nothing is split twice.  Two plane buffers, ONE bare barrier per record (a wave that passed the

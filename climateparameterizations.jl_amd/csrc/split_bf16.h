@@ -1,4 +1,4 @@
-// split_bf16.h — fp32 matrix products on the bf16 matrix pipe by EXACT three-way operand splitting (opt-in kernels).
+// split_bf16.h — fp32 matrix products on the bf16 matrix pipe by EXACT three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT, the default matrix arithmetic).
 //
 // A float has 24 significant bits = three bf16 (8 bits each): x = x_h + x_m + x_l exactly, by truncation (x_h = the top half of the
 // word, r = x - x_h is exact, x_m = the top half of r, x_l = r - x_m has at most 8 significant bits).  A product a b is then the nine

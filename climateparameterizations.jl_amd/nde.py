@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
-from .config import NDEConfig, to_c_config
+from .config import MATRIX_ARITHMETIC_NAMES, NDEConfig, matrix_arithmetic_id, to_c_config
 
 KERNEL_IDS = {"forward": 0, "adjoint": 1, "reduce": 2, "rhs": 3, "infer": 4, "dw1": 5, "convadj": 6, "adam": 7, "impldiff": 8}
 ENGINE_AUTO, ENGINE_TILE16, ENGINE_REGTILE, ENGINE_FC32 = 0, 1, 2, 3
@@ -53,14 +53,16 @@ def rkc_stages(cfg: NDEConfig) -> int:
 
 
 class ColumnNDE:
-    def __init__(self, cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0):
+    def __init__(self, cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0, matrix_arithmetic="bf16x3_exact"):
+        """matrix_arithmetic: "bf16x3_exact" (default: f32 products as six bf16 MFMA products of exact three-way operand splits, f32 accumulation,
+        wherever the engine has a split kernel) or "f32_mfma" (v_mfma_f32_* throughout) — include/colnde.h COLNDE_MATRIX_*."""
         cfg.validate()
         self.cfg = cfg
         self.n_columns = int(n_columns)
         self.device = int(device)
         self._h = ctypes.c_void_p()
         L = _lib.lib()
-        c, keep = to_c_config(cfg, n_columns, device, engine)
+        c, keep = to_c_config(cfg, n_columns, device, engine, matrix_arithmetic)
         _lib.check(L.colnde_create(ctypes.byref(c), ctypes.byref(self._h)))
         self._L = L
         self.n_params = L.colnde_n_params(self._h)
@@ -94,6 +96,14 @@ class ColumnNDE:
         import torch
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_matrix_arithmetic(self, matrix_arithmetic):
+        """Switch the handle between "bf16x3_exact" and "f32_mfma" (tapes and plans do not depend on it: same-handle A/B)."""
+        _lib.check(self._L.colnde_set_matrix_arithmetic(self._h, matrix_arithmetic_id(matrix_arithmetic)))
+
+    @property
+    def matrix_arithmetic(self) -> str:
+        return MATRIX_ARITHMETIC_NAMES[self._L.colnde_matrix_arithmetic(self._h)]
+
     def set_global_columns(self, n_total: int):
         _lib.check(self._L.colnde_set_global_columns(self._h, int(n_total)))
         self.n_columns_total = int(n_total)
@@ -114,7 +124,10 @@ class ColumnNDE:
         return dict(engine=info[0], block_columns=info[1], n_blocks=info[2], z1_taped=bool(info[3]) and info[0] == ENGINE_REGTILE,
                     time_segments=info[3] if info[0] == ENGINE_FC32 else 0,
                     dw_taped=bool(info[4]), dw_slices=info[5], split_forward=bool(info[6] & 1), split_adjoint=bool(info[6] & 2), split_rich_tape=bool(info[6] & 4),
-                    approximate_gradient=bool(info[7] & 1))
+                    approximate_gradient=bool(info[7] & 1),
+                    # which kernel families run the exact three-way bf16 split (the others: f32 MFMA)
+                    bf16x3_forward=bool(info[7] & 2), bf16x3_adjoint=bool(info[7] & 4), bf16x3_dw=bool(info[7] & 8),
+                    matrix_arithmetic=self.matrix_arithmetic)
 
     def pretrain_flux(self, flux_type: int, theta, m, v, profiles, bcs, fluxes, order, gradient_scaling: float, opt, update: bool = True):
         """`colnde_pretrain_flux_dev`: one `Flux.train!` pass (one ADAM update per sample, in `order`) over device tensors; `opt` is a

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define COLNDE_VERSION 102
+#define COLNDE_VERSION 103
 #define COLNDE_MAX_LAYERS 8
 
 enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_training.jl:56-165 */
@@ -56,6 +56,19 @@ enum { COLNDE_STEPPER_RK4 = 0,      /* classical RK4, `substeps` per save interv
                                        and is exact for smooth closures (the Richardson-number branch).  colnde_plan reports it
                                        (info[7] bit 0). */
 
+/* How the Float32 `Dense` products of the reference (W*x, NDE_training.jl:94-96; their transposes and outer products in the gradient) are
+ * evaluated on the matrix pipe.  Both are f32 arithmetic: f32 operands, f32 accumulation, no operand rounded.
+ *   BF16X3_EXACT (default, = 0): every f32 operand is split EXACTLY into three bf16 parts (x = x_h + x_m + x_l by truncation; 3 x 8 = 24
+ *     significant bits) and a product is the six part-products down to 2^-16 on v_mfma_f32_*_bf16 with f32 accumulation; the three dropped
+ *     part-products are below 2^-23 |a b| together — one f32 rounding of the product, which an f32 FMA chain commits at every step anyway
+ *     (measured: profiles/r03ze_split_error_probe.txt).  Inf/NaN operands give NaN (Inf - Inf in the split), which the solve calls report
+ *     as a non-finite loss; operands whose low part falls below the bf16 subnormal range lose that part (error below 2^-133 absolute).
+ *     Used where a split kernel exists (colnde_plan info[7] says which kernels ran on it); the other kernels run F32_MFMA.
+ *   F32_MFMA (= 1): v_mfma_f32_32x32x2_f32 / 16x16x4_f32 throughout (bitwise an fmaf chain; 1/16 of the bf16 pipe's rate).
+ * Test overrides (read when the arithmetic is resolved: colnde_create, colnde_set_matrix_arithmetic): COLNDE_FWD_SPLIT / COLNDE_ADJ_SPLIT /
+ * COLNDE_DW_SPLIT = 0 | 1 force the forward-solve / adjoint / weight-gradient-GEMM kernels individually. */
+enum { COLNDE_MATRIX_BF16X3_EXACT = 0, COLNDE_MATRIX_F32_MFMA = 1 };
+
 /* Mirrors the `constants`, `scalings`, `conditions` NamedTuples of prepare_parameters_NDE_training
  * (wind_mixing/src/NDE_training.jl:1-44, :205-207) and the parameter tail of the free-convection NDEs
  * (free_convection/src/free_convection_nde.jl:49-62). */
@@ -85,6 +98,7 @@ typedef struct colnde_config {
     int32_t engine;                              /* COLNDE_ENGINE_* */
     int32_t stepper;                             /* COLNDE_STEPPER_* (0 = RK4) */
     int32_t rkc_stages;                          /* RKC2: stages per step, 2..256; 0 = automatic (colnde_rkc_stages) */
+    int32_t matrix_arithmetic;                   /* COLNDE_MATRIX_* (0 = exact three-way bf16 split where a split kernel exists) */
 } colnde_config;
 
 typedef struct colnde_handle colnde_handle;
@@ -110,6 +124,10 @@ void colnde_destroy(colnde_handle* h);
 int  colnde_n_params(const colnde_handle* h);
 int  colnde_engine(const colnde_handle* h);                  /* engine actually selected */
 int  colnde_set_stream(colnde_handle* h, void* hip_stream);  /* default: the null stream */
+/* Switch the matrix arithmetic of an existing handle (COLNDE_MATRIX_*): tapes, plans and results layout do not depend on it, so the same
+ * handle can run both for an A/B on identical inputs.  colnde_matrix_arithmetic returns the configured value. */
+int  colnde_set_matrix_arithmetic(colnde_handle* h, int matrix_arithmetic);
+int  colnde_matrix_arithmetic(const colnde_handle* h);
 /* Global column count when columns are sharded over ranks: losses and gradients are normalised by it so
  * that a SUM all-reduce of the per-rank results is the global mean (NDE_training.jl:312-317). */
 int  colnde_set_global_columns(colnde_handle* h, int64_t n_columns_total);
@@ -240,7 +258,9 @@ int  colnde_allreduce_result_dev(colnde_handle* h, colnde_comm* comm, float* d_o
  * [5] tile16 taped mode: K-slices of the dW GEMM, [6] net-split kernels of the latency points (per 16-column tile one wavefront per flux net
  * plus a helper wavefront): bit 0 = forward solve, bit 1 = adjoint, bit 2 = with the rich tape (activations, their derivatives and the physics-pullback
  * coefficients taped by the forward kernel: blocks of at most 2,048 columns), [7] bit 0 = the gradient is the one-switch-pattern
- * RKC2 pullback, an approximation of the discrete adjoint (see COLNDE_STEPPER_RKC2); 0 = exact discrete adjoint of the stepper. */
+ * RKC2 pullback, an approximation of the discrete adjoint (see COLNDE_STEPPER_RKC2); 0 = exact discrete adjoint of the stepper;
+ * bits 1, 2, 3 = the forward-solve / adjoint / weight-gradient kernels of the handle's engine run BF16X3_EXACT (a cleared bit: F32_MFMA — the
+ * configured arithmetic, a test override, or no split kernel for this engine and shape). */
 int colnde_plan(const colnde_handle* h, int info[8]);
 
 /* ---- measurement: HIP-event timing of the handle's kernels on its stream.

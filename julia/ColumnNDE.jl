@@ -24,7 +24,11 @@ Base.@kwdef mutable struct Config
     n_save::Int32 = 2; substeps::Int32 = 2; save_times::Ptr{Float32} = C_NULL
     n_columns::Int32 = 1; device::Int32 = 0; engine::Int32 = 0
     stepper::Int32 = 0; rkc_stages::Int32 = 0                            # COLNDE_STEPPER_RK4 / _RKC2 (stands where the reference uses ROCK4)
+    matrix_arithmetic::Int32 = 0                                         # COLNDE_MATRIX_BF16X3_EXACT (0, default) / COLNDE_MATRIX_F32_MFMA (1)
 end
+
+const MATRIX_BF16X3_EXACT = Int32(0)   # Float32 Dense products as six bf16 MFMA products of exact three-way operand splits, f32 accumulation
+const MATRIX_F32_MFMA = Int32(1)       # v_mfma_f32_* throughout
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:colnde_last_error, libcolnde), Cstring, ())))
 
@@ -187,14 +191,34 @@ function compute_neural_network_forcing!(forcing::Matrix{Float32}, h::Handle, we
     forcing
 end
 
-"how the gradient path runs: (engine, block_columns, n_blocks, z1_taped, dw_taped, dw_slices, split_forward, split_adjoint, split_rich_tape,
-approximate_gradient = the one-switch-pattern RKC2 pullback, see COLNDE_STEPPER_RKC2 in colnde.h) — colnde_plan"
+"switch an existing handle between MATRIX_BF16X3_EXACT and MATRIX_F32_MFMA (tapes and plans do not depend on it) — colnde_set_matrix_arithmetic"
+set_matrix_arithmetic!(h::Handle, ma) = check(ccall((:colnde_set_matrix_arithmetic, libcolnde), Cint, (Ptr{Cvoid}, Cint), h.ptr, ma))
+matrix_arithmetic(h::Handle) = ccall((:colnde_matrix_arithmetic, libcolnde), Cint, (Ptr{Cvoid},), h.ptr)
+
+"how the gradient path runs: (engine, block_columns, n_blocks, z1_taped [regtile], time_segments [fc32], dw_taped, dw_slices, split_forward,
+split_adjoint, split_rich_tape, approximate_gradient = the one-switch-pattern RKC2 pullback, see COLNDE_STEPPER_RKC2 in colnde.h,
+bf16x3_forward / _adjoint / _dw = which kernel families run the exact three-way bf16 split) — colnde_plan (info[3] is the Z1-tape flag on
+the regtile engine, engine 2, and the number of time segments on fc32, engine 3: the same mapping as nde.py's plan())"
 function plan(h::Handle)
     info = zeros(Cint, 8)
     check(ccall((:colnde_plan, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Cint}), h.ptr, info))
-    (engine=info[1], block_columns=info[2], n_blocks=info[3], z1_taped=info[4] != 0, dw_taped=info[5] != 0, dw_slices=info[6],
+    engine = info[1]
+    (engine=engine, block_columns=info[2], n_blocks=info[3], z1_taped=info[4] != 0 && engine == 2, time_segments=engine == 3 ? Int(info[4]) : 0,
+     dw_taped=info[5] != 0, dw_slices=info[6],
      split_forward=(info[7] & 1) != 0, split_adjoint=(info[7] & 2) != 0, split_rich_tape=(info[7] & 4) != 0,
-     approximate_gradient=(info[8] & 1) != 0)
+     approximate_gradient=(info[8] & 1) != 0, bf16x3_forward=(info[8] & 2) != 0, bf16x3_adjoint=(info[8] & 4) != 0, bf16x3_dw=(info[8] & 8) != 0)
+end
+
+"The reference's closures at the reference's ARITIES, closed over a handle: what `ODEProblem`, `OptimizationFunction` and `Flux.train!` are handed
+today.  `NDE(x, p, t)` (NDE_training.jl:56), `NDE!(dx, x, p, t)` (training_postprocessing.jl:131; create that handle with inplace_variant = 1),
+`loss_NDE(weights, BCs)` / `loss_gradient_NDE(weights, BCs)` (NDE_training.jl:290-323; BCs were given to set_problem! and are ignored here, as the
+reference's closures capture everything but the weights), `∂T∂t(T, p, t)` (free_convection_nde.jl:29)."
+function reference_closures(h::Handle, loss_scalings::NamedTuple=(u=1f0, v=1f0, T=1f0, ∂u∂z=5f-3, ∂v∂z=5f-3, ∂T∂z=5f-3))
+    (NDE=(x, p, t) -> NDE(h, x, p, t),
+     NDE! =(dx, x, p, t) -> NDE!(h, dx, x, p, t),
+     ∂T∂t=(T, p, t) -> ∂T∂t(h, T, p, t),
+     loss_NDE=(weights, BCs) -> loss_gradient_NDE(h, weights, loss_scalings),
+     loss_gradient_NDE=(weights, BCs) -> loss_gradient_NDE(h, weights, loss_scalings))
 end
 
 # ---- multi-GPU: one Julia process per GPU, columns sharded, ONE exchange per optimiser iteration (include/colnde.h, colnde_comm_*) ----

@@ -73,4 +73,23 @@ def test_workload_switch_reaches_the_ranks_and_the_default_stays_the_headline():
     cmd = bench.launcher_command(4, ["--gpus", "4", "--workload", "free_convection", "--steps", "2"])
     assert cmd[-4:] == ["--workload", "free_convection", "--steps", "2"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     src = open(bench.__file__).read()
-    assert 'choices=["wind_mixing", "free_convection"], default="wind_mixing"' in src
+    assert 'choices=["wind_mixing", "free_convection", "inference"], default="wind_mixing"' in src
+
+
+def test_inference_workload_is_sharded_by_column_without_a_collective():
+    """BASELINE configs[4] (`--workload inference --gpus 8`: 65,536 columns dealt as 8 x 8,192): the launcher hands the switch to every rank,
+    the ranks' shards tile the grid exactly, and the workload's data path calls no collective (the reductions it makes are the timing barriers)."""
+    import ast
+    import bench
+    from colnde.distributed import shard_columns
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--workload", "inference"])
+    assert cmd[-2:] == ["--workload", "inference"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    shards = [shard_columns(65536, r, 8) for r in range(8)]
+    assert shards[0] == (0, 8192) and all(hi - lo == 8192 for lo, hi in shards) and all(shards[i][1] == shards[i + 1][0] for i in range(7))
+    ragged = [shard_columns(65536, r, 6) for r in range(6)]
+    assert ragged[0][0] == 0 and ragged[-1][1] == 65536 and all(ragged[i][1] == ragged[i + 1][0] for i in range(5))
+    fn = next(n for n in ast.parse(open(bench.__file__).read()).body if isinstance(n, ast.FunctionDef) and n.name == "inference_workload")
+    calls = {c.func.attr for c in ast.walk(fn) if isinstance(c, ast.Call) and isinstance(c.func, ast.Attribute)}
+    assert "infer_forcing" in calls and "allreduce_result" not in calls and "all_gather" not in calls
+    timed = [n for n in ast.walk(fn) if isinstance(n, ast.For) and any(isinstance(c, ast.Call) and getattr(c.func, "attr", "") == "infer_forcing" for c in ast.walk(n))]
+    assert timed and all(not any(isinstance(c, ast.Call) and getattr(c.func, "id", getattr(c.func, "attr", "")) in ("reduce_", "barrier", "allreduce") for c in ast.walk(n)) for n in timed)

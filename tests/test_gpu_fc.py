@@ -9,7 +9,7 @@ import colnde
 from colnde import synthetic
 from colnde.nde import ENGINE_FC32, ENGINE_TILE16
 from oracle import nde_oracle as O
-from tests.test_gpu_parity import _record, _rel, FC_SOL_ATOL, FC_LOSS_RTOL, FC_GRAD_REL
+from tests.test_gpu_parity import _arith, _record, _rel, FC_SOL_ATOL, FC_LOSS_RTOL, FC_GRAD_REL
 
 pytestmark = pytest.mark.gpu
 
@@ -240,7 +240,7 @@ def test_fc32_time_segmented_tapes_equal_the_single_pass(model, seg, block, cw, 
 
 @pytest.mark.parametrize("Nz,ncol,engine", [(64, 45, 0), (32, 70, 0), (64, 20, ENGINE_TILE16), (32, 33, ENGINE_TILE16)])
 def test_dw_gemm_on_the_bf16_pipe_with_exact_operand_splitting_is_float32_grade(Nz, ncol, engine, monkeypatch):
-    """COLNDE_DW_SPLIT=1 when the tapes are planned: `dw_gemm_split_kernel` contracts the same delta-tape records as `dw_gemm_lds_kernel`, in passes
+    """The tape GEMM alone on the split arithmetic: `dw_gemm_split_kernel` contracts the same delta-tape records as `dw_gemm_lds_kernel`, in passes
     by layer, with six bf16 MFMA products of the exact three-way splits of both operands (split once per record into LDS planes) in place of
     v_mfma_f32_32x32x2_f32.  Same forward and adjoint kernels, same tapes: the weight gradient differs from the fp32 GEMM's by float32 round-off
     (stated: 2e-6 relative L2), the bias gradients and the loss are bit-identical, and the gap to the float64 oracle is the same (within 1.5x)."""
@@ -249,13 +249,14 @@ def test_dw_gemm_on_the_bf16_pipe_with_exact_operand_splitting_is_float32_grade(
     sc = O.default_loss_scalings(p.cfg)
     tot, terms, g, _ = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
     out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("COLNDE_DW_SPLIT", mode)
-        with colnde.ColumnNDE(p.cfg, ncol, engine=engine) as nde:
-            nde.set_problem(p.x0, p.bcs, truth)
+    with colnde.ColumnNDE(p.cfg, ncol, engine=engine) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        for mode in ("0", "1"):
+            _arith(monkeypatch, nde, dw=mode == "1")
             out[mode] = nde.loss_grad(p.weights, sc)
             again = nde.loss_grad(p.weights, sc)
-        assert np.array_equal(again[2], out[mode][2])                   # bit-reproducible in either mode
+            assert nde.plan()["bf16x3_dw"] == (mode == "1")
+            assert np.array_equal(again[2], out[mode][2])               # bit-reproducible in either mode
     (t32, _, g32), (tsp, _, gsp) = out["0"], out["1"]
     assert t32 == tsp
     H, off, wmask = 4 * Nz, 0, np.zeros(p.cfg.n_params, bool)

@@ -34,6 +34,19 @@ def _rel(a, b):
     return np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-300)
 
 
+def _arith(monkeypatch, nde, fwd=None, adj=None, dw=None, base="f32_mfma"):
+    """Matrix arithmetic of an existing handle, per kernel family: `base` ("f32_mfma" | "bf16x3_exact", include/colnde.h COLNDE_MATRIX_*)
+    for all three, then single families forced through the test overrides COLNDE_{FWD,ADJ,DW}_SPLIT (True: exact three-way bf16 split,
+    False: f32 MFMA, None: as `base`).  The overrides are read when the arithmetic is resolved, i.e. by set_matrix_arithmetic here —
+    every test that compares the two arithmetics switches them itself, nothing depends on the environment pytest was started in."""
+    for k, v in (("COLNDE_FWD_SPLIT", fwd), ("COLNDE_ADJ_SPLIT", adj), ("COLNDE_DW_SPLIT", dw)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, "1" if v else "0")
+    nde.set_matrix_arithmetic(base)
+
+
 def _record(case, **errs):
     """With COLNDE_RECORD_ERRORS set, append the measured errors to gpurun_out/parity_errors.jsonl: the tolerances in this
     file are set to about 10x what this records (profiles/r03_parity_errors.json keeps the last measuring run)."""
@@ -365,15 +378,17 @@ def test_regtile_engine_against_oracle(name):
     assert _rel(grad_g, g) < GRAD_REL
 
 
+@pytest.mark.parametrize("ma", ["bf16x3_exact", "f32_mfma"])
 @pytest.mark.parametrize("env", [{"COLNDE_RT_ZTAPE": "0"}, {"COLNDE_RT_FWD": "32"}, {"COLNDE_RT_BLOCK": "32"},
-                                 {"COLNDE_RT_BLOCK": "64", "COLNDE_RT_ZTAPE": "0"}, {"COLNDE_DW_SPLIT": "1"},
-                                 {"COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}, {"COLNDE_FWD_SPLIT": "1"},
-                                 {"COLNDE_FWD_SPLIT": "1", "COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "64"}, {"COLNDE_ADJ_SPLIT": "1"},
-                                 {"COLNDE_ADJ_SPLIT": "1", "COLNDE_FWD_SPLIT": "1", "COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}])
-def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
-    """The variants behind environment switches: no Z1 tape (the adjoint recomputes layer 1), the 32-column forward kernel
-    (one wave per SIMD; implies no Z1 tape), and the column-blocked gradient path that problems larger than the free HBM
-    take (70 columns as blocks of 32 + 32 + 6 / 64 + 6 through one set of tapes)."""
+                                 {"COLNDE_RT_BLOCK": "64", "COLNDE_RT_ZTAPE": "0"}, {"COLNDE_DW_SPLIT": "0"},
+                                 {"COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}, {"COLNDE_FWD_SPLIT": "0"},
+                                 {"COLNDE_FWD_SPLIT": "1", "COLNDE_DW_SPLIT": "0", "COLNDE_RT_BLOCK": "64"}, {"COLNDE_ADJ_SPLIT": "1"},
+                                 {"COLNDE_ADJ_SPLIT": "0", "COLNDE_FWD_SPLIT": "1", "COLNDE_DW_SPLIT": "1", "COLNDE_RT_BLOCK": "32"}])
+def test_regtile_alternative_paths_against_oracle(env, ma, monkeypatch):
+    """The variants behind environment switches, under both matrix arithmetics (the handle's configured one, with single kernel families forced
+    the other way by the test overrides): no Z1 tape (the adjoint recomputes layer 1; its split W1ᵀ products need the tape, so it runs f32 MFMA),
+    the 32-column forward kernel (one wave per SIMD; f32 MFMA only; implies no Z1 tape), and the column-blocked gradient path that problems larger
+    than the free HBM take (70 columns as blocks of 32 + 32 + 6 / 64 + 6 through one set of tapes)."""
     from colnde.nde import ENGINE_REGTILE
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -381,18 +396,27 @@ def test_regtile_alternative_paths_against_oracle(env, monkeypatch):
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
     sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
     tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
-    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
+    with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE, matrix_arithmetic=ma) as nde:
         nde.set_problem(p.x0, p.bcs, truth)
         sol_g = nde.forward(p.weights)
         tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
-    _record("test_regtile_alternative_paths_against_oracle" + "/" + str(env), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g))
+        plan = nde.plan()
+    assert plan["matrix_arithmetic"] == ma
+    want = {k: (env[e] == "1" if e in env else ma == "bf16x3_exact") for k, e in (("bf16x3_forward", "COLNDE_FWD_SPLIT"), ("bf16x3_adjoint", "COLNDE_ADJ_SPLIT"),
+                                                                                   ("bf16x3_dw", "COLNDE_DW_SPLIT"))}
+    if env.get("COLNDE_RT_FWD") == "32":
+        want["bf16x3_forward"] = want["bf16x3_adjoint"] = False
+    if env.get("COLNDE_RT_ZTAPE") == "0":
+        want["bf16x3_adjoint"] = False
+    assert {k: plan[k] for k in want} == want
+    _record("test_regtile_alternative_paths_against_oracle" + "/" + ma + "/" + str(env), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / abs(tot), grad_rel=_rel(grad_g, g))
     assert np.abs(sol_g - sol).max() < SOL_ATOL
     np.testing.assert_allclose(terms_g, terms, rtol=LOSS_RTOL, atol=1e-12)
     assert _rel(grad_g, g) < GRAD_REL
 
 
 def test_dw1_on_the_bf16_pipe_with_exact_operand_splitting_is_float32_grade(monkeypatch):
-    """COLNDE_DW_SPLIT=1: rt_dw1_split_kernel contracts the same two tapes with six v_mfma_f32_32x32x16_bf16 products of the exact
+    """The dW1 GEMM alone on the split arithmetic: rt_dw1_split_kernel contracts the same two tapes with six v_mfma_f32_32x32x16_bf16 products of the exact
     three-way bf16 splits of both operands instead of v_mfma_f32_32x32x2_f32.  Same handle, same tapes: the layer-1 weight gradient of
     the two kernels differs by float32 round-off only (stated: 2e-6 relative L2 — the dropped cross terms are below 2^-23 per product),
     everything else in the gradient is bit-identical, and against the float64 oracle the split kernel is as close as the fp32 one
@@ -404,10 +428,11 @@ def test_dw1_on_the_bf16_pipe_with_exact_operand_splitting_is_float32_grade(monk
     tot, terms, g, _ = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
     with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
         nde.set_problem(p.x0, p.bcs, truth)
-        monkeypatch.setenv("COLNDE_DW_SPLIT", "0")
+        _arith(monkeypatch, nde)
         _, _, g32 = nde.loss_grad(p.weights, sc)
-        monkeypatch.setenv("COLNDE_DW_SPLIT", "1")
+        _arith(monkeypatch, nde, dw=True)
         _, _, gsp = nde.loss_grad(p.weights, sc)
+        assert nde.plan()["bf16x3_dw"] and not nde.plan()["bf16x3_forward"] and not nde.plan()["bf16x3_adjoint"]
     net = p.cfg.n_params // 3
     l1 = np.zeros(p.cfg.n_params, bool)
     for n in range(3):
@@ -423,7 +448,7 @@ def test_dw1_on_the_bf16_pipe_with_exact_operand_splitting_is_float32_grade(monk
 
 @pytest.mark.parametrize("name", [None, "diurnal", "relu", "mpp_bc_faces", "weights/4"])
 def test_forward_nets_on_the_bf16_pipe_with_exact_operand_splitting_are_float32_grade(name, monkeypatch):
-    """COLNDE_FWD_SPLIT=1: rt16_forward_kernel<ACT, true> evaluates the three flux nets with v_mfma_f32_16x16x32_bf16 on the exact three-way
+    """The forward solve alone on the split arithmetic: rt16_forward_kernel<ACT, true> evaluates the three flux nets with v_mfma_f32_16x16x32_bf16 on the exact three-way
     bf16 splits of weights (packed once) and activations (split in registers) — through the whole nonlinear solve, 2,304 stage evaluations at
     the bench horizon.  Same handle: the trajectory differs from the fp32-MFMA kernel's by float32 round-off (stated: 2e-5 in scaled units,
     the tolerance of the fp32 kernel itself against the oracle), and against the float64 oracle it is as close as the fp32 kernel (within 1.5x)."""
@@ -435,9 +460,9 @@ def test_forward_nets_on_the_bf16_pipe_with_exact_operand_splitting_are_float32_
     assert np.isfinite(sol).all()
     with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
         nde.set_problem(p.x0, p.bcs)
-        monkeypatch.setenv("COLNDE_FWD_SPLIT", "0")
+        _arith(monkeypatch, nde)
         s32 = nde.forward(p.weights)
-        monkeypatch.setenv("COLNDE_FWD_SPLIT", "1")
+        _arith(monkeypatch, nde, fwd=True)
         ssp = nde.forward(p.weights)
     d = np.abs(ssp - s32).max()
     e32, esp = np.abs(s32 - sol).max(), np.abs(ssp - sol).max()
@@ -450,7 +475,7 @@ def test_forward_nets_on_the_bf16_pipe_with_exact_operand_splitting_are_float32_
 
 @pytest.mark.parametrize("name", [None, "diurnal", "relu", "conv_adj_branch", "weights/4"])
 def test_adjoint_w1t_products_on_the_bf16_pipe_with_exact_operand_splitting_are_float32_grade(name, monkeypatch):
-    """COLNDE_ADJ_SPLIT=1: rt_adjoint_kernel<ACT, true, true> forms x̄ += W1ᵀ δz1 — 225 of the stage's 552 MFMAs — with v_mfma_f32_32x32x16_bf16 on the exact
+    """The adjoint kernel alone on the split arithmetic: rt_adjoint_kernel<ACT, true, true> forms x̄ += W1ᵀ δz1 — 225 of the stage's 552 MFMAs — with v_mfma_f32_32x32x16_bf16 on the exact
     three-way splits (W1ᵀ planes h, m in LDS, l from L2; δz1 split in registers; features 48, 49 on one fp32 k-step).  x̄ feeds λ, so every later stage sees
     the difference.  Same handle, same tapes: the gradient differs from the fp32-MFMA kernel's by float32 round-off (stated: 2e-6 relative L2 on 24–288 frames),
     and against the float64 oracle it is as close (within 1.5x)."""
@@ -462,9 +487,9 @@ def test_adjoint_w1t_products_on_the_bf16_pipe_with_exact_operand_splitting_are_
     tot, terms, g, _ = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
     with colnde.ColumnNDE(p.cfg, p.n_columns, engine=ENGINE_REGTILE) as nde:
         nde.set_problem(p.x0, p.bcs, truth)
-        monkeypatch.setenv("COLNDE_ADJ_SPLIT", "0")
+        _arith(monkeypatch, nde)
         t32, _, g32 = nde.loss_grad(p.weights, sc)
-        monkeypatch.setenv("COLNDE_ADJ_SPLIT", "1")
+        _arith(monkeypatch, nde, adj=True)
         tsp, _, gsp = nde.loss_grad(p.weights, sc)
         again = nde.loss_grad(p.weights, sc)[2]
     assert t32 == tsp and np.array_equal(again, gsp)
@@ -477,7 +502,7 @@ def test_adjoint_w1t_products_on_the_bf16_pipe_with_exact_operand_splitting_are_
 
 @pytest.mark.parametrize("rich", ["0", "1"])
 def test_net_split_forward_on_the_bf16_pipe_with_exact_operand_splitting(rich, monkeypatch):
-    """COLNDE_FWD_SPLIT=1 under AUTO at a latency size: rt16sh_forward_kernel<ACT, RICH, false, true> (layers 1 and 2 of each net wave on
+    """The split arithmetic under AUTO at a latency size, forward kernel alone: rt16sh_forward_kernel<ACT, RICH, false, true> (layers 1 and 2 of each net wave on
     v_mfma_f32_16x16x32_bf16 from exact three-way splits, the per-net operand image of rt_pack_split_ns_kernel with its quarter-filled fourth
     tile).  Same handle: trajectories within float32 round-off of the fp32-MFMA kernel and as close to the float64 oracle; the gradient taken
     from the split forward's tapes (plain and rich) stays within the net-split tolerances."""
@@ -488,10 +513,10 @@ def test_net_split_forward_on_the_bf16_pipe_with_exact_operand_splitting(rich, m
     tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
     with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
         nde.set_problem(p.x0, p.bcs, truth)
-        monkeypatch.setenv("COLNDE_FWD_SPLIT", "0")
+        _arith(monkeypatch, nde)
         s32 = nde.forward(p.weights)
         t32, _, g32 = nde.loss_grad(p.weights, sc)
-        monkeypatch.setenv("COLNDE_FWD_SPLIT", "1")
+        _arith(monkeypatch, nde, fwd=True)
         ssp = nde.forward(p.weights)
         tsp, terms_sp, gsp = nde.loss_grad(p.weights, sc)
         plan = nde.plan()

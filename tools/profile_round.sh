@@ -27,13 +27,15 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cw -o cw -
 echo "config 4: FETCH_SIZE / WRITE_SIZE done"
 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/cs -o cs -- $C > $OUT/cs.log 2>&1
 echo "config 4: SQ counters done"
+SQCSV=$(find $OUT/sq -name "*counter_collection.csv" | head -1)
+python3 $R/tools/traffic_from_pmc.py $(find $OUT/pf -name "*counter_collection.csv" | head -1) $(find $OUT/pw -name "*counter_collection.csv" | head -1) $TAG "$SQCSV" > $OUT/traffic.log 2>&1 || true
+cp $R/profiles/traffic.json $OUT/traffic.json || true
 for d in sq cs pf pw cf cw; do
   f=$(find $OUT/$d -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 $R/tools/sq_table.py $f > $OUT/${d}_table.csv
 done
 cp $(find $OUT/ks -name "*kernel_stats.csv" | head -1) $OUT/ks_kernel_stats.csv
 cp $(find $OUT/oc -name "*kernel_stats.csv" | head -1) $OUT/oc_kernel_stats.csv
-python3 $R/tools/traffic_from_pmc.py $(find $OUT/pf -name "*counter_collection.csv" | head -1) $(find $OUT/pw -name "*counter_collection.csv" | head -1) $TAG > $OUT/traffic.log 2>&1 || true
 # the raw per-dispatch dumps are large: keep the tables only
 rm -rf $OUT/ks $OUT/oc $OUT/pf $OUT/pw $OUT/sq $OUT/cf $OUT/cw $OUT/cs
 ls -la $OUT
