@@ -62,7 +62,9 @@ enum { COLNDE_STEPPER_RK4 = 0,      /* classical RK4, `substeps` per save interv
  *     significant bits) and a product is the six part-products down to 2^-16 on v_mfma_f32_*_bf16 with f32 accumulation; the three dropped
  *     part-products are below 2^-23 |a b| together — one f32 rounding of the product, which an f32 FMA chain commits at every step anyway
  *     (measured: profiles/r03ze_split_error_probe.txt).  Inf/NaN operands give NaN (Inf - Inf in the split), which the solve calls report
- *     as a non-finite loss; operands whose low part falls below the bf16 subnormal range lose that part (error below 2^-133 absolute).
+ *     as a non-finite loss.  Subnormals are not flushed (bf16 inputs, f32 results: measured, profiles/r04_split_edge_probe.txt), but the part of an
+ *     operand below 2^-133, the smallest bf16 subnormal, is dropped: operands are exact for |x| >= 2^-110 and carry an ABSOLUTE error below 2^-133
+ *     (9e-41) under that — F32_MFMA keeps full relative precision down to FLT_MIN.
  *     Used where a split kernel exists (colnde_plan info[7] says which kernels ran on it); the other kernels run F32_MFMA.
  *   F32_MFMA (= 1): v_mfma_f32_32x32x2_f32 / 16x16x4_f32 throughout (bitwise an fmaf chain; 1/16 of the bf16 pipe's rate).
  * Test overrides (read when the arithmetic is resolved: colnde_create, colnde_set_matrix_arithmetic): COLNDE_FWD_SPLIT / COLNDE_ADJ_SPLIT /

@@ -106,13 +106,15 @@ def test_config_field_is_validated_and_switchable():
 @pytest.mark.parametrize("log2_scale", [-100, -108, -118])
 def test_split_with_operands_near_flt_min(engine, log2_scale):
     """Weights scaled to 2^log2_scale x O(0.1): below 2^-110 (= 2^16 FLT_MIN) the low plane of the three-way split is a subnormal float, below
-    2^-118 the middle plane too.  What the hardware does with them (tools/probe/split_edge.hip -> profiles/r04_split_edge_probe.txt): the planes are
-    formed by VALU subtractions, which keep float32 subnormals; a part below the bf16 subnormal range cannot occur (every part of a float is a
-    multiple of 2^-149 > 2^-133·2^-16 — the bf16 format has the float's exponent range and the parts are bit fields of it).  Consequence tested
-    here on whole solves: with every net operand that small the nets' outputs (~1e-31 … 1e-36) vanish against the O(1) tendencies, so both
-    arithmetics must give the same finite trajectory, loss and — for the blocks whose scale is set by O(1) factors (b3: column sums of the
-    flux cotangent) — the same gradient as the float64 oracle; the remaining blocks are products with factors ~1e-33 and are compared between the
-    two arithmetics with an absolute floor at the float32 subnormal scale."""
+    2^-118 the middle plane too.  What the hardware does with them (tools/probe/split_edge.hip -> profiles/r04_split_edge_probe.txt, measured):
+    v_mfma_f32_32x32x16_bf16 honours subnormal bf16 INPUTS and keeps subnormal f32 RESULTS (nothing is flushed; a product below 2^-149 is 0), and
+    the planes are formed by VALU subtractions that keep float32 subnormals — but a plane is the TOP HALF of a float word, so whatever part of an
+    operand lies below 2^-133, the smallest bf16 subnormal, is dropped: the split represents x to within 2^-133 ≈ 9e-41 ABSOLUTE, exactly for
+    |x| >= 2^-110 and with relative error 2^-133 / |x| below that (1.6e-6 at 2^-116, 1.6e-4 at 2^-124, 2^-7 at FLT_MIN).  f32 MFMA keeps full
+    relative precision down to FLT_MIN.  Consequence tested here on whole solves: with every net operand that small the nets' outputs (~1e-31 …
+    1e-36) vanish against the O(1) tendencies, so both arithmetics must give the same finite trajectory, loss and — for the blocks whose scale
+    is set by O(1) factors (b3: column sums of the flux cotangent) — the same gradient as the float64 oracle; the remaining blocks are products
+    with factors ~1e-33 and are compared between the two arithmetics with an absolute floor at the float32 subnormal scale."""
     p = synthetic.wind_mixing_problem(70 if engine == ENGINE_REGTILE else 24, n_frames=9, weight_divisor=1e2)
     w = (p.weights.astype(np.float64) * 2.0 ** log2_scale).astype(np.float32)
     assert 0 < np.abs(w[w != 0]).max() < 2.0 ** (log2_scale + 1) and np.abs(w[w != 0]).max() > 1e-40
