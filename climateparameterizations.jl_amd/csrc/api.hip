@@ -64,6 +64,7 @@ struct colnde_handle {
                                                       // f32 MFMA — cfg.matrix_arithmetic with the test overrides COLNDE_{FWD,ADJ,DW}_SPLIT (resolve_arithmetic)
     bool use_fc = false;            // 32-column free-convection engine (engine_fc.hip: Nz = 32 | 64, the reference's relu network, RK4)
     float *d_fc_imgf = nullptr, *d_fc_imgb = nullptr, *d_fc_bias = nullptr;
+    unsigned int *d_fc_simgf = nullptr, *d_fc_simgb = nullptr;   // the split operand images (COLNDE_MATRIX_BF16X3_EXACT; 32-column tiles)
     unsigned int* d_fc_masks = nullptr;
     unsigned long long* d_fc_switch = nullptr;   // ConvectiveAdjustmentNDE: the taped switch patterns
     int fc_block = 0, fc_nblocks = 0, fc_rows = 0;   // gradient path: columns per pass (multiple of 32), passes, slab rows
@@ -465,6 +466,8 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         ALLOC(h->d_fc_imgf, fc_image_floats(m.Nz), float);
         ALLOC(h->d_fc_imgb, fc_image_floats(m.Nz), float);
         ALLOC(h->d_fc_bias, fc_bias_floats(m.Nz), float);
+        ALLOC(h->d_fc_simgf, fc_split_image_words(m.Nz), unsigned int);
+        ALLOC(h->d_fc_simgb, fc_split_image_words(m.Nz), unsigned int);
     }
     ALLOC(h->d_x0, (size_t)h->n_col * m.ns, float);
     ALLOC(h->d_bcs, (size_t)h->n_col * m.n_bc, float);
@@ -504,7 +507,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
                     h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc,
-                    h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks, h->d_fc_switch, h->d_fc_lam};
+                    h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks, h->d_fc_switch, h->d_fc_lam, h->d_fc_simgf, h->d_fc_simgb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     dw_split_free(h->dw_split);
@@ -762,7 +765,7 @@ static int fc_forward_range(colnde_handle* h, float* d_sol, bool with_tape, int 
     const float* init = iv0 == 0 ? h->d_x0 + (size_t)c0 * ns : d_sol + ((size_t)c0 * h->cfg.n_save + iv0) * ns;
     const size_t stride = iv0 == 0 ? ns : (size_t)h->cfg.n_save * ns;
     Timed tm(h, K_FORWARD);
-    hipError_t e = fc_launch_forward(h->m, h->fc_cw, h->d_fc_imgf, h->d_fc_bias, init, stride, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
+    hipError_t e = fc_launch_forward(h->m, h->fc_cw, h->d_fc_imgf, (h->sp_fwd && fc_split_supported(h->fc_cw)) ? h->d_fc_simgf : nullptr, h->d_fc_bias, init, stride, h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save,
                                      iv0, iv1, tape_iv0, h->cfg.substeps, d_sol ? d_sol + (size_t)c0 * h->cfg.n_save * ns : nullptr,
                                      with_tape ? h->d_dwtape : nullptr, with_tape ? h->d_fc_masks : nullptr, with_tape ? h->d_fc_switch : nullptr, nc,
                                      h->stream);
@@ -796,7 +799,7 @@ static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, 
         return rt_forward_range(h, d_sol, false, 0, h->n_col);
     }
     if (h->use_fc) {
-        hipError_t e = fc_launch_pack(h->m, h->fc_cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        hipError_t e = fc_launch_pack(h->m, h->fc_cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_simgf, h->d_fc_simgb, h->stream);
         if (e != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(e));
         return fc_forward_range(h, d_sol, false, 0, h->n_col);
     }
@@ -1120,7 +1123,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
         LossWeights lw;
         loss_weights(h, scalings, &lw);
         const size_t ns = h->m.ns;
-        hipError_t e = fc_launch_pack(h->m, h->fc_cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        hipError_t e = fc_launch_pack(h->m, h->fc_cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_simgf, h->d_fc_simgb, h->stream);
         if (e != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(e));
         HIPCHK(hipMemsetAsync(h->d_slab, 0, (size_t)h->fc_rows * stride * sizeof(float), h->stream));
         const int cw = h->fc_cw;
@@ -1138,7 +1141,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                 if (!(nseg > 1 && sg == nseg - 1) && fc_forward_range(h, h->d_sol, true, c0, nc, iv0, iv1)) return 1;
                 {
                     Timed tm(h, K_ADJOINT);
-                    e = fc_launch_adjoint(h->m, h->fc_cw, h->d_fc_imgb, h->d_times, h->cfg.n_save, iv0, iv1, h->cfg.substeps, h->d_sol + (size_t)c0 * h->cfg.n_save * ns,
+                    e = fc_launch_adjoint(h->m, h->fc_cw, h->d_fc_imgb, (h->sp_adj && fc_split_supported(h->fc_cw)) ? h->d_fc_simgb : nullptr, h->d_times, h->cfg.n_save, iv0, iv1, h->cfg.substeps, h->d_sol + (size_t)c0 * h->cfg.n_save * ns,
                                           h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_dwtape, h->d_fc_masks, h->d_fc_switch, lw.w[2],
                                           nseg > 1 ? h->d_fc_lam + (size_t)c0 * h->m.Nz : nullptr,
                                           h->d_slab + ((size_t)sg * n_wg + (size_t)(c0 / cw)) * stride, nc, h->stream);
@@ -1266,7 +1269,7 @@ extern "C" int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights
     if (h->use_fc && h->m.model == COLNDE_MODEL_FREE_CONVECTION) {
         // the reference's forcing network IS the fc32 shape (32-128-128-31 in double_gyre_nn.jl): the 32-column engine's sections, one evaluation
         const int cw = fc_tile_width(n_columns);                 // (the images are packed per call: this call's own tile width)
-        hipError_t ef = fc_launch_pack(h->m, cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->stream);
+        hipError_t ef = fc_launch_pack(h->m, cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, nullptr, nullptr, h->stream);
         if (ef != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(ef));
         Timed tm(h, K_INFER);
         ef = fc_launch_infer(h->m, cw, h->d_fc_imgf, h->d_fc_bias, d_T, d_top_flux, (float)h->m.Nz / Lz, d_out, n_columns, h->stream);
@@ -1490,6 +1493,8 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
         bf_adj = h->sp_adj && (h->d_rt_tape ? h->rt_ztape : !h->rt_fwd32);     // (needs the Z1 tape; before the tapes are planned: the expectation)
         bf_dw = h->sp_dw;
     } else if (h->use_fc) {
+        bf_fwd = h->sp_fwd && fc_split_supported(h->fc_cw);
+        bf_adj = h->sp_adj && fc_split_supported(h->fc_cw);
         bf_dw = h->sp_dw && (h->d_dwtape ? !h->dw_split.passes.empty() : true);
     } else {
         bf_fwd = h->sp_fwd && h->fwd_split && h->fwd_helper && h->cfg.stepper == COLNDE_STEPPER_RK4;

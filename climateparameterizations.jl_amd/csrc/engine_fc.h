@@ -14,17 +14,23 @@ hipError_t fc_set_kernel_attributes();
 // cw = columns per workgroup tile (32: v_mfma_f32_32x32x2_f32, the throughput shape; 16: v_mfma_f32_16x16x4_f32, half the matrix work per stage for
 // problems that cannot fill 32-column tiles on every CU); the operand images depend on it
 int fc_tile_width(int n_col);
-hipError_t fc_launch_pack(const DevModel& m, int cw, const float* w, float* imgf, float* imgb, float* bias, hipStream_t stream);
+// simgf / simgb (fc_split_image_words(Nz) words each, or null): the operand images of COLNDE_MATRIX_BF16X3_EXACT — every weight split exactly into three
+// bf16 planes, in each wave's stream order — packed beside the f32 images when the tile width is 32 (fc_split_supported)
+size_t fc_split_image_words(int Nz);
+bool fc_split_supported(int cw);
+hipError_t fc_launch_pack(const DevModel& m, int cw, const float* w, float* imgf, float* imgb, float* bias, unsigned int* simgf, unsigned int* simgb,
+                          hipStream_t stream);
 // Save intervals [iv_begin, iv_end) from x0 (column stride x0_stride floats).  dwtape == nullptr: plain forward solve.  Otherwise, from interval
 // tape_iv0 on (iv_begin <= tape_iv0 < iv_end; records numbered from its first step), the stage inputs
 // and hidden activations go into the records [tile32][step of this launch][stage][cw/16 records of 16 columns][R], the relu bits into masks [..][512] and
 // (ConvectiveAdjustmentNDE) the switch pattern into swtape [..][cw].  Stages per step: m.nst (4, or the RKC2 stage count when m.rkc is set).
-hipError_t fc_launch_forward(const DevModel& m, int cw, const float* imgf, const float* bias, const float* x0, size_t x0_stride, const float* bcs,
-                             const float* save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float* sol, float* dwtape,
-                             unsigned int* masks, unsigned long long* swtape, int n_col, hipStream_t stream);
+// simgf != null (and cw == 32): the split kernels (v_mfma_f32_32x32x16_bf16 on exact three-way operand splits) instead of the f32-MFMA ones
+hipError_t fc_launch_forward(const DevModel& m, int cw, const float* imgf, const unsigned int* simgf, const float* bias, const float* x0, size_t x0_stride,
+                             const float* bcs, const float* save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float* sol,
+                             float* dwtape, unsigned int* masks, unsigned long long* swtape, int n_col, hipStream_t stream);
 // slab: one row of n_params + 8 floats per tile (bias gradients and the squared-error sum; the weight gradients are the dW GEMM's).
 // lam_io [columns padded to 32][Nz]: carries λ between the time segments of a segmented gradient pass (null when one launch covers the axis).
-hipError_t fc_launch_adjoint(const DevModel& m, int cw, const float* imgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
+hipError_t fc_launch_adjoint(const DevModel& m, int cw, const float* imgb, const unsigned int* simgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
                              const float* sol, const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape,
                              float w_loss, float* lam_io, float* slab, int n_col, hipStream_t stream);
 // compute_neural_network_forcing! (double_gyre_nn.jl:149-168): T [n_col][Nz] model units, top_flux [n_col], out = -dz(wT) on cell centres

@@ -10,6 +10,9 @@ if os.environ.get("COLNDE_LIB"):      # A/B aid: another build of the library
     _lib.LIB_PATH = os.path.join(ROOT, "climateparameterizations.jl_amd", os.environ["COLNDE_LIB"])
 
 dev = torch.device("cuda", 0)
+MA = os.environ.get("COLNDE_MA", "bf16x3_exact")      # matrix arithmetic of every handle below (f32_mfma: the opt-out)
+_ColumnNDE = colnde.ColumnNDE
+colnde.ColumnNDE = lambda *a, **k: _ColumnNDE(*a, **dict(dict(matrix_arithmetic=MA), **k))
 which = sys.argv[1:] or ["2", "4s", "5"]
 
 
