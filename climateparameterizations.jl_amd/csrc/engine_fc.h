@@ -30,9 +30,22 @@ hipError_t fc_launch_forward(const DevModel& m, int cw, const float* imgf, const
                              float* dwtape, unsigned int* masks, unsigned long long* swtape, int n_col, hipStream_t stream);
 // slab: one row of n_params + 8 floats per tile (bias gradients and the squared-error sum; the weight gradients are the dW GEMM's).
 // lam_io [columns padded to 32][Nz]: carries λ between the time segments of a segmented gradient pass (null when one launch covers the axis).
-hipError_t fc_launch_adjoint(const DevModel& m, int cw, const float* imgb, const unsigned int* simgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
+hipError_t fc_launch_adjoint(const DevModel& m, int cw, const float* imgb, const unsigned int* simgb, const float* save_times, int n_save, int iv_begin, int iv_end,
+                             int substeps,
                              const float* sol, const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape,
                              float w_loss, float* lam_io, float* slab, int n_col, hipStream_t stream);
 // compute_neural_network_forcing! (double_gyre_nn.jl:149-168): T [n_col][Nz] model units, top_flux [n_col], out = -dz(wT) on cell centres
 hipError_t fc_launch_infer(const DevModel& m, int cw, const float* imgf, const float* bias, const float* T, const float* top_flux, float inv_dz,
                            float* out, int n_col, hipStream_t stream);
+
+// engine_fc_split.hip: the same kernels on v_mfma_f32_32x32x16_bf16 from exact three-way bf16 operand splits (COLNDE_MATRIX_BF16X3_EXACT; 32-column tiles):
+// one wave per 32-row tile of a hidden layer, activations as bf16 planes in LDS, split once in the producing wave's epilogue.  Reached through the
+// fc_launch_* calls above when the split images are handed over; tapes, slab rows and argument meaning are engine_fc.hip's.
+hipError_t fcs_set_kernel_attributes();
+hipError_t fcs_launch_pack(const DevModel& m, const float* w, unsigned int* simgf, unsigned int* simgb, hipStream_t stream);
+hipError_t fcs_launch_forward(const DevModel& m, const unsigned int* simgf, const float* bias, const float* x0, size_t x0_stride, const float* bcs,
+                              const float* save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float* sol, float* dwtape,
+                              unsigned int* masks, unsigned long long* swtape, int n_col, hipStream_t stream);
+hipError_t fcs_launch_adjoint(const DevModel& m, const unsigned int* simgb, const float* save_times, int n_save, int iv_begin, int iv_end, int substeps,
+                              const float* sol, const float* truth, float* dwtape, const unsigned int* masks, const unsigned long long* swtape,
+                              float w_loss, float* lam_io, float* slab, int n_col, hipStream_t stream);
