@@ -681,10 +681,11 @@ static int rt_plan_tapes(colnde_handle* h) {
     const size_t margin = (size_t)2 << 30;
     const size_t budget = free_b > margin ? free_b - margin : 0;
     const size_t per_col_x = (size_t)n_steps * 4 * 96 * sizeof(float), per_col_2 = (size_t)n_steps * 4 * ((21 * 256) / 32) * sizeof(float);
+    const size_t per_col_z = rt_tapez_floats(32, n_steps) / 32 * sizeof(float);      // (twice per_col_2 in the A/B build that tapes activation pairs)
     const int n32 = ((h->n_col + 31) / 32) * 32;
     int block = 0;
     for (int pass = 0; pass < 2 && block == 0; pass++) {
-        const size_t per_col = per_col_x + per_col_2 * (want_z ? 2 : 1);
+        const size_t per_col = per_col_x + per_col_2 + (want_z ? per_col_z : 0);
         const size_t fit = budget / per_col;
         if (fit >= (size_t)n32) block = n32;
         else if (fit >= 1024) {

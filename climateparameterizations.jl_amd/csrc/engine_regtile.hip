@@ -48,7 +48,11 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #ifndef RT_ADJ_CH
 #define RT_ADJ_CH 8       // A-operand prefetch depth (k-steps) of the adjoint kernel's layer-1 chains
 #endif
-#define RT_TAPEZ (21 * 256)   // floats per (tile, step, stage) of the layer-1 pre-activation tape: 3 nets x 7 groups x 64 lanes x 4
+#ifndef RT_ZRICH
+#define RT_ZRICH 0            // 1 (A/B build, VERDICT r3 task 3): the forward kernel tapes the layer-1 activation VALUES and DERIVATIVES (act(z1), act'(z1)) instead of
+#endif                        // z1 — twice the bytes of this tape (+50 GB written and read at the bench size), no layer-1 activation pairs in the adjoint's stage loop
+#define RT_TAPEZ_HALF (21 * 256)
+#define RT_TAPEZ ((RT_ZRICH ? 2 : 1) * RT_TAPEZ_HALF)   // floats per (tile, step, stage) of the layer-1 tape: 3 nets x 7 groups x 64 lanes x 4 (RT_ZRICH: values, then derivatives)
 #define RT_TAPE2 (20 * 256)   // ... of the layer-1 delta tape: 20 groups x 64 lanes x 4, the three nets' 25 registers stacked (G = 25 n + g)
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -892,7 +896,8 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     inject(0, false);
 
     // taped layer-1 pre-activations of net n at (step, stage): registers G' < 25 of Z (padding registers untouched)
-    auto load_z1 = [&](int step, int st, int n, f32x16 (&Z)[2]) {
+    // (RT_ZRICH: Z receives the taped activation values and Dz their derivatives; nothing is left to evaluate)
+    auto load_z1 = [&](int step, int st, int n, f32x16 (&Z)[2], f32x16 (&Dz)[2]) {
         const float* srcz = tpz + ((size_t)step * 4 + st) * RT_TAPEZ + n * 7 * 256;
 #pragma unroll
         for (int grp = 0; grp < 7; grp++) {
@@ -900,6 +905,15 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 if (4 * grp + e < 25) Z[grp >> 2][(grp & 3) * 4 + e] = v[e];
+        }
+        if (RT_ZRICH) {
+#pragma unroll
+            for (int grp = 0; grp < 7; grp++) {
+                const f32x4v v = RT_TAPE_LOAD4(srcz + RT_TAPEZ_HALF + grp * 256);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (4 * grp + e < 25) Dz[grp >> 2][(grp & 3) * 4 + e] = v[e];
+            }
         }
     };
 
@@ -954,14 +968,16 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     //     pre-activations were fetched and activated in the shadow of the previous net's W1^T products (6).
                     if (ZT) {
                         if (n == 0) {
-                            load_z1(step, st, 0, A1);
+                            load_z1(step, st, 0, A1, D1);
 #ifdef COLNDE_STAMPS
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             RT_STAMP(7);            // diagnostic build only: the exposed latency of net 0's Z1 loads
 #endif
+                            if (!RT_ZRICH) {
 #pragma unroll
-                            for (int G = 0; G < 24; G += 4) rt_act_pair4_at<ACT>(A1, D1, G);
-                            rt_act_pair_at<ACT>(A1, D1, 24);
+                                for (int G = 0; G < 24; G += 4) rt_act_pair4_at<ACT>(A1, D1, G);
+                                rt_act_pair_at<ACT>(A1, D1, 24);
+                            }
                         }
                     } else {
 #pragma unroll
@@ -1018,7 +1034,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     }
                     RT_STAMP(3);
                     // fetch net n + 1's taped pre-activations now: dW2, W2^T and the first W1^T chunk cover the HBM latency
-                    if (ZT && n < 2) load_z1(step, st, n + 1, A1n);
+                    if (ZT && n < 2) load_z1(step, st, n + 1, A1n, D1n);
                     // (SPLIT) the nine l-plane operands of this net's W1^T products: from L2, issued before the dW2 outer products (one phase earlier than needed: 56.5 -> 55.6 ms)
                     u32x4 Lr[9];
                     if constexpr (SPLIT) {
@@ -1091,7 +1107,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                                 const int G = n * 9 + c * 3 + q, slot = c * 3 + q;
                                 const u32x4 Ah = hm[(G * 2) * 64], Am = hm[(G * 2 + 1) * 64];
                                 // net n + 1's 25 activation pairs, spread over slots 2 .. 8 (as in the fp32 chain: not under the first chunks)
-                                if (ZT && n < 2 && slot >= 2) {
+                                if (ZT && !RT_ZRICH && n < 2 && slot >= 2) {
                                     if (slot < 8) rt_act_pair4_at<ACT>(A1n, D1n, 4 * (slot - 2));
                                     else rt_act_pair_at<ACT>(A1n, D1n, 24);
                                 }
@@ -1117,7 +1133,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                                                      [&](int g) { return D1[g >> 4][g & 15]; },
                                                      [&](int c) {
                                                          // net n + 1's 25 activation pairs, spread over the 15 chunks
-                                                         if (ZT && n < 2 && (q > 0 || c > 0)) {
+                                                         if (ZT && !RT_ZRICH && n < 2 && (q > 0 || c > 0)) {
 #pragma unroll
                                                              for (int G = 0; G < 24; G += 4)
                                                                  if ((G >> 2) * 2 + 2 == q * 5 + c)
@@ -1652,7 +1668,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                             const int nx = q * 10 + t + 1;                                        // the group after (q, t) in this order
                             if (nx < 30) Apf = rt16_ldA(simg, 3 * (nx % 10) + nx / 10, lz);
                             auto finish = [&](int tt) {        // tile tt is complete: tape store, activation
-                                if (tz) {
+                                if (tz && !RT_ZRICH) {
                                     float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
 #pragma unroll
                                     for (int r = 0; r < 4; r++) {
@@ -1664,6 +1680,22 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                                 //  asm statements pin the activation's inputs below the products' issue point and its results above the closing fence)
 #pragma unroll
                                 for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
+                                if (RT_ZRICH && tz) {
+                                    // value and derivative together (one exponential, one reciprocal), both taped
+                                    f32x2v a0, d0, a1, d1;
+                                    rt_act_pair4<ACT>((f32x2v){A1[tt][0], A1[tt][1]}, (f32x2v){A1[tt][2], A1[tt][3]}, a0, d0, a1, d1);
+                                    A1[tt] = (f32x4t){a0.x, a0.y, a1.x, a1.y};
+                                    const float dd[4] = {d0.x, d0.y, d1.x, d1.y};
+                                    float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
+#pragma unroll
+                                    for (int r = 0; r < 4; r++) {
+                                        const int Q = 4 * tt + r, qq = Q % 13;
+                                        if (Q < 39 && (qq < 12 || g < 2)) {
+                                            oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = A1[tt][r];
+                                            oz[RT_TAPEZ_HALF + ((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = dd[r];
+                                        }
+                                    }
+                                } else
                                 A1[tt] = rt_act4<ACT>(A1[tt]);
 #pragma unroll
                                 for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
@@ -1691,7 +1723,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                     }
                 } else {
                 auto finish1 = [&](int tt) {          // tile tt of layer 1 is complete: Z1 tape store, activation (pinned: see rt16_chain_fill)
-                    if (tz) {
+                    if (tz && !RT_ZRICH) {
                         float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -1701,6 +1733,21 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                     }
 #pragma unroll
                     for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
+                    if (RT_ZRICH && tz) {
+                        f32x2v a0, d0, a1, d1;
+                        rt_act_pair4<ACT>((f32x2v){A1[tt][0], A1[tt][1]}, (f32x2v){A1[tt][2], A1[tt][3]}, a0, d0, a1, d1);
+                        A1[tt] = (f32x4t){a0.x, a0.y, a1.x, a1.y};
+                        const float dd[4] = {d0.x, d0.y, d1.x, d1.y};
+                        float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int Q = 4 * tt + r, qq = Q % 13;
+                            if (Q < 39 && (qq < 12 || g < 2)) {
+                                oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = A1[tt][r];
+                                oz[RT_TAPEZ_HALF + ((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = dd[r];
+                            }
+                        }
+                    } else
                     A1[tt] = rt_act4<ACT>(A1[tt]);
 #pragma unroll
                     for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
