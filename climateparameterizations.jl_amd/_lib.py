@@ -29,6 +29,16 @@ SYMBOLS = [
     ("colnde_set_problem", ctypes.c_int, [_V, _V, _V, _V]),
     ("colnde_rhs", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
     ("colnde_forward", ctypes.c_int, [_V, _V, _V]),
+    ("colnde_error_estimate", ctypes.c_int, [_V, _V, _F]),
+    ("colnde_error_estimate_dev", ctypes.c_int, [_V, _V, _F]),
+    ("colnde_choose_substeps", ctypes.c_int, [_V, _V, ctypes.c_float, ctypes.POINTER(ctypes.c_int), _F]),
+    ("colnde_substeps", ctypes.c_int, [_V]),
+    ("colnde_flux", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_flux_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_loss_per_tstep", ctypes.c_int, [_V, _V, _V]),
+    ("colnde_loss_per_tstep_dev", ctypes.c_int, [_V, _V, _V]),
+    ("colnde_infer_dz_wT", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
+    ("colnde_infer_dz_wT_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
     ("colnde_loss", ctypes.c_int, [_V, _V, _F, _F, _F]),
     ("colnde_loss_grad", ctypes.c_int, [_V, _V, _F, _F, _F, _V]),
     ("colnde_infer_forcing", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),

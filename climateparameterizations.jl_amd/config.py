@@ -103,6 +103,9 @@ class NDEConfig:
     # stiffest diffusive mode, colnde_rkc_stages)
     stepper: str = "rk4"
     rkc_stages: int = 0
+    # the tolerance the reference hands its adaptive integrator (reltol=1f-3: NDE_training.jl:291; 1e-4: free_convection/src/solve.jl:4): used when
+    # substeps = 0 (the handle chooses the sub-step count in its first solve call) and by ColumnNDE.choose_substeps; see colnde_error_estimate
+    reltol: float = 1e-3
     # oracle-only diagnostic (tests/test_oracle.py::test_rkc2_switch_pullback): pull the convective-adjustment switch back stage
     # by stage — the exact discrete adjoint of the RKC recurrence, unbounded on switching right-hand sides; the product never does
     rkc_exact_switch_pullback: bool = False
@@ -167,8 +170,10 @@ class NDEConfig:
             raise ValueError("stepper must be 'rk4' or 'rkc2'")
         if self.rkc_stages != 0 and not (2 <= self.rkc_stages <= 256):
             raise ValueError("rkc_stages must be 0 (automatic) or 2..256")
-        if self.n_save < 2 or self.substeps < 1:
-            raise ValueError("need >= 2 save times and >= 1 substep")
+        if self.n_save < 2 or self.substeps < 0:
+            raise ValueError("need >= 2 save times and >= 1 substep (0: chosen from reltol)")
+        if not (0.0 <= self.reltol < 1.0):
+            raise ValueError("0 <= reltol < 1")
         if self.Nz < 4 or self.Nz > 128:
             raise ValueError("4 <= Nz <= 128")
 
@@ -208,6 +213,7 @@ class CConfig(ctypes.Structure):
         ("stepper", ctypes.c_int32),
         ("rkc_stages", ctypes.c_int32),
         ("matrix_arithmetic", ctypes.c_int32),
+        ("reltol", ctypes.c_float),
     ]
 
 
@@ -244,4 +250,5 @@ def to_c_config(cfg: NDEConfig, n_columns: int, device: int = 0, engine: int = 0
     c.n_columns, c.device, c.engine = int(n_columns), int(device), int(engine)
     c.stepper, c.rkc_stages = STEPPER_IDS[cfg.stepper], int(cfg.rkc_stages)
     c.matrix_arithmetic = matrix_arithmetic_id(matrix_arithmetic)
+    c.reltol = float(cfg.reltol)
     return c, times

@@ -95,6 +95,8 @@ struct colnde_handle {
     bool have_problem = false, have_truth = false;
     bool prof = false;
     int min_substeps = 1;           // least RK4 sub-steps per save interval inside the diffusive stability bound
+    bool auto_substeps = false;     // cfg.substeps = 0 at creation: the first solve call chooses the sub-step count from cfg.reltol (choose_substeps)
+    float last_estimate = -1.0f;    // ... and the error estimate it settled on
     float* d_rkc = nullptr;         // RKC2 coefficient table (DevModel::rkc)
     std::vector<PendingEvent> pending;
     double ms[K_COUNT] = {};
@@ -125,7 +127,8 @@ static int validate(const colnde_config* c) {
             return fail("zero_weights requires modified_pacanowski_philander (NDE_training.jl:192-194)");
     }
     if (c->n_save < 2 || !c->save_times) return fail("need >= 2 save times");
-    if (c->substeps < 1) return fail("substeps must be >= 1");
+    if (c->substeps < 0) return fail("substeps must be >= 1 (or 0: chosen from reltol by the first solve, colnde_choose_substeps)");
+    if (!(c->reltol >= 0.0f) || c->reltol >= 1.0f) return fail("reltol = %g outside [0, 1) (0 = the reference's 1e-3)", c->reltol);
     for (int i = 1; i < c->n_save; i++)
         if (!(c->save_times[i] > c->save_times[i - 1])) return fail("save_times must be strictly increasing");
     if (c->n_columns < 1) return fail("n_columns must be >= 1");
@@ -206,7 +209,7 @@ static double widest_interval(const colnde_config* c) {
 extern "C" int colnde_rkc_stages(const colnde_config* c) {
     if (validate(c)) return -1;
     if (c->rkc_stages) return c->rkc_stages;
-    const double z = stiff_lambda(c) * widest_interval(c) / c->substeps;
+    const double z = stiff_lambda(c) * widest_interval(c) / (c->substeps > 0 ? c->substeps : 1);
     int s = 2;
     while (s < 256 && COLNDE_RKC_SAFETY * rkc_tables(s, nullptr) < z) s++;
     return s;
@@ -342,19 +345,29 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     colnde_handle* h = new (std::nothrow) colnde_handle();
     if (!h) return fail("out of host memory");
     h->cfg = *cfg;
+    if (cfg->substeps == 0) {       // automatic: start from the least power of two inside the stability bound; the first solve call refines it
+        h->auto_substeps = true;
+        colnde_config c1 = *cfg;
+        c1.substeps = 1;
+        const int ms = colnde_min_substeps(&c1);
+        int s2 = 1;
+        while (s2 < ms) s2 *= 2;
+        h->cfg.substeps = s2;
+    }
+    if (h->cfg.reltol == 0.0f) h->cfg.reltol = 1e-3f;            // solve(...; reltol=1f-3): NDE_training.jl:291
     h->save_times.assign(cfg->save_times, cfg->save_times + cfg->n_save);
     h->cfg.save_times = h->save_times.data();
     h->device = cfg->device;
     h->n_col = cfg->n_columns;
     h->n_col_total = cfg->n_columns;
     h->n_tiles = (cfg->n_columns + CT - 1) / CT;
-    h->min_substeps = colnde_min_substeps(cfg);
+    h->min_substeps = colnde_min_substeps(&h->cfg);
     resolve_arithmetic(h);
     build_model(cfg, &h->m, &h->pk);
     h->m.nst = 4;
     h->m.rkc = nullptr;
     if (cfg->stepper == COLNDE_STEPPER_RKC2) {
-        const int s = colnde_rkc_stages(cfg);
+        const int s = colnde_rkc_stages(&h->cfg);
         std::vector<double> tab;
         rkc_tables(s, &tab);
         std::vector<float> ft((size_t)6 * RKC_LD, 0.0f);
@@ -790,8 +803,14 @@ static int check_stability(const colnde_handle* h) {
                 h->cfg.substeps, stiff_lambda(&h->cfg), COLNDE_RK4_REAL_BOUND, h->min_substeps);
 }
 
+static int choose_substeps_impl(colnde_handle* h, const float* d_weights, float reltol, int* chosen, float* estimate);
+
 static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape) {
     if (!h->have_problem) return fail("colnde_set_problem has not been called");
+    if (h->auto_substeps) {           // substeps = 0 at creation: settle the count now, from these weights and cfg.reltol
+        h->auto_substeps = false;
+        if (choose_substeps_impl(h, d_weights, h->cfg.reltol, nullptr, nullptr)) { h->auto_substeps = true; return 1; }
+    }
     if (check_stability(h)) return 1;
     if (h->use_rt) {
         // (the gradient path tapes block by block: colnde_loss_grad_dev drives rt_forward_range itself)
@@ -935,6 +954,14 @@ static int fc_plan_tapes(colnde_handle* h) {
                 block = (int)std::min<size_t>((size_t)n32, cols_iv);
                 if (block < n32 && block >= 8192) block = block / 8192 * 8192;
                 seg = (int)std::min<size_t>((size_t)n_iv, budget / (per_col_iv * (size_t)block));
+                // the partial-gradient slab grows with the number of segments ([tile][segment] + [block][segment][<= 512 slices] rows of n_params + 8
+                // floats: 50 GB at 128 segments of the 64-level network): it must fit beside the tapes it is chosen for
+                auto slab_bytes = [&](int sg) {
+                    const size_t nsg = ((size_t)n_iv + sg - 1) / sg, nblk = ((size_t)n32 + block - 1) / block;
+                    return ((size_t)(n32 / cw) + nblk * 512) * nsg * (size_t)(m.n_params + 8) * sizeof(float);
+                };
+                while (seg > 1 && per_col_iv * (size_t)block * seg + slab_bytes(seg) > budget) seg--;
+                if (per_col_iv * (size_t)block * seg + slab_bytes(seg) > budget) seg = 0;      // not even one interval with its slab: reported below
             }
         }
     }
@@ -1073,8 +1100,13 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
     if (!d_weights || !scalings || !d_out) return fail("null pointer argument");
     if (!h->have_truth) return fail("no truth trajectories: pass truth to colnde_set_problem");
     if (h->m.inplace) return fail("the in-place NDE! variant is an evaluation RHS; gradients use the training RHS (inplace_variant = 0)");
-    if (check_stability(h)) return 1;
     HIPCHK(hipSetDevice(h->device));
+    if (h->auto_substeps) {
+        if (!h->have_problem) return fail("colnde_set_problem has not been called");
+        h->auto_substeps = false;
+        if (choose_substeps_impl(h, d_weights, h->cfg.reltol, nullptr, nullptr)) { h->auto_substeps = true; return 1; }
+    }
+    if (check_stability(h)) return 1;
     const int stride = h->m.n_params + 8;
     if (h->use_rt) {
         if (!h->have_problem) return fail("colnde_set_problem has not been called");
@@ -1259,9 +1291,212 @@ extern "C" int colnde_loss_grad(colnde_handle* h, const float* weights, const fl
     return 0;
 }
 
+// ---- error-controlled time stepping: what `reltol` means at this boundary ------------------------------------------------------------
+// The reference hands the solve to an adaptive integrator (solve(prob, ROCK4(); reltol=1f-3, ...): NDE_training.jl:291,304,403; reltol=1e-4 at
+// free_convection/src/solve.jl:4).  This path steps at a fixed `substeps` per save interval, so the tolerance is enforced a posteriori: a second
+// forward solve at 2 x substeps and Richardson's estimate of the error of the first, e = (u_S - u_2S) 2^p / (2^p - 1) (p = 4: RK4, 2: RKC2), in
+// the integrator's own norm: per column and save point the RMS over the state's components of e_i / (abstol / reltol + |u_i|), abstol / reltol = 1e-3
+// (OrdinaryDiffEq's default abstol 1e-6 over the reference's reltol; its accept test is rms(err / (abstol + reltol |u|)) <= 1), then the maximum over
+// columns and save points.
+static int forward_at(colnde_handle* h, const float* d_weights, float* d_sol, int substeps) {
+    const int keep = h->cfg.substeps;
+    h->cfg.substeps = substeps;
+    const bool au = h->auto_substeps;
+    h->auto_substeps = false;
+    const int rc = forward_impl(h, d_weights, d_sol, false);
+    h->cfg.substeps = keep;
+    h->auto_substeps = au;
+    return rc;
+}
+
+static int tapes_planned(const colnde_handle* h) { return h->d_rt_tape || h->d_dwtape || h->d_tape; }
+
+// estimate at `substeps` given its solution d_a; d_b receives the solution at 2 x substeps; *d_est (device) the estimate
+static int estimate_from(colnde_handle* h, const float* d_weights, const float* d_a, float* d_b, int substeps, float* d_est) {
+    if (forward_at(h, d_weights, d_b, 2 * substeps)) return 1;
+    hipError_t e = launch_rel_diff_max(d_a, d_b, (long)h->n_col * h->cfg.n_save, h->m.ns, 1e-3f, h->d_partial, d_est, h->stream);
+    if (e != hipSuccess) return fail("error-estimate launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+static float richardson_factor(const colnde_handle* h) { return h->cfg.stepper == COLNDE_STEPPER_RKC2 ? 4.0f / 3.0f : 16.0f / 15.0f; }
+
+extern "C" int colnde_error_estimate_dev(colnde_handle* h, const float* d_weights, float* max_rel_err) {
+    if (!h) return fail("null handle");
+    if (!d_weights || !max_rel_err) return fail("null pointer argument");
+    if (!h->have_problem) return fail("colnde_set_problem has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n_col * h->cfg.n_save * h->m.ns;
+    float* d_b = nullptr;
+    HIPCHK(hipMalloc((void**)&d_b, (n + 4) * sizeof(float)));
+    int rc = forward_at(h, d_weights, h->d_sol, h->cfg.substeps);
+    if (!rc) rc = estimate_from(h, d_weights, h->d_sol, d_b, h->cfg.substeps, d_b + n);
+    float est = 0.0f;
+    if (!rc && (hipMemcpyAsync(&est, d_b + n, sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess))
+        rc = fail("error estimate: device-to-host copy failed");
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d_b);
+    if (rc) return 1;
+    *max_rel_err = est * richardson_factor(h);
+    return 0;
+}
+
+extern "C" int colnde_error_estimate(colnde_handle* h, const float* weights, float* max_rel_err) {
+    if (!h) return fail("null handle");
+    if (!weights || !max_rel_err) return fail("null pointer argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_w, weights, sizeof(float) * h->m.n_params, hipMemcpyHostToDevice, h->stream));
+    return colnde_error_estimate_dev(h, h->d_w, max_rel_err);
+}
+
+// The least power-of-two sub-step count (not below the stability bound) whose estimate meets reltol; the handle keeps it.
+static int choose_substeps_impl(colnde_handle* h, const float* d_weights, float reltol, int* chosen, float* estimate) {
+    if (tapes_planned(h)) return fail("the sub-step count sizes the tapes: choose it before the first colnde_loss_grad of this handle");
+    if (!(reltol > 0.0f)) return fail("reltol must be > 0");
+    const size_t n = (size_t)h->n_col * h->cfg.n_save * h->m.ns;
+    float* d_b = nullptr;
+    HIPCHK(hipMalloc((void**)&d_b, (2 * n + 4) * sizeof(float)));
+    float* buf[2] = {d_b, d_b + n};
+    int S = 1;
+    while (S < h->min_substeps) S *= 2;
+    int rc = forward_at(h, d_weights, buf[0], S);
+    float est = -1.0f, prev = -1.0f;
+    int cur = 0;
+    bool floor_hit = false;
+    while (!rc) {
+        rc = estimate_from(h, d_weights, buf[cur], buf[cur ^ 1], S, d_b + 2 * n);
+        if (rc) break;
+        float e = 0.0f;
+        if (hipMemcpyAsync(&e, d_b + 2 * n, sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+            rc = fail("choose_substeps: device-to-host copy failed");
+            break;
+        }
+        est = e * richardson_factor(h);
+        if (!(est == est) || est > 3.0e38f) { rc = fail("the solve is not finite at %d sub-steps per save interval: no sub-step count can be chosen", S); break; }
+        if (est <= reltol || S >= 4096) break;
+        // halving a fourth-order step divides the error by ~16 (second order: 4); an estimate that no longer falls by even a factor 2 is float32
+        // round-off of the two solves it compares (more steps only add to it): the tolerance is below what this arithmetic resolves
+        if (prev > 0.0f && est > 0.5f * prev) { floor_hit = true; break; }
+        prev = est;
+        S *= 2;                      // the solution at 2S is already there: it is the next candidate's own
+        cur ^= 1;
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d_b);
+    if (rc) return 1;
+    if (floor_hit) return fail("reltol = %g is below the float32 round-off floor of this solve: the estimate stopped falling at %g (%d sub-steps per save interval, "
+                               "%g at half as many)", reltol, est, S, prev);
+    if (est > reltol) return fail("reltol = %g is not met with %d sub-steps per save interval (estimate %g): the right-hand side is too stiff for this stepper", reltol, S, est);
+    h->cfg.substeps = S;
+    h->last_estimate = est;
+    if (chosen) *chosen = S;
+    if (estimate) *estimate = est;
+    return 0;
+}
+
+extern "C" int colnde_choose_substeps(colnde_handle* h, const float* weights, float reltol, int* substeps, float* estimate) {
+    if (!h) return fail("null handle");
+    if (!weights) return fail("null weights");
+    if (!h->have_problem) return fail("colnde_set_problem has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_w, weights, sizeof(float) * h->m.n_params, hipMemcpyHostToDevice, h->stream));
+    const bool au = h->auto_substeps;
+    h->auto_substeps = false;
+    const int rc = choose_substeps_impl(h, h->d_w, reltol > 0.0f ? reltol : h->cfg.reltol, substeps, estimate);
+    if (rc) h->auto_substeps = au;
+    return rc;
+}
+
+extern "C" int colnde_substeps(const colnde_handle* h) { return h ? h->cfg.substeps : -1; }
+
+// ---- flux diagnostics: predict_flux and loss_per_tstep ---------------------------------------------------------------------------------
+extern "C" int colnde_flux_dev(colnde_handle* h, const float* d_x, const float* d_weights, const float* d_bcs, float t, float* d_flux, int n_columns) {
+    if (!h) return fail("null handle");
+    if (!d_x || !d_weights || !d_bcs || !d_flux) return fail("null pointer argument");
+    if (n_columns < 1) return fail("n_columns must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    if (pack(h, d_weights)) return 1;
+    Timed tm(h, K_RHS);
+    hipError_t e = launch_rhs(h->m, h->pk, d_weights, h->d_wf, d_x, d_bcs, t, nullptr, n_columns, 256, h->lds_fwd, h->stream, d_flux);
+    if (e != hipSuccess) return fail("flux launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_flux(colnde_handle* h, const float* x, const float* weights, const float* bcs, float t, float* flux, int n_columns) {
+    if (!h) return fail("null handle");
+    if (!x || !weights || !bcs || !flux) return fail("null pointer argument");
+    if (n_columns < 1) return fail("n_columns must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    if (ensure_tmp(h, (size_t)n_columns)) return 1;
+    const DevModel& m = h->m;
+    const size_t nfl = (size_t)n_columns * m.n_nets * (m.Nz + 1);
+    float* d_fl = nullptr;
+    HIPCHK(hipMalloc((void**)&d_fl, nfl * sizeof(float)));
+    int rc = 1;
+    do {
+        if (hipMemcpyAsync(h->d_w, weights, sizeof(float) * m.n_params, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(h->d_tmp_a, x, sizeof(float) * (size_t)n_columns * m.ns, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(h->d_tmp_b, bcs, sizeof(float) * (size_t)n_columns * m.n_bc, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            fail("flux: host-to-device copy failed");
+            break;
+        }
+        if (colnde_flux_dev(h, h->d_tmp_a, h->d_w, h->d_tmp_b, t, d_fl, n_columns)) break;
+        if (hipMemcpyAsync(flux, d_fl, nfl * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+            fail("flux: device-to-host copy failed");
+            break;
+        }
+        rc = 0;
+    } while (0);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d_fl);
+    return rc;
+}
+
+extern "C" int colnde_loss_per_tstep_dev(colnde_handle* h, const float* d_weights, float* d_out) {
+    if (!h) return fail("null handle");
+    if (!d_weights || !d_out) return fail("null pointer argument");
+    if (!h->have_truth) return fail("no truth trajectories: pass truth to colnde_set_problem");
+    HIPCHK(hipSetDevice(h->device));
+    if (forward_impl(h, d_weights, h->d_sol, false)) return 1;
+    hipError_t e = launch_loss_per_tstep(h->d_sol, h->d_truth, h->n_col, h->cfg.n_save, h->m.Nz, h->m.ns / h->m.Nz, d_out, h->stream);
+    if (e != hipSuccess) return fail("loss_per_tstep launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int colnde_loss_per_tstep(colnde_handle* h, const float* weights, float* out) {
+    if (!h) return fail("null handle");
+    if (!weights || !out) return fail("null pointer argument");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n_col * 6 * h->cfg.n_save;
+    float* d_o = nullptr;
+    HIPCHK(hipMalloc((void**)&d_o, n * sizeof(float)));
+    int rc = 1;
+    do {
+        if (hipMemcpyAsync(h->d_w, weights, sizeof(float) * h->m.n_params, hipMemcpyHostToDevice, h->stream) != hipSuccess) { fail("loss_per_tstep: host-to-device copy failed"); break; }
+        if (colnde_loss_per_tstep_dev(h, h->d_w, d_o)) break;
+        if (hipMemcpyAsync(out, d_o, n * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+            fail("loss_per_tstep: device-to-host copy failed");
+            break;
+        }
+        rc = 0;
+    } while (0);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d_o);
+    return rc;
+}
+
 // ---- embedded inference --------------------------------------------------------------------------------
+// sign = +1: the forcing -dz(wT); -1: +dz(wT), what the reference stores in params.∂z_wT_NN (double_gyre_nn.jl:165)
+static int infer_impl(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux, float Lz, float* d_out, int n_columns, float sign);
 extern "C" int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux,
                                         float Lz, float* d_out, int n_columns) {
+    return infer_impl(h, d_weights, d_T, d_top_flux, Lz, d_out, n_columns, 1.0f);
+}
+extern "C" int colnde_infer_dz_wT_dev(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux,
+                                      float Lz, float* d_out, int n_columns) {
+    return infer_impl(h, d_weights, d_T, d_top_flux, Lz, d_out, n_columns, -1.0f);
+}
+static int infer_impl(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux, float Lz, float* d_out, int n_columns, float sign) {
     if (!h) return fail("null handle");
     if (!d_weights || !d_T || !d_top_flux || !d_out) return fail("null pointer argument");
     if (h->m.model == COLNDE_MODEL_WIND_MIXING) return fail("infer_forcing needs a single T-only network (free-convection model)");
@@ -1273,20 +1508,28 @@ extern "C" int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights
         hipError_t ef = fc_launch_pack(h->m, cw, d_weights, h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, nullptr, nullptr, h->stream);
         if (ef != hipSuccess) return fail("fc32 pack launch failed: %s", hipGetErrorString(ef));
         Timed tm(h, K_INFER);
-        ef = fc_launch_infer(h->m, cw, h->d_fc_imgf, h->d_fc_bias, d_T, d_top_flux, (float)h->m.Nz / Lz, d_out, n_columns, h->stream);
+        ef = fc_launch_infer(h->m, cw, h->d_fc_imgf, h->d_fc_bias, d_T, d_top_flux, sign * (float)h->m.Nz / Lz, d_out, n_columns, h->stream);
         if (ef != hipSuccess) return fail("fc32 infer launch failed: %s", hipGetErrorString(ef));
         return 0;
     }
     if (pack(h, d_weights)) return 1;
     Timed tm(h, K_INFER);
-    hipError_t e = launch_infer(h->m, h->pk, d_weights, h->d_wf, d_T, d_top_flux, (float)h->m.Nz / Lz, d_out, n_columns, 256,
+    hipError_t e = launch_infer(h->m, h->pk, d_weights, h->d_wf, d_T, d_top_flux, sign * (float)h->m.Nz / Lz, d_out, n_columns, 256,
                                 h->lds_fwd, h->stream);
     if (e != hipSuccess) return fail("infer launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 
+static int infer_host(colnde_handle* h, const float* weights, const float* T, const float* top_flux, float Lz, float* out, int n_columns, float sign);
 extern "C" int colnde_infer_forcing(colnde_handle* h, const float* weights, const float* T, const float* top_flux, float Lz,
                                     float* out, int n_columns) {
+    return infer_host(h, weights, T, top_flux, Lz, out, n_columns, 1.0f);
+}
+extern "C" int colnde_infer_dz_wT(colnde_handle* h, const float* weights, const float* T, const float* top_flux, float Lz,
+                                  float* out, int n_columns) {
+    return infer_host(h, weights, T, top_flux, Lz, out, n_columns, -1.0f);
+}
+static int infer_host(colnde_handle* h, const float* weights, const float* T, const float* top_flux, float Lz, float* out, int n_columns, float sign) {
     if (!h) return fail("null handle");
     if (!weights || !T || !top_flux || !out) return fail("null pointer argument");
     if (n_columns < 1) return fail("n_columns must be >= 1");
@@ -1296,7 +1539,7 @@ extern "C" int colnde_infer_forcing(colnde_handle* h, const float* weights, cons
     HIPCHK(hipMemcpyAsync(h->d_w, weights, sizeof(float) * h->m.n_params, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_tmp_a, T, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_tmp_b, top_flux, sizeof(float) * (size_t)n_columns, hipMemcpyHostToDevice, h->stream));
-    if (colnde_infer_forcing_dev(h, h->d_w, h->d_tmp_a, h->d_tmp_b, Lz, h->d_tmp_c, n_columns)) return 1;
+    if (infer_impl(h, h->d_w, h->d_tmp_a, h->d_tmp_b, Lz, h->d_tmp_c, n_columns, sign)) return 1;
     HIPCHK(hipMemcpyAsync(out, h->d_tmp_c, sizeof(float) * (size_t)n_columns * Nz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;

@@ -17,3 +17,10 @@ hipError_t launch_adam_step(float* w, const float* grad, float* m, float* v, flo
 hipError_t launch_coarse_grain(const float* in, int n_rows, int N, int n, int face, float* out, hipStream_t stream);
 hipError_t launch_zscore_stats(const float* x, long count, float* out2 /* mu, sigma */, hipStream_t stream);
 hipError_t launch_zscore_scale(const float* x, long count, const float* mu_sigma, float* out, hipStream_t stream);
+// loss_per_tstep (wind_mixing/src/loss.jl:44-46) for the six profile terms of every column: sol, truth [n_col][n_save][n_var Nz] (n_var = 3 | 1),
+// out [n_col][6][n_save] = mse over the Nz levels (terms u, v, T) and over the Nz + 1 faces of the finite-difference gradient, its two zero
+// boundary rows included (terms dudz, dvdz, dTdz: loss.jl:9, NDE_training.jl:308-317); T-only models fill terms 2 and 5, the others are 0
+hipError_t launch_loss_per_tstep(const float* sol, const float* truth, int n_col, int n_save, int Nz, int n_var, float* out, hipStream_t stream);
+// out[0] = max over the n_rows rows of rms_i((a_i - b_i) / (floor + |b_i|)) over the `row` floats of a row (+inf if any entry is not finite);
+// partial: scratch of >= 1024 floats
+hipError_t launch_rel_diff_max(const float* a, const float* b, long n_rows, int row, float floor, float* partial, float* out, hipStream_t stream);

@@ -453,3 +453,75 @@ hipError_t launch_mpp_diffusion(const float* u, const float* v, const float* T, 
 #undef MPP_LAUNCH
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// loss_per_tstep (wind_mixing/src/loss.jl:44-46; called on the six profile matrices of one simulation at training_postprocessing.jl:311-316)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) loss_per_tstep_kernel(const float* __restrict__ sol, const float* __restrict__ truth, int n_col, int n_save, int Nz,
+                                                             int n_var, float* __restrict__ out) {
+    const long total = (long)n_col * n_save * n_var;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const int v = (int)(it % n_var);
+        const long cs = it / n_var;                        // column * n_save + save point
+        const int sp = (int)(cs % n_save);
+        const long c = cs / n_save;
+        const float* a = sol + (cs * n_var + v) * Nz;
+        const float* b = truth + (cs * n_var + v) * Nz;
+        float sp2 = 0.0f, sg2 = 0.0f, prev = 0.0f;
+        for (int k = 0; k < Nz; k++) {
+            const float d = a[k] - b[k];
+            sp2 += d * d;
+            if (k > 0) { const float g = (d - prev) * (float)Nz; sg2 += g * g; }      // D^f: (x[k] - x[k-1]) Nz on the interior faces, 0 on the two end faces
+            prev = d;
+        }
+        const int term = n_var == 3 ? v : 2;
+        out[(c * 6 + term) * n_save + sp] = sp2 / (float)Nz;
+        out[(c * 6 + 3 + term) * n_save + sp] = sg2 / (float)(Nz + 1);
+    }
+}
+
+hipError_t launch_loss_per_tstep(const float* sol, const float* truth, int n_col, int n_save, int Nz, int n_var, float* out, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)n_col * 6 * n_save * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    const long total = (long)n_col * n_save * n_var;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(loss_per_tstep_kernel, dim3(blocks), dim3(256), 0, stream, sol, truth, n_col, n_save, Nz, n_var, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The adaptive integrator's error norm of a difference (the Richardson estimate of colnde_error_estimate): per state vector (row) the RMS over its
+// components of (a_i - b_i) / (floor + |b_i|) — OrdinaryDiffEq's internalnorm of err / (abstol + reltol |u|), divided through by reltol —, then the
+// maximum over the rows (columns x save points)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rel_diff_max_kernel(const float* __restrict__ a, const float* __restrict__ b, long n_rows, int row, float floor,
+                                                           float* __restrict__ partial) {
+    float mx = 0.0f;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (long)gridDim.x * 256) {
+        float s2 = 0.0f;
+        for (int i = 0; i < row; i++) {
+            const float q = (a[r * row + i] - b[r * row + i]) / (floor + fabsf(b[r * row + i]));
+            s2 += q * q;
+        }
+        const float v = sqrtf(s2 / (float)row);
+        mx = (v <= 3.0e38f) ? fmaxf(mx, v) : __int_as_float(0x7f800000);              // a NaN or Inf anywhere: +inf
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ void __launch_bounds__(64) rel_diff_finish_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+    float mx = 0.0f;
+    for (int i = threadIdx.x; i < nb; i += 64) mx = fmaxf(mx, partial[i]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off));
+    if (threadIdx.x == 0) out[0] = mx;
+}
+
+hipError_t launch_rel_diff_max(const float* a, const float* b, long n_rows, int row, float floor, float* partial, float* out, hipStream_t stream) {
+    const int blocks = (int)((n_rows + 255) / 256 < 1024 ? (n_rows + 255) / 256 : 1024);
+    hipLaunchKernelGGL(rel_diff_max_kernel, dim3(blocks), dim3(256), 0, stream, a, b, n_rows, row, floor, partial);
+    hipLaunchKernelGGL(rel_diff_finish_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, out);
+    return hipGetLastError();
+}

@@ -30,8 +30,9 @@ static inline size_t lds_floats_adjoint_noA(const DevModel& m) { return lds_floa
 
 hipError_t set_kernel_attributes(size_t max_lds_bytes);
 hipError_t launch_pack(const DevModel& m, const PackInfo& pk, const float* w, float* wf, float* wb, hipStream_t stream);
+// dx [n_col][ns] tendencies and / or flux [n_col][n_nets][Nz + 1] face fluxes (predict_flux); either may be null
 hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x,
-                      const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream);
+                      const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream, float* flux = nullptr);
 hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x0,
                           const float* bcs, const float* save_times, int n_save, int substeps, float* sol, float* tape,
                           int n_col, int nthreads, bool wlds, size_t lds_bytes, hipStream_t stream, float* ztape = nullptr);

@@ -714,7 +714,7 @@ __device__ __forceinline__ void load_bcs(const DevModel& m, const float* __restr
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                            const float* __restrict__ x, const float* __restrict__ bcs, float t,
-                           float* __restrict__ dx, int n_col) {
+                           float* __restrict__ dx, float* __restrict__ flux, int n_col) {
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
     float* xs = smem;
@@ -735,9 +735,19 @@ __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const
     __syncthreads();
     mlp_forward<false, false>(m, pk, w, wf, xs, nullptr, A, wave, nwaves, lane);
     physics_forward(m, xs, A, F, Ri_l, bcl, t, kk, tid, nth);
-    for (int it = tid; it < CT * m.ns; it += nth) {
-        const int c = it / m.ns, i = it - c * m.ns;
-        if (col0 + c < n_col) dx[(size_t)(col0 + c) * m.ns + i] = kk[c * m.ld_x + i];
+    if (dx)
+        for (int it = tid; it < CT * m.ns; it += nth) {
+            const int c = it / m.ns, i = it - c * m.ns;
+            if (col0 + c < n_col) dx[(size_t)(col0 + c) * m.ns + i] = kk[c * m.ld_x + i];
+        }
+    if (flux) {
+        // predict_flux (NDE_training.jl:83-147): the face vectors the tendencies difference — NN flux minus the closure's diffusive flux, with the
+        // boundary faces as the conditions say; free convection: [b; NN(T); t] (- min(0, K dT/dz): free_convection/src/solve.jl:32-46)
+        const int nf = m.Nz + 1;
+        for (int it = tid; it < CT * m.n_nets * nf; it += nth) {
+            const int c = it / (m.n_nets * nf), r = it - c * m.n_nets * nf, k = r / nf, f = r - k * nf;
+            if (col0 + c < n_col) flux[((size_t)(col0 + c) * m.n_nets + k) * nf + f] = F[(k * CT + c) * m.ld_f + f];
+        }
     }
 }
 
@@ -1872,8 +1882,8 @@ hipError_t launch_pack(const DevModel& m, const PackInfo& pk, const float* w, fl
 }
 
 hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x,
-                      const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(rhs_kernel, dim3((n_col + CT - 1) / CT), dim3(nthreads), lds_bytes, stream, m, pk, w, wf, x, bcs, t, dx, n_col);
+                      const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream, float* flux) {
+    hipLaunchKernelGGL(rhs_kernel, dim3((n_col + CT - 1) / CT), dim3(nthreads), lds_bytes, stream, m, pk, w, wf, x, bcs, t, dx, flux, n_col);
     return hipGetLastError();
 }
 

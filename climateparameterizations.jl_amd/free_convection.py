@@ -4,6 +4,7 @@
                                                                         convective_adjustment_nde.jl:1-57   -> FreeConvectionNDE class
     FreeConvectionNDEParameters(ds, T_scaling, wT_scaling)               free_convection_nde.jl:49-62        -> nde_params rows [bottom, top]
     solve_nde(nde, NN, T₀, alg, nde_params)                              free_convection/src/solve.jl:1-6
+    solve_nde(ds, NN, NDEType, algorithm, T_scaling, wT_scaling) -> (T, wT)  free_convection/src/solve.jl:8-51 -> solve_nde_dataset
     nde_loss()  and the Flux.train! loop                                  free_convection/src/training.jl:44-74
     compute_neural_network_forcing!                                       free_convection/double_gyre_nn.jl:149-168
     convective_adjustment!(model, Δt, K)                                  free_convection/double_gyre_nn.jl:27-62, src/oceananigans_nn.jl:13-40
@@ -85,6 +86,28 @@ def train_neural_differential_equation(nde: FreeConvectionNDE, weights, opt: ADA
         if cb is not None:
             cb(theta, total)
     return theta, history
+
+
+def solve_nde_dataset(engine: ColumnNDE, weights, nde_params):
+    """Dataset-level `solve_nde(ds, NN, NDEType, algorithm, T_scaling, wT_scaling)` (free_convection/src/solve.jl:8-51) for every simulation of the
+    handle (set_problem gave it T₀ and the scaled [bottom, top] fluxes `nde_params`): the solution at the save points and the flux re-evaluated at each
+    of them — `wT_NN_n = [bottom; NN(T_n); top]`, minus `min(0, 10 ∂T/∂z)` for ConvectiveAdjustmentNDE (:32-46) — both UNSCALED
+    (`inv(T_scaling).(T)`, `inv(wT_scaling).(wT)`).  Returns (T [n, Nt, Nz], wT [n, Nt, Nz + 1])."""
+    c = engine.cfg
+    sol = engine.forward(np.asarray(weights, np.float32))                       # [n, Nt, Nz], scaled
+    n, nt, nz = sol.shape
+    bc = np.repeat(np.asarray(nde_params, np.float32)[:, None, :2], nt, axis=1).reshape(n * nt, 2)
+    wT = engine.flux(sol.reshape(n * nt, nz), weights, bc).reshape(n, nt, nz + 1)
+    return c.sigma[2] * sol + c.mu[2], c.sigma[5] * wT + c.mu[5]
+
+
+def compute_neural_network_dz_wT(engine: ColumnNDE, weights, T_interior, surface_flux, Lz: float):
+    """What `compute_neural_network_forcing!` stores: `params.∂z_wT_NN .= ∂z_wT(wT)` (double_gyre_nn.jl:165), +∂z wT; the forcing function
+    `neural_network_∂z_wT` negates it (:135) — `compute_neural_network_forcing` below returns that forcing."""
+    T = np.asarray(T_interior, dtype=np.float32)
+    nx, ny, nz = T.shape
+    out = engine.infer_dz_wT(weights, T.reshape(nx * ny, nz), np.asarray(surface_flux, np.float32).reshape(-1), Lz)
+    return out.reshape(nx, ny, nz)
 
 
 def compute_neural_network_forcing(engine: ColumnNDE, weights, T_interior, surface_flux, Lz: float):

@@ -205,6 +205,73 @@ class ColumnNDE:
         _lib.check(self._L.colnde_rhs(self._h, _ptr(x), _ptr(w), _ptr(b), float(t), _ptr(dx), n))
         return dx
 
+    # ---- flux diagnostics -----------------------------------------------------------------------------
+    def flux(self, x, weights, bcs, t: float = 0.0):
+        """`predict_flux` (wind_mixing/src/NDE_training.jl:83-147): [n][n_nets][Nz + 1] face fluxes (scaled) of n states; T-only models: the wT that the
+        dataset-level `solve_nde` re-evaluates per saved step (free_convection/src/solve.jl:32-46)."""
+        c = self.cfg
+        nn = 3 if c.n_state == 3 * c.Nz else 1
+        if _is_torch(x):
+            import torch
+            n = x.shape[0]
+            self._chk_dev(x, (n, c.n_state))
+            self._chk_dev(weights, (self.n_params,))
+            self._chk_dev(bcs, (n, c.n_bc))
+            fl = torch.empty((n, nn, c.Nz + 1), dtype=torch.float32, device=x.device)
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_flux_dev(self._h, x.data_ptr(), weights.data_ptr(), bcs.data_ptr(), float(t), fl.data_ptr(), n))
+            return fl
+        x = _f32(x)
+        n = x.shape[0]
+        x = _f32(x, (n, c.n_state))
+        w = _f32(weights, (self.n_params,))
+        b = _f32(bcs, (n, c.n_bc))
+        fl = np.empty((n, nn, c.Nz + 1), dtype=np.float32)
+        _lib.check(self._L.colnde_flux(self._h, _ptr(x), _ptr(w), _ptr(b), float(t), _ptr(fl), n))
+        return fl
+
+    def loss_per_tstep(self, weights):
+        """`loss_per_tstep` (wind_mixing/src/loss.jl:44-46) of the six profile terms: [n_columns][6][n_save], unscaled mse per save point."""
+        shape = (self.n_columns, 6, self.cfg.n_save)
+        if _is_torch(weights):
+            import torch
+            self._chk_dev(weights, (self.n_params,))
+            out = torch.empty(shape, dtype=torch.float32, device=weights.device)
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_loss_per_tstep_dev(self._h, weights.data_ptr(), out.data_ptr()))
+            return out
+        w = _f32(weights, (self.n_params,))
+        out = np.empty(shape, dtype=np.float32)
+        _lib.check(self._L.colnde_loss_per_tstep(self._h, _ptr(w), _ptr(out)))
+        return out
+
+    # ---- error-controlled time stepping ---------------------------------------------------------------
+    @property
+    def substeps(self) -> int:
+        """Sub-steps per save interval in use (cfg.substeps, or what the handle chose from reltol)."""
+        return int(self._L.colnde_substeps(self._h))
+
+    def error_estimate(self, weights) -> float:
+        """Richardson estimate of the solve's error at the current sub-step count against one at twice the count, in the integrator's mixed norm
+        max |e| / (1e-3 + |u|) (include/colnde.h: colnde_error_estimate) — what `reltol` bounds."""
+        est = ctypes.c_float(0)
+        if _is_torch(weights):
+            self._chk_dev(weights, (self.n_params,))
+            self.use_torch_stream()
+            _lib.check(self._L.colnde_error_estimate_dev(self._h, weights.data_ptr(), ctypes.byref(est)))
+        else:
+            w = _f32(weights, (self.n_params,))
+            _lib.check(self._L.colnde_error_estimate(self._h, _ptr(w), ctypes.byref(est)))
+        return float(est.value)
+
+    def choose_substeps(self, weights, reltol: float = 0.0):
+        """The least power-of-two sub-step count (not below the stability bound) whose error estimate meets `reltol` (0: cfg.reltol); the handle
+        keeps it.  Returns (substeps, estimate).  Before the first loss_grad only: the count sizes the tapes."""
+        w = _f32(weights.cpu().numpy() if _is_torch(weights) else weights, (self.n_params,))
+        s, est = ctypes.c_int(0), ctypes.c_float(0)
+        _lib.check(self._L.colnde_choose_substeps(self._h, _ptr(w), float(reltol), ctypes.byref(s), ctypes.byref(est)))
+        return int(s.value), float(est.value)
+
     # ---- forward solve --------------------------------------------------------------------------------
     def forward(self, weights, out=None):
         c = self.cfg
@@ -259,7 +326,11 @@ class ColumnNDE:
         return float(total.value), np.array(list(terms), dtype=np.float32), grad
 
     # ---- embedded inference ---------------------------------------------------------------------------
-    def infer_forcing(self, weights, T, top_flux, Lz: float):
+    def infer_dz_wT(self, weights, T, top_flux, Lz: float):
+        """+∂z wT, what `compute_neural_network_forcing!` stores in `params.∂z_wT_NN` (double_gyre_nn.jl:165); `infer_forcing` is its negative (:135)."""
+        return self.infer_forcing(weights, T, top_flux, Lz, _dz_wT=True)
+
+    def infer_forcing(self, weights, T, top_flux, Lz: float, _dz_wT: bool = False):
         Nz = self.cfg.Nz
         if _is_torch(T):
             import torch
@@ -269,8 +340,8 @@ class ColumnNDE:
             self._chk_dev(weights, (self.n_params,))
             out = torch.empty_like(T)
             self.use_torch_stream()
-            _lib.check(self._L.colnde_infer_forcing_dev(self._h, weights.data_ptr(), T.data_ptr(), top_flux.data_ptr(),
-                                                        float(Lz), out.data_ptr(), n))
+            fn = self._L.colnde_infer_dz_wT_dev if _dz_wT else self._L.colnde_infer_forcing_dev
+            _lib.check(fn(self._h, weights.data_ptr(), T.data_ptr(), top_flux.data_ptr(), float(Lz), out.data_ptr(), n))
             return out
         T = _f32(T)
         n = T.shape[0]
@@ -278,7 +349,8 @@ class ColumnNDE:
         tf = _f32(top_flux, (n,))
         w = _f32(weights, (self.n_params,))
         out = np.empty_like(T)
-        _lib.check(self._L.colnde_infer_forcing(self._h, _ptr(w), _ptr(T), _ptr(tf), float(Lz), _ptr(out), n))
+        fn = self._L.colnde_infer_dz_wT if _dz_wT else self._L.colnde_infer_forcing
+        _lib.check(fn(self._h, _ptr(w), _ptr(T), _ptr(tf), float(Lz), _ptr(out), n))
         return out
 
     # ---- the steps either side of the hot path --------------------------------------------

@@ -149,7 +149,10 @@ def train_NDE(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epoch
       * per iteration: loss and gradient at θ, `cb(θ, total, losses, loss_scalings)` (true = stop), `update!(opt, θ, g)`,
         then `save_best`: if this iteration's loss is the lowest so far, `min_θ = copy(θ)` — taken AFTER the update, i.e. the
         point one ADAM step past the best-loss point; at `i == maxiters` θ reverts to `min_θ` and `cb(min_θ, min_err...)` is called once
-        more, so a solve that is not halted issues maxiters + 1 callbacks (the log of `write_data_NDE_training` has that many records)."""
+        more, so a solve that is not halted issues maxiters + 1 callbacks.
+    The reference's OWN callback ignores that extra call: its body is guarded by `if iter <= maxiters` with `iter += 1` behind it
+    (NDE_training.jl:343-368), so it prints and `write_data_NDE_training`s exactly `maxiters` records per solve.  A `cb` that logs must carry
+    the same guard to produce a reference-shaped log: `reference_logging_callback` below is that closure."""
     theta = np.array(weights, dtype=np.float32)
     history = []
     for opt in optimizers:
@@ -168,11 +171,34 @@ def train_NDE(problem: WindMixingNDE, weights, optimizers: Sequence[ADAM], epoch
                 if total < best:
                     best, best_losses, best_theta = total, losses, theta.copy()
             theta = best_theta
-            # `if i == maxiters ... θ = min_θ; cb(θ, x...); break` — the extra callback on the reverted best point, the one through which
-            # the reference's `write_data_NDE_training` logs the (maxiters+1)-th record of every solve (its return value is ignored)
+            # `if i == maxiters ... θ = min_θ; cb(θ, x...); break` — GalacticOptim's extra callback on the reverted best point (its return value is
+            # ignored).  The reference's cb does nothing on it (`if iter <= maxiters`, NDE_training.jl:344): see reference_logging_callback
             if cb is not None and not halted and maxiters > 0 and best_losses is not None:
                 cb(theta, best, best_losses, problem.loss_scalings)
     return TrainResult(theta, history)
+
+
+def reference_logging_callback(FILE_PATH, cfg: NDEConfig, stage, opt: ADAM, maxiters: int, log: Optional[Callable] = None):
+    """The `cb(args...)` closure `train_NDE` builds per (optimizer, epoch) solve (NDE_training.jl:342-368): while `iter <= maxiters` it writes one
+    record — losses, loss scalings, the three networks cut out of θ, the optimiser state — through `write_data_NDE_training`
+    (wind_mixing/src/data_writing.jl:28-78), then `iter += 1` and returns false.  The guard is what makes the (maxiters + 1)-th call of
+    GalacticOptim's solve (the reverted best point) a no-op, so a log holds exactly `maxiters` records per solve and `extract_NN`'s
+    `N_data` / arg-min see what they see in a reference log.  `log(iter, total, losses)`: optional hook in place of the reference's `@info`."""
+    from .checkpoint import network_record, write_data_NDE_training
+    state = {"iter": 1}
+    third = cfg.n_params // 3
+
+    def cb(theta, total, losses, loss_scalings):
+        if state["iter"] <= maxiters:
+            if log is not None:
+                log(state["iter"], total, losses)
+            th = np.asarray(theta, dtype=np.float32)
+            nets = [network_record(th[k * third:(k + 1) * third], cfg.layer_sizes, cfg.activations) for k in range(3)]
+            sc = dict(zip(LOSS_KEYS, [float(s) for s in loss_scalings])) if not isinstance(loss_scalings, dict) else loss_scalings
+            write_data_NDE_training(FILE_PATH, losses, sc, nets[0], nets[1], nets[2], stage, opt)
+        state["iter"] += 1
+        return False
+    return cb
 
 
 def _check_replicas(theta, comm, process_group, it):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define COLNDE_VERSION 103
+#define COLNDE_VERSION 104
 #define COLNDE_MAX_LAYERS 8
 
 enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_training.jl:56-165 */
@@ -93,7 +93,8 @@ typedef struct colnde_config {
     float sigma[6];
     float ca_K;                                  /* convective_adjustment_nde.jl:43 (10) */
     int32_t n_save;                              /* number of `saveat` times, >= 2 */
-    int32_t substeps;                            /* classical RK4 steps per save interval */
+    int32_t substeps;                            /* steps per save interval (RK4; RKC2: steps of rkc_stages stages); 0 = chosen from `reltol` by the first solve
+                                                    call of the handle (colnde_choose_substeps), then kept */
     const float* save_times;                     /* [n_save] nondimensional t_train ./ tau (borrowed during create) */
     int32_t n_columns;                           /* columns (simulations) held by this handle */
     int32_t device;                              /* HIP device ordinal */
@@ -101,6 +102,9 @@ typedef struct colnde_config {
     int32_t stepper;                             /* COLNDE_STEPPER_* (0 = RK4) */
     int32_t rkc_stages;                          /* RKC2: stages per step, 2..256; 0 = automatic (colnde_rkc_stages) */
     int32_t matrix_arithmetic;                   /* COLNDE_MATRIX_* (0 = exact three-way bf16 split where a split kernel exists) */
+    float reltol;                                /* the tolerance the reference hands its adaptive integrator (solve(...; reltol=1f-3): NDE_training.jl:291;
+                                                    1e-4: free_convection/src/solve.jl:4); 0 = 1e-3.  Used when substeps = 0 and by colnde_choose_substeps:
+                                                    see colnde_error_estimate for the norm */
 } colnde_config;
 
 typedef struct colnde_handle colnde_handle;
@@ -148,6 +152,39 @@ int colnde_rhs(colnde_handle* h, const float* x, const float* weights, const flo
  * free_convection/src/solve.jl:1-6.  sol [n_col][n_save][n_state] (NULL: keep on device only). */
 int colnde_forward(colnde_handle* h, const float* weights, float* sol);
 
+/* ---- what `reltol` means here.  The reference integrates with an ADAPTIVE stepper (solve(prob, ROCK4(); reltol=1f-3, saveat=...): wind_mixing/src/
+ * NDE_training.jl:291,304,403; reltol=1e-4: free_convection/src/solve.jl:4); this path steps at a fixed `substeps` per save interval, and the tolerance is
+ * enforced a posteriori.  colnde_error_estimate: one more forward solve at 2 x substeps and Richardson's estimate of the error of the solve at `substeps`,
+ *   e = (u_S - u_2S) 2^p / (2^p - 1)   (p = 4: RK4, p = 2: RKC2),   *max_rel_err = max over columns and save points of rms_i(e_i / (1e-3 + |u_i|))
+ * (rms over the state's components) — the integrator's accept test rms(err / (abstol + reltol |u|)) <= 1 with OrdinaryDiffEq's default abstol = 1e-6
+ * and the reference's reltol = 1e-3, divided through by reltol, applied to the whole save interval instead of one adaptive step; +inf when a solve
+ * is not finite.  colnde_choose_substeps: the least
+ * power-of-two sub-step count, not below colnde_min_substeps, whose estimate is <= reltol (reltol <= 0: cfg.reltol); the handle keeps it (call it before
+ * the first colnde_loss_grad: the sub-step count sizes the tapes).  A handle created with substeps = 0 does this by itself in its first solve call, with
+ * the weights of that call; later calls reuse the count (a training loop re-checks with colnde_error_estimate when it wants to).  colnde_substeps: the
+ * count in use.  The stability bound alone (colnde_min_substeps) knows only the closure's diffusion; a trained net's Jacobian shows up here.
+ * float32 solves resolve about 1e-4 in this norm (it divides by 1e-3 + |u|; round-off grows with the step count): a tolerance below that floor is
+ * refused by colnde_choose_substeps with the floor it found, and the reference's 1e-3 / 1e-4 sit at or above it. */
+int colnde_error_estimate(colnde_handle* h, const float* weights, float* max_rel_err);
+int colnde_error_estimate_dev(colnde_handle* h, const float* d_weights, float* max_rel_err /* host */);
+int colnde_choose_substeps(colnde_handle* h, const float* weights, float reltol, int* substeps /* nullable */, float* estimate /* nullable */);
+int colnde_substeps(const colnde_handle* h);
+
+/* predict_flux(uvT, BCs, ...) (wind_mixing/src/NDE_training.jl:83-147; exported at wind_mixing/src/WindMixing.jl:6): the face fluxes whose divergence the
+ * RHS takes — uw, vw, wT on the Nz + 1 faces, NN output minus the closure's diffusive flux (MPP) or convective-adjustment flux, boundary faces as the
+ * conditions say — for n_columns states: flux [n_col][3][Nz + 1], scaled units.  T-only models: flux [n_col][1][Nz + 1] = [bottom; NN(T); top]
+ * (free_convection_nde.jl:33) minus min(0, K dT/dz) for ConvectiveAdjustmentNDE — the wT that the dataset-level solve_nde re-evaluates per saved step
+ * (free_convection/src/solve.jl:32-46).  Same arguments as colnde_rhs. */
+int colnde_flux(colnde_handle* h, const float* x, const float* weights, const float* bcs, float t, float* flux, int n_columns);
+int colnde_flux_dev(colnde_handle* h, const float* d_x, const float* d_weights, const float* d_bcs, float t, float* d_flux, int n_columns);
+
+/* loss_per_tstep(a, b) (wind_mixing/src/loss.jl:44-46) on the six profile matrices of every simulation, as NDE_profile calls it
+ * (training_postprocessing.jl:311-316): out [n_col][6][n_save], term order u, v, T, dudz, dvdz, dTdz; entry = mse over the Nz levels (gradient terms:
+ * over the Nz + 1 faces, the two zero boundary rows included) of solve(weights) against the truth at that save point, UNSCALED by the loss scalings.
+ * T-only models fill terms 2 and 5. */
+int colnde_loss_per_tstep(colnde_handle* h, const float* weights, float* out);
+int colnde_loss_per_tstep_dev(colnde_handle* h, const float* d_weights, float* d_out);
+
 /* loss_NDE / loss_gradient_NDE value (NDE_training.jl:290-323), nde_loss (training.jl:55-62).
  * scalings[6] = loss_scalings (u,v,T,dudz,dvdz,dTdz); terms[6] = scaled losses; total = their sum. */
 int colnde_loss(colnde_handle* h, const float* weights, const float scalings[6], float terms[6], float* total);
@@ -161,6 +198,10 @@ int colnde_loss_grad(colnde_handle* h, const float* weights, const float scaling
  * top_flux [n_col]; out [n_col][Nz] = -dz(wT) on cell centres with dz = Lz/Nz. */
 int colnde_infer_forcing(colnde_handle* h, const float* weights, const float* T, const float* top_flux,
                          float Lz, float* out, int n_columns);
+/* The same evaluation with the reference's storage convention: compute_neural_network_forcing! fills params.∂z_wT_NN with +dz(wT)
+ * (double_gyre_nn.jl:165) and the forcing function negates it (:135).  out [n_col][Nz] = +dz(wT); colnde_infer_forcing returns the forcing itself. */
+int colnde_infer_dz_wT(colnde_handle* h, const float* weights, const float* T, const float* top_flux,
+                       float Lz, float* out, int n_columns);
 
 /* ---- device-pointer twins: every pointer is device memory on cfg.device; work is enqueued on the
  * handle's stream and NOT synchronised.  d_out of loss_grad_dev has n_params + 8 floats:
@@ -173,6 +214,8 @@ int colnde_loss_dev(colnde_handle* h, const float* d_weights, const float scalin
 int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, const float scalings[6], float* d_out);
 int colnde_infer_forcing_dev(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux,
                              float Lz, float* d_out, int n_columns);
+int colnde_infer_dz_wT_dev(colnde_handle* h, const float* d_weights, const float* d_T, const float* d_top_flux,
+                           float Lz, float* d_out, int n_columns);
 
 /* ---- the steps either side of the hot path --------------------------------------------------------
  *

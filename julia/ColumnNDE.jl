@@ -25,6 +25,7 @@ Base.@kwdef mutable struct Config
     n_columns::Int32 = 1; device::Int32 = 0; engine::Int32 = 0
     stepper::Int32 = 0; rkc_stages::Int32 = 0                            # COLNDE_STEPPER_RK4 / _RKC2 (stands where the reference uses ROCK4)
     matrix_arithmetic::Int32 = 0                                         # COLNDE_MATRIX_BF16X3_EXACT (0, default) / COLNDE_MATRIX_F32_MFMA (1)
+    reltol::Float32 = 0                                                  # solve(...; reltol=1f-3) (0 = 1f-3); with substeps = 0 the handle chooses the sub-step count from it
 end
 
 const MATRIX_BF16X3_EXACT = Int32(0)   # Float32 Dense products as six bf16 MFMA products of exact three-way operand splits, f32 accumulation
@@ -33,7 +34,7 @@ const MATRIX_F32_MFMA = Int32(1)       # v_mfma_f32_* throughout
 check(rc) = rc == 0 || error(unsafe_string(ccall((:colnde_last_error, libcolnde), Cstring, ())))
 
 mutable struct Handle
-    ptr::Ptr{Cvoid}; n_params::Int; n_state::Int; n_save::Int; n_columns::Int
+    ptr::Ptr{Cvoid}; n_params::Int; n_state::Int; n_save::Int; n_columns::Int; n_nets::Int
 end
 
 "least RK4 sub-steps per save interval inside the stability bound / stages of the RKC2 step (no GPU needed)"
@@ -61,7 +62,7 @@ function Handle(cfg::Config, save_times::Vector{Float32})
         check(ccall((:colnde_create, libcolnde), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out))
     end
     h = Handle(out[], ccall((:colnde_n_params, libcolnde), Cint, (Ptr{Cvoid},), out[]),
-               cfg.model == 0 ? 3cfg.Nz : cfg.Nz, cfg.n_save, cfg.n_columns)
+               cfg.model == 0 ? 3cfg.Nz : cfg.Nz, cfg.n_save, cfg.n_columns, cfg.model == 0 ? 3 : 1)
     finalizer(x -> ccall((:colnde_destroy, libcolnde), Cvoid, (Ptr{Cvoid},), x.ptr), h)
 end
 
@@ -189,6 +190,61 @@ function compute_neural_network_forcing!(forcing::Matrix{Float32}, h::Handle, we
     check(ccall((:colnde_infer_forcing, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Ptr{Float32}, Cint),
                 h.ptr, weights, T_interior, surface_flux, Float32(Lz), forcing, size(T_interior, 2)))
     forcing
+end
+
+"predict_flux(uvT, BCs, ...) — wind_mixing/src/NDE_training.jl:83-147 (exported at WindMixing.jl:6): (uw, vw, wT) on the Nz+1 faces for ONE state, as the
+reference returns them; `p = [weights; BCs]` as for NDE"
+function predict_flux(h::Handle, x::Vector{Float32}, p::Vector{Float32}, t=0)
+    w = @view p[1:h.n_params]; bc = @view p[h.n_params+1:end]
+    nn = h.n_nets                                                          # wind mixing: three nets on the 3 Nz state
+    Nz = h.n_state ÷ nn
+    fl = Matrix{Float32}(undef, Nz + 1, nn)                                 # column-major (Nz+1) x nn = C-order [nn][Nz+1]
+    check(ccall((:colnde_flux, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Ptr{Float32}, Cint),
+                h.ptr, x, w, bc, Float32(t), fl, 1))
+    nn == 3 ? (fl[:, 1], fl[:, 2], fl[:, 3]) : fl[:, 1]
+end
+
+"loss_per_tstep (wind_mixing/src/loss.jl:44-46) of the six profile terms of every simulation: n_save x 6 x n_simulations"
+function loss_per_tstep(h::Handle, weights::Vector{Float32})
+    out = Array{Float32}(undef, h.n_save, 6, h.n_columns)
+    check(ccall((:colnde_loss_per_tstep, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}), h.ptr, weights, out))
+    out
+end
+
+"dataset-level solve_nde(ds, NN, NDEType, algorithm, T_scaling, wT_scaling) — free_convection/src/solve.jl:8-51: the solution of every simulation and the
+flux wT re-evaluated at each saved step (min(0, 10 ∂T/∂z) included for ConvectiveAdjustmentNDE), both unscaled: (T = Nz x Nt x n, wT = (Nz+1) x Nt x n).
+`BCs` (2 x n: scaled bottom and top flux) are the ones given to set_problem!."
+function solve_nde(h::Handle, NN, BCs::Matrix{Float32}, T_scaling, wT_scaling)
+    θ = first(Flux.destructure(NN))
+    sols = solve_NDE(h, θ)
+    h.n_nets == 1 || error("solve_nde(ds-level) is the free-convection driver: a T-only handle")
+    Nz = h.n_state
+    T = Array{Float32}(undef, Nz, h.n_save, h.n_columns); wT = Array{Float32}(undef, Nz + 1, h.n_save, h.n_columns)
+    for i in 1:h.n_columns, n in 1:h.n_save
+        T[:, n, i] .= sols[i][:, n]
+        wT[:, n, i] .= predict_flux(h, sols[i][:, n], vcat(θ, BCs[:, i]), 0)
+    end
+    (T=inv(T_scaling).(T), wT=inv(wT_scaling).(wT))
+end
+
+"Richardson estimate of the solve's error at the current sub-step count (max |e| / (1f-3 + |u|): colnde_error_estimate) — what `reltol` bounds here"
+function error_estimate(h::Handle, weights::Vector{Float32})
+    est = Ref{Float32}(0)
+    check(ccall((:colnde_error_estimate, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ref{Float32}), h.ptr, weights, est)); est[]
+end
+"the least power-of-two sub-step count meeting reltol (0: the handle's); kept by the handle — colnde_choose_substeps"
+function choose_substeps!(h::Handle, weights::Vector{Float32}, reltol=0f0)
+    s = Ref{Cint}(0); est = Ref{Float32}(0)
+    check(ccall((:colnde_choose_substeps, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cfloat, Ref{Cint}, Ref{Float32}), h.ptr, weights, reltol, s, est))
+    Int(s[]), est[]
+end
+substeps(h::Handle) = ccall((:colnde_substeps, libcolnde), Cint, (Ptr{Cvoid},), h.ptr)
+
+"+∂z wT as compute_neural_network_forcing! stores it in params.∂z_wT_NN (double_gyre_nn.jl:165; the forcing function negates it, :135)"
+function compute_∂z_wT!(dz_wT::Matrix{Float32}, h::Handle, weights::Vector{Float32}, T_interior::Matrix{Float32}, surface_flux::Vector{Float32}, Lz)
+    check(ccall((:colnde_infer_dz_wT, libcolnde), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Ptr{Float32}, Cint),
+                h.ptr, weights, T_interior, surface_flux, Float32(Lz), dz_wT, size(T_interior, 2)))
+    dz_wT
 end
 
 "switch an existing handle between MATRIX_BF16X3_EXACT and MATRIX_F32_MFMA (tapes and plans do not depend on it) — colnde_set_matrix_arithmetic"

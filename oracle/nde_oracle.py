@@ -202,7 +202,7 @@ class Model:
         Q = bcs[:, 5]
         return (Q * np.sin(2 * np.pi / 86400.0 * (t * c.tau)) / (c.alpha * c.g) - self.mu_wT) / self.s_wT
 
-    def wm_rhs(self, x, bcs, nets, t=0.0, want_vjp=False, sw=None):
+    def wm_rhs(self, x, bcs, nets, t=0.0, want_vjp=False, sw=None, want_flux=False):
         c, Nz = self.cfg, self.Nz
         H, tau, f = c.H, c.tau, c.f
         u, v, T = x[:, :Nz], x[:, Nz:2 * Nz], x[:, 2 * Nz:]
@@ -267,6 +267,8 @@ class Model:
         dv = -A[1] * (F[1][:, 1:] - F[1][:, :-1]) - f * tau / s_v * (s_u * u + self.mu_u)
         dT = -A[2] * (F[2][:, 1:] - F[2][:, :-1])
         dx = np.concatenate([du, dv, dT], axis=1)
+        if want_flux:                                     # what predict_flux returns (:139, :143, :145): the three face vectors
+            return np.stack(F, axis=1)
         if not want_vjp:
             return dx
 
@@ -320,7 +322,7 @@ class Model:
 
     # -- free convection: ∂T∂t (free_convection_nde.jl:29-38) and convective-adjustment NDE
     #    (convective_adjustment_nde.jl:33-48) ----------------------------------------------------
-    def fc_rhs(self, x, bcs, nets, t=0.0, want_vjp=False, sw=None):
+    def fc_rhs(self, x, bcs, nets, t=0.0, want_vjp=False, sw=None, want_flux=False):
         c, Nz = self.cfg, self.Nz
         C = (self.s_wT / self.s_T) * (c.tau / c.H)
         n = x.shape[0]
@@ -333,6 +335,8 @@ class Model:
             gT = _face_grad(x, Nz)
             q = np.minimum(0.0, c.ca_K * gT)
             dT = dT + C * Nz * (q[:, 1:] - q[:, :-1])
+        if want_flux:                                     # free_convection/src/solve.jl:32-46: wT_NN (- min(0, 10 dT/dz) for the CA-NDE), scaled
+            return (w - q if ca else w)[:, None, :]
         if not want_vjp:
             return dT
 
@@ -363,6 +367,47 @@ class Model:
         if c.model == WIND_MIXING and c.convective_adjustment and not c.modified_pacanowski_philander:
             return _face_grad(x[:, 2 * Nz:], Nz) < 0
         return None
+
+
+def predict_flux(cfg, x, bcs, theta, t=0.0, dtype=np.float64):
+    """`predict_flux` (wind_mixing/src/NDE_training.jl:83-147) for every column: [n][n_nets][Nz + 1] face fluxes in scaled units; T-only models: the
+    flux the dataset-level `solve_nde` re-evaluates per saved step (free_convection/src/solve.jl:32-46)."""
+    m = Model(cfg, dtype)
+    x, bcs = np.asarray(x, dtype), np.asarray(bcs, dtype)
+    nets = m.unpack(theta)
+    if cfg.model == WIND_MIXING:
+        return m.wm_rhs(x, bcs, nets, t, want_flux=True)
+    return m.fc_rhs(x, bcs, nets, t, want_flux=True)
+
+
+def loss_per_tstep(cfg, sol, truth):
+    """`loss_per_tstep(a, b)` (wind_mixing/src/loss.jl:44-46) on the six profile matrices of every simulation (training_postprocessing.jl:311-316):
+    [n][6][n_save]; gradient terms over the Nz + 1 faces of `Dᶠ`, zero boundary rows included (loss.jl:9).  T-only models fill terms 2 and 5."""
+    sol, truth = np.asarray(sol, np.float64), np.asarray(truth, np.float64)
+    n, n_save, Nz = sol.shape[0], sol.shape[1], cfg.Nz
+    nv = sol.shape[2] // Nz
+    out = np.zeros((n, 6, n_save))
+    for v in range(nv):
+        d = sol[:, :, v * Nz:(v + 1) * Nz] - truth[:, :, v * Nz:(v + 1) * Nz]
+        g = np.zeros(d.shape[:2] + (Nz + 1,))
+        g[:, :, 1:Nz] = (d[:, :, 1:] - d[:, :, :-1]) * Nz
+        term = v if nv == 3 else 2
+        out[:, term] = (d ** 2).mean(axis=2)
+        out[:, 3 + term] = (g ** 2).mean(axis=2)
+    return out
+
+
+def error_estimate(cfg, x0, bcs, theta, dtype=np.float64):
+    """Richardson estimate of the error of the solve at cfg.substeps from one at twice as many (what colnde_error_estimate returns):
+    e = (u_S - u_2S) 2^p / (2^p - 1), p = 4 (RK4) or 2 (RKC2); per column and save point rms_i(e_i / (1e-3 + |u_2S,i|)), then the maximum — the adaptive
+    integrator's accept test rms(err / (abstol + reltol |u|)) <= 1 with OrdinaryDiffEq's default abstol = 1e-6 over the reference's reltol = 1e-3
+    (NDE_training.jl:291), divided through by reltol."""
+    from dataclasses import replace
+    a = solve(cfg, x0, bcs, theta, dtype=dtype)
+    b = solve(replace(cfg, substeps=2 * cfg.substeps), x0, bcs, theta, dtype=dtype)
+    p = 2 if cfg.stepper == "rkc2" else 4
+    q = (a - b) / (1e-3 + np.abs(b))
+    return float(np.max(np.sqrt(np.mean(q * q, axis=-1)))) * 2 ** p / (2 ** p - 1)      # rms over the state's components, max over columns and save points
 
 
 def rhs(cfg, x, bcs, theta, t=0.0, dtype=np.float64):

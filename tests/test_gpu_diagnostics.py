@@ -1,0 +1,167 @@
+"""GPU parity of the round-4 entry points through the C ABI: `colnde_flux` = `predict_flux` (wind_mixing/src/NDE_training.jl:83-147; the wT of the
+dataset-level `solve_nde`, free_convection/src/solve.jl:32-46), `colnde_loss_per_tstep` = `loss_per_tstep` (wind_mixing/src/loss.jl:44-46),
+`colnde_infer_dz_wT` (the +∂z wT that double_gyre_nn.jl:165 stores), and error-controlled time stepping: `colnde_error_estimate`,
+`colnde_choose_substeps`, `substeps = 0` (the reference's `reltol=1f-3`, NDE_training.jl:291)."""
+import numpy as np
+import pytest
+
+import colnde
+from colnde import synthetic
+from colnde.nde import ENGINE_REGTILE, ENGINE_TILE16
+from oracle import nde_oracle as O
+from tests.test_oracle import VARIANTS, INPLACE_VARIANTS
+from tests.test_gpu_parity import _record, _rel, SOL_ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS) + sorted(INPLACE_VARIANTS))
+def test_predict_flux_wind_mixing(name):
+    kw = dict(VARIANTS[name] if name in VARIANTS else INPLACE_VARIANTS[name])
+    p = synthetic.wind_mixing_problem(37, n_frames=3, weight_divisor=10.0, **kw)
+    ref = O.predict_flux(p.cfg, p.x0, p.bcs, p.weights, 0.02)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        got = nde.flux(p.x0, p.weights, p.bcs, 0.02)
+        dx = nde.rhs(p.x0, p.weights, p.bcs, 0.02)
+    assert got.shape == (37, 3, 33)
+    if "inplace" not in name and not p.cfg.inplace_variant:
+        assert np.isfinite(got).all()
+    ok = np.isfinite(ref)                                   # the in-place NDE! leaves 0/0 on the two boundary faces of Ri, never read (training_postprocessing.jl:114)
+    _record("flux_wm/" + name, flux_rel=_rel(got[ok], ref[ok]))
+    assert _rel(got[ok], ref[ok]) < 1e-6                    # the tolerance of one RHS evaluation (tests/test_gpu_parity.py::test_rhs_wind_mixing)
+    # ... and the tendencies colnde_rhs returns are these fluxes' divergence (temperature: no Coriolis term)
+    c, Nz = p.cfg, 32
+    A = c.tau / c.H * c.sigma[5] / c.sigma[2] * Nz
+    np.testing.assert_allclose(-A * (got[:, 2, 1:].astype(np.float64) - got[:, 2, :-1]), dx[:, 2 * Nz:], rtol=2e-4, atol=2e-4 * np.abs(dx[:, 2 * Nz:]).max())
+
+
+@pytest.mark.parametrize("Nz,ca", [(32, False), (32, True), (64, False), (64, True)])
+def test_predict_flux_free_convection_and_dataset_level_solve_nde(Nz, ca):
+    """The flux of the T-only models at a state, and the dataset-level `solve_nde(ds, …) -> (T, wT)` of free_convection/src/solve.jl:8-51 built from it:
+    the solution of every simulation and wT re-evaluated at each saved step, both unscaled."""
+    from colnde import free_convection as FC
+    p = synthetic.free_convection_problem(9, Nz=Nz, n_save=5, substeps=20 * (Nz // 32) ** 2 if ca else 2, convective_adjustment=ca, t_end=0.01)
+    x0 = p.x0.copy()
+    x0[:, Nz // 2:Nz // 2 + 6] = x0[:, Nz // 2:Nz // 2 + 6][:, ::-1]
+    ref = O.predict_flux(p.cfg, x0, p.bcs, p.weights)
+    with colnde.ColumnNDE(p.cfg, 9) as nde:
+        got = nde.flux(x0, p.weights, p.bcs)
+        assert got.shape == (9, 1, Nz + 1)
+        assert _rel(got, ref) < 2e-6
+        nde.set_problem(x0, p.bcs)
+        sol = nde.forward(p.weights)
+        T, wT = FC.solve_nde_dataset(nde, p.weights, p.bcs)
+    sol64 = O.solve(p.cfg, x0, p.bcs, p.weights)
+    s_T, mu_T, s_w, mu_w = p.cfg.sigma[2], p.cfg.mu[2], p.cfg.sigma[5], p.cfg.mu[5]
+    assert T.shape == (9, 5, Nz) and wT.shape == (9, 5, Nz + 1)
+    np.testing.assert_allclose(T, s_T * sol + mu_T, rtol=1e-6)
+    for n in range(5):
+        ref_n = s_w * O.predict_flux(p.cfg, sol64[:, n], p.bcs, p.weights)[:, 0] + mu_w
+        assert _rel(wT[:, n], ref_n) < (5e-3 if ca else 2e-4)                # (through the solve: the free-convection solution tolerances; CA: kinks)
+
+
+def test_loss_per_tstep():
+    p = synthetic.wind_mixing_problem(21, n_frames=9, weight_divisor=1e2)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sol = O.solve(p.cfg, p.x0, p.bcs, p.weights)
+    ref = O.loss_per_tstep(p.cfg, sol, truth)
+    sc = [1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3]
+    with colnde.ColumnNDE(p.cfg, 21) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        got = nde.loss_per_tstep(p.weights)
+        tot, terms = nde.loss(p.weights, sc)
+    assert got.shape == (21, 6, 9)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-3 * ref.max())
+    np.testing.assert_allclose(got.mean(axis=(0, 2)) * np.array(sc), terms, rtol=2e-4)      # loss_NDE's terms are its averages (NDE_training.jl:308-317)
+    pf = synthetic.free_convection_problem(7, Nz=32, n_save=5, substeps=2, t_end=0.01)
+    tr = O.solve(pf.cfg, pf.x0, pf.bcs, pf.weights_truth).astype(np.float32)
+    with colnde.ColumnNDE(pf.cfg, 7) as nde:
+        nde.set_problem(pf.x0, pf.bcs, tr)
+        g = nde.loss_per_tstep(pf.weights)
+        tot, _ = nde.loss(pf.weights, [0, 0, 1, 0, 0, 0])
+    assert not g[:, [0, 1, 3, 4]].any() and np.isclose(g[:, 2].mean(), tot, rtol=1e-4)
+
+
+def test_infer_dz_wT_is_the_negative_forcing():
+    cfg, T, top, w = synthetic.inference_problem(16, 9)
+    for eng in (0, ENGINE_TILE16):
+        with colnde.ColumnNDE(cfg, 144, engine=eng) as nde:
+            f = nde.infer_forcing(w, T, top, 1000.0)
+            d = nde.infer_dz_wT(w, T, top, 1000.0)
+        np.testing.assert_array_equal(d, -f)                                 # params.∂z_wT_NN vs the forcing function (double_gyre_nn.jl:165, :135)
+        assert np.abs(f).max() > 0
+
+
+@pytest.mark.parametrize("engine", [ENGINE_REGTILE, 0])
+def test_error_estimate_tracks_the_true_error(engine):
+    """colnde_error_estimate against the oracle's (float64) and against the TRUE error of the engine's solve — measured against a float64 oracle solve
+    at 64 sub-steps, in the same norm: within 2x.  Nets 100x the 2-day suite's initial ones (weights/1) keep the discretisation error at 2 and 4
+    sub-steps (5e-3, 3e-4) above float32's round-off floor in this norm (~1e-4: the norm divides by 1e-3 + |u| and the deep velocities are ~0),
+    below which no estimate from float32 solves can track anything."""
+    n = 70 if engine == ENGINE_REGTILE else 24
+    p = synthetic.wind_mixing_problem(n, n_frames=17, weight_divisor=1.0)
+    b = O.solve(p.cfg.with_(substeps=64), p.x0, p.bcs, p.weights)
+    for S in (2, 4):
+        cfg = p.cfg.with_(substeps=S)
+        est64 = O.error_estimate(cfg, p.x0, p.bcs, p.weights)
+        with colnde.ColumnNDE(cfg, n, engine=engine) as nde:
+            nde.set_problem(p.x0, p.bcs)
+            est = nde.error_estimate(p.weights)
+            a = nde.forward(p.weights)
+        q = (a.astype(np.float64) - b) / (1e-3 + np.abs(b))
+        true = np.max(np.sqrt(np.mean(q * q, axis=-1)))
+        _record("error_estimate/%d/%d" % (engine, S), estimate=est, oracle_estimate=est64, true_error=true)
+        assert 0.5 * true < est < 2.0 * true, (S, est, true)
+        assert 0.5 * est64 < est < 2.0 * est64, (S, est, est64)
+
+
+def test_choose_substeps_and_the_automatic_mode():
+    """reltol at the boundary: the 2-day suite's own nets (weights/1e2) meet the reference's reltol = 1e-3 at the 2 sub-steps the diffusive stability
+    bound allows; nets 67x larger (weights/1.5) make the right-hand side stiffer than the closure and need 4 — colnde_min_substeps does not see that, the estimate
+    does.  substeps = 0 makes the handle choose in its first solve call; after the tapes are planned the count is fixed."""
+    sc = [1, 1, 1, 5e-3, 5e-3, 5e-3]
+    for divisor in (1e2, 1.5):
+        p = synthetic.wind_mixing_problem(24, n_frames=9, weight_divisor=divisor)
+        assert colnde.min_substeps(p.cfg) == 2
+        est64 = {S: O.error_estimate(p.cfg.with_(substeps=S), p.x0, p.bcs, p.weights) for S in (2, 4, 8, 16)}
+        want = min(S for S, e in est64.items() if e <= 1e-3)                # what the float64 oracle's estimate chooses
+        assert not any(0.8e-3 < e < 1.25e-3 for e in est64.values())         # (no candidate sits on the threshold: float32 must choose the same)
+        assert want == 2 if divisor == 1e2 else want > 2
+        with colnde.ColumnNDE(p.cfg, 24) as nde:
+            nde.set_problem(p.x0, p.bcs)
+            S, est = nde.choose_substeps(p.weights, 1e-3)
+            assert (S, nde.substeps) == (want, want) and 0 < est <= 1e-3
+            ref = O.solve(p.cfg.with_(substeps=want), p.x0, p.bcs, p.weights)
+            assert np.abs(nde.forward(p.weights) - ref).max() < SOL_ATOL
+            S2, _ = nde.choose_substeps(p.weights, 2e-4)                     # a tighter tolerance: more sub-steps
+            assert S2 > want and nde.substeps == S2
+            # float32 solves resolve ~1e-4 in this norm (it divides by 1e-3 + |u|, and round-off grows with the step count): a tolerance below that
+            # is refused with the floor named, not chased to thousands of sub-steps
+            with pytest.raises(colnde.ColndeError, match="round-off floor"):
+                nde.choose_substeps(p.weights, 1e-6)
+        auto = p.cfg.with_(substeps=0, reltol=1e-3)
+        with colnde.ColumnNDE(auto, 24) as nde:
+            nde.set_problem(p.x0, p.bcs)
+            truth = nde.forward(p.weights_truth)                              # the first solve call chooses (from these weights)
+            first = nde.substeps
+            assert first >= 2
+            nde.set_problem(p.x0, p.bcs, truth)
+            tot, terms, grad = nde.loss_grad(p.weights, sc)
+            assert np.isfinite(tot) and np.isfinite(grad).all() and nde.substeps == first
+            with pytest.raises(colnde.ColndeError, match="sizes the tapes"):
+                nde.choose_substeps(p.weights, 1e-6)
+            g = O.loss_and_grad(p.cfg.with_(substeps=first), p.x0, p.bcs, p.weights, truth, np.array(sc, float))[2]
+            assert _rel(grad, g) < 2e-3
+    with pytest.raises(ValueError):
+        synthetic.wind_mixing_problem(4, n_frames=3).cfg.with_(reltol=2.0).validate()
+
+
+def test_error_estimate_reports_a_non_finite_solve_as_infinite():
+    p = synthetic.wind_mixing_problem(9, n_frames=5, weight_divisor=1e2)
+    x0 = p.x0.copy()
+    x0[2, 17] = np.nan
+    with colnde.ColumnNDE(p.cfg, 9) as nde:
+        nde.set_problem(x0, p.bcs)
+        assert nde.error_estimate(p.weights) == np.inf
+        with pytest.raises(colnde.ColndeError, match="not finite"):
+            nde.choose_substeps(p.weights, 1e-3)

@@ -115,8 +115,9 @@ def test_flux_train_keeps_adam_state_across_calls():
 
 
 def test_solve_issues_maxiters_plus_one_callbacks_the_last_on_the_reverted_best():
-    """GalacticOptim's `__solve` calls `cb(min_θ, min_err...)` once more at `i == maxiters`: an un-halted solve logs
-    maxiters + 1 records, the last one holding the reverted best θ and the best loss."""
+    """GalacticOptim's `__solve` calls `cb(min_θ, min_err...)` once more at `i == maxiters`: an un-halted solve ISSUES maxiters + 1
+    callbacks, the last one on the reverted best θ with the best loss.  (What the reference's own callback does with that extra call — nothing:
+    `if iter <= maxiters`, NDE_training.jl:344 — is the next test's subject)"""
     prob = Quadratic()
     lit_calls, calls = [], []
     w = galactic_solve(prob.grad_loss, np.zeros(12), FluxADAM(0.3), 15, cb=lambda th, x: lit_calls.append((th.copy(), x)) and False)
@@ -134,3 +135,41 @@ def test_solve_issues_maxiters_plus_one_callbacks_the_last_on_the_reverted_best(
     calls.clear()
     train_NDE(prob, np.zeros(12, np.float32), [ADAM(0.3)], epochs=2, maxiters=5, cb=cb)
     assert len(calls) == 12
+
+
+def test_reference_logging_callback_writes_maxiters_records_per_solve(tmp_path):
+    """the reference's `cb` is guarded by `if iter <= maxiters` (NDE_training.jl:343-368), so the extra callback GalacticOptim issues on
+    the reverted best point neither prints nor writes: a reference log holds exactly `maxiters` records per (optimizer, epoch) solve.
+    `reference_logging_callback` reproduces the closure; wired into `train_NDE` as the docstring says, the log has maxiters records per solve,
+    their losses are the per-iteration ones (not the duplicated minimum), and `extract_NN` indexes them as in a reference log."""
+    from colnde import checkpoint as ck
+    from colnde.config import NDEConfig
+    from colnde.wind_mixing import reference_logging_callback
+    cfg = NDEConfig(layer_sizes=(96, 2, 31), activations=("mish", "identity"), save_times=(0.0, 1.0))
+    n = cfg.n_params
+
+    class Prob:                        # a quadratic in the full weight vector with the six-term loss bookkeeping of WindMixingNDE.grad_loss
+        loss_scalings = np.array([1, 1, 1, 5e-3, 5e-3, 5e-3])
+
+        def grad_loss(self, th):
+            th = np.asarray(th, np.float64)
+            tot = float(0.5 * np.sum((th - 0.3) ** 2))
+            return tot, dict(zip(("u", "v", "T", "dudz", "dvdz", "dTdz"), [tot / 6] * 6)), (th - 0.3).astype(np.float32)
+
+    path = str(tmp_path / "log.tree")
+    maxiters, calls = 7, []
+    w = np.zeros(n, np.float32)
+    nets0 = [ck.network_record(w[k * (n // 3):(k + 1) * (n // 3)], cfg.layer_sizes, cfg.activations) for k in range(3)]
+    opts = [ADAM(0.05), ADAM(0.02)]
+    ck.write_metadata_NDE_training(path, ["f"], [1], [range(1, 3)], {"Pr": 1.0}, [opts], *nets0)
+    for opt in opts:                                       # one cb per solve, as train_NDE's loop builds them (the stage is the same: one training stage)
+        cb = reference_logging_callback(path, cfg, 1, opt, maxiters, log=lambda it, tot, losses: calls.append((it, tot)))
+        res = train_NDE(Prob(), w, [opt], epochs=1, maxiters=maxiters, cb=cb)
+        w = res.weights
+    assert len(calls) == 2 * maxiters and [c[0] for c in calls[:maxiters]] == list(range(1, maxiters + 1))
+    with ck.GroupFile(path) as f:
+        keys = f.keys("training_data/loss/total/1")
+        assert len(keys) == 2 * maxiters                    # maxiters per solve — not maxiters + 1
+        logged = [float(f["training_data/loss/total/1/%d" % (i + 1)]) for i in range(2 * maxiters)]
+    np.testing.assert_allclose(logged, [c[1] for c in calls], rtol=1e-6)
+    assert len(set(np.round(logged[:maxiters], 12))) == maxiters      # strictly decreasing quadratic: no duplicated minimum record
