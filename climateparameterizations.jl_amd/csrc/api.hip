@@ -1221,7 +1221,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                     // the companion of the split forward: one wavefront per flux net (+ a helper) per tile, writing tile16's delta tape
                     e = rt_launch_adjoint_split(h->m, h->d_wimg, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                                 h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
-                                                h->d_t16_ztape, lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, h->d_dwtape, h->split_rich, h->adj_helper, h->stream);
+                                                h->d_t16_ztape, lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, h->d_dwtape, h->split_rich, h->adj_helper, h->sp_adj, h->stream);
                 else
                 e = launch_adjoint(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->d_tiles, h->d_bias_zoff, h->d_bias_goff,
                                               h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
@@ -1742,6 +1742,7 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
         bf_dw = h->sp_dw && (h->d_dwtape ? !h->dw_split.passes.empty() : true);
     } else {
         bf_fwd = h->sp_fwd && h->fwd_split && h->fwd_helper && h->cfg.stepper == COLNDE_STEPPER_RK4;
+        bf_adj = h->sp_adj && h->adj_split && rt_adjoint_split_has_bf16(h->m, h->adj_helper) && (h->t16_dwtape < 0 || (h->t16_dwtape == 1 && h->d_t16_ztape));
         bf_dw = h->sp_dw && h->t16_dwtape == 1 && !h->dw_split.passes.empty();
     }
     info[7] |= (bf_fwd ? 2 : 0) | (bf_adj ? 4 : 0) | (bf_dw ? 8 : 0);

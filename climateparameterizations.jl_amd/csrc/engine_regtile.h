@@ -41,7 +41,14 @@
 #define RT_ASIMG_LEFT (RT_ASIMG_HM_WORDS)                 // 576 floats
 #define RT_ASIMG_L (RT_ASIMG_LEFT + 576)                  // 27 * 256 words
 #define RT_ASIMG_WORDS (RT_ASIMG_L + 27 * 256)
-#define RT_IMG_ALLOC (RT_ASIMG_OFF + RT_ASIMG_WORDS)
+// ... and for the net-split adjoint's W1_n^T products (rt16sh_adjoint_kernel<ACT, RICH, false, true>, COLNDE_MATRIX_BF16X3_EXACT): per net n, 32-deep k-block kb
+// (element e of lane (i, kq) <-> quad Q = 8 kb + e of the net's 13, hidden feature 4 Q + kq) and 16-row state tile (x index 16 tile + i):
+// [net][kb][tile][planes h, m][64 lanes][8 bf16] go to LDS in the fp32 W1's place, [net][kb][tile][plane l][64 lanes][8 bf16] stay in global memory (L2)
+#define RT_NSA_OFF (RT_ASIMG_OFF + RT_ASIMG_WORDS)
+#define RT_NSA_HM_WORDS (3 * 2 * 6 * 2 * 256)
+#define RT_NSA_L (RT_NSA_HM_WORDS)
+#define RT_NSA_WORDS (RT_NSA_L + 3 * 2 * 6 * 256)
+#define RT_IMG_ALLOC (RT_NSA_OFF + RT_NSA_WORDS)
 
 bool rt_supported(const DevModel& m);
 size_t rt_forward_lds_bytes();
@@ -55,7 +62,8 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
 size_t rt_split_rich_record_floats();   // floats per (tile, step, stage) of the net-split kernels' rich tape (which then takes the place of t16_ztape)
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
-                                   int n_col, float* dwtape, bool rich, bool use_helper, hipStream_t stream);
+                                   int n_col, float* dwtape, bool rich, bool use_helper, bool want_split, hipStream_t stream);
+bool rt_adjoint_split_has_bf16(const DevModel& m, bool use_helper);   // the net-split adjoint has a split (bf16-pipe) kernel for this configuration
 bool rt_forward_is32();   // COLNDE_RT_FWD=32 in the environment (read when a handle is created)
 size_t rt_adjoint_lds_bytes();
 size_t rt_tape_floats(int n_col, int n_steps);

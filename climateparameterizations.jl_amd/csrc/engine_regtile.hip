@@ -377,6 +377,26 @@ __global__ void rt_pack_split_kernel(const float* __restrict__ img, unsigned* __
     }
 }
 
+// ... and for the net-split adjoint's W1_n^T products (RT_NSA_*: rt16sh_adjoint_kernel<ACT, RICH, false, true>): group G = (n * 2 + kb) * 6 + tile, lane (i, kq),
+// element e <-> W1_n[feature 4 (8 kb + e) + kq][x index 16 tile + i] (zero beyond feature 49); planes h, m interleaved per group, plane l behind them
+__global__ void rt_pack_split_nsadj_kernel(const float* __restrict__ img, unsigned* __restrict__ simg) {
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < 36 * 256; x += gridDim.x * blockDim.x) {
+        const int G = x >> 8, lane = (x >> 2) & 63, pr = x & 3;
+        const int n = G / 12, kb = (G / 6) & 1, tile = G % 6, i = lane & 15, kq = lane >> 4;
+        float v[2];
+#pragma unroll
+        for (int z = 0; z < 2; z++) {
+            const int f = 4 * (8 * kb + 2 * pr + z) + kq;
+            v[z] = f < 50 ? img[RT_W1C + (n * 50 + f) * RT_LD1 + 16 * tile + i] : 0.0f;
+        }
+        const float r0 = v[0] - __uint_as_float(__float_as_uint(v[0]) & 0xffff0000u), r1 = v[1] - __uint_as_float(__float_as_uint(v[1]) & 0xffff0000u);
+        const float l0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), l1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        simg[(size_t)(G * 2 + 0) * 256 + lane * 4 + pr] = (__float_as_uint(v[1]) & 0xffff0000u) | (__float_as_uint(v[0]) >> 16);
+        simg[(size_t)(G * 2 + 1) * 256 + lane * 4 + pr] = (__float_as_uint(r1) & 0xffff0000u) | (__float_as_uint(r0) >> 16);
+        simg[RT_NSA_L + (size_t)G * 256 + lane * 4 + pr] = (__float_as_uint(l1) & 0xffff0000u) | (__float_as_uint(l0) >> 16);
+    }
+}
+
 // ... and for the net-split forward kernel (RT_SIMG2_*): layer 1 per net (tiles of that kernel: quad Q = 4 t + (i & 3) of the net's 13, feature
 // 4 Q + (i >> 2)), layer 2 as above, and the 8 live lanes of each net's fourth layer-1 tile (quad 12: features 48, 49 -> rows i = 0, 4)
 __global__ void rt_pack_split_ns_kernel(const float* __restrict__ img, unsigned* __restrict__ simg) {
@@ -3126,19 +3146,33 @@ rt16s_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 // parts into x̄.  While the helper works (between A and B) the net waves do what depends on the tapes alone: next stage's prefetch, this
 // stage's activations, the record's x and a parts.  Every wave executes exactly the barriers B and A in every stage.
 // ------------------------------------------------------------------------------------------------
-template <int ACT, bool RICH, bool RKC = false>
+// SPLIT (COLNDE_MATRIX_BF16X3_EXACT, RK4): the net waves' W1_n^T δz1_n products — 78 of a stage's 114 fp32 MFMAs, 3.0 k of its 8.2 k cycles — on
+// v_mfma_f32_16x16x32_bf16 from exact three-way operand splits: δz1 is already held as the B operand needs it (lane group kq holds the features
+// 4 Q + kq of its column: two 32-deep k-blocks, quads 0..7 and 8..12 + padding), W1_n^T comes pre-split (RT_NSA_*), planes h and m from LDS in the
+// fp32 W1's place (the rest of the fp32 image moves down), plane l from L2 into registers before barrier B.
+template <int ACT, bool RICH, bool RKC = false, bool SPLIT = false>
 __global__ void __launch_bounds__(256)
 rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ save_times, int n_save, int substeps,
                       const float* __restrict__ sol, const float* __restrict__ truth, const float* __restrict__ t16_tape,
                       const float* __restrict__ t16_ztape, LossWeights lw, float* __restrict__ slab, int n_col,
                       float* __restrict__ dwtape) {
-    float* wl = rt_smem;
-    for (int e = threadIdx.x; e < RT_IMG_FLOATS; e += 256) wl[e] = wimg[e];
-    float* lbase = rt_smem + ((RT_IMG_FLOATS + 3) & ~3);
+    static_assert(!(SPLIT && RKC), "the split net-split adjoint is built for RK4");
+    // SPLIT: LDS holds the fp32 image from W2 on (addressed through wl as before: wl[RT_W2C + x]), no fp32 W1
+    constexpr int IMG0 = SPLIT ? RT_W2C : 0;
+    constexpr int IMGF = ((RT_IMG_FLOATS - IMG0) + 3) & ~3;
+    float* wl = rt_smem - IMG0;
+    for (int e = IMG0 + threadIdx.x; e < RT_IMG_FLOATS; e += 256) wl[e] = wimg[e];
+    float* lbase = rt_smem + IMGF;
     f32x4v* ex = reinterpret_cast<f32x4v*>(lbase);                    // the nets' parts of x̄: [3 nets][6 tiles][64 lanes]
     f32x4v* dOl = ex + 3 * 6 * 64;                                     // the helper's dO: [3 variables][2 tiles][64 lanes]
     float* stg_all = lbase + (3 * 6 * 64 + 3 * 2 * 64) * 4;           // record staging: see rt16s_adjoint_kernel
     for (int e = threadIdx.x; e < 3 * RT16S_STG; e += 256) stg_all[e] = 0.0f;
+    const u32x4* hm = reinterpret_cast<const u32x4*>(stg_all + 3 * RT16S_STG);      // SPLIT: [net][kb][tile][h, m][64 lanes] operand planes
+    if constexpr (SPLIT) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(wimg + RT_NSA_OFF);
+        u32x4* dst = reinterpret_cast<u32x4*>(stg_all + 3 * RT16S_STG);
+        for (int e = threadIdx.x; e < RT_NSA_HM_WORDS / 4; e += 256) dst[e] = src[e];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -3416,6 +3450,20 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                     if (g >= 2) D1[3][0] = 0.0f;                                         // features 50, 51 of quad 12
                 }
                 if (qs > 0) prefetch(qs - 1);
+                // (SPLIT) the twelve l-plane operands of this net's W1^T products, from L2: requested here, consumed behind barrier B and two chains
+                // ... and the 24 h / m plane fragments from LDS: all of them before barrier B too, so that behind it the products wait for nothing
+                // (fetched tile by tile in front of their products they exposed an LDS round trip per tile: 8.03 instead of 8.2 ms, no more)
+                u32x4 Lr[12], Hm[24];
+                if constexpr (SPLIT) {
+                    int lz = lane;                        // (opaque: left loop-invariant the loads are hoisted out of the time loop and their registers pinned)
+                    asm volatile("" : "+v"(lz));
+                    const u32x4* lg = reinterpret_cast<const u32x4*>(wimg + RT_NSA_OFF + RT_NSA_L) + n * 12 * 64 + lz;
+#pragma unroll
+                    for (int u = 0; u < 12; u++) Lr[u] = lg[u * 64];
+                    const u32x4* hn = hm + n * 24 * 64 + lz;
+#pragma unroll
+                    for (int u = 0; u < 24; u++) Hm[u] = hn[u * 64];
+                }
                 float a3[2][8], a2[4][5];
                 rt16_fetch_ops<2, 8>(wl, a3, [&](int u, int k) { return b3T[u] + (16 * (k >> 2) + (k & 3)) * RT_LD3; });
                 rt16_fetch_ops<4, 5>(wl, a2, [&](int t, int k) { return b2T[t] + 4 * k * RT_LD2; });
@@ -3439,7 +3487,7 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
 #pragma unroll
                 for (int u = 0; u < 2; u++) dZ2[u] *= D2[u];
                 float a1[2][2][13];
-                rt16_fetch_ops<2, 13>(wl, a1[0], [&](int c, int k) { return b1T + 16 * c + 4 * k * RT_LD1; });
+                if constexpr (!SPLIT) rt16_fetch_ops<2, 13>(wl, a1[0], [&](int c, int k) { return b1T + 16 * c + 4 * k * RT_LD1; });
                 RT_SCHED_HARD();
                 // (4) δz1 = (W2^T δz2) ∘ act'(z1)
                 f32x4t dZ1[4] = {(f32x4t)(0.0f), (f32x4t)(0.0f), (f32x4t)(0.0f), (f32x4t)(0.0f)};
@@ -3459,6 +3507,8 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
 #pragma unroll
                         for (int r = 0; r < 4; r++)
                             if (!(v == 0 && r == 0 && g == 0)) s3[16 * v + r] = dO.t[v][r];
+                    // (deferring this copy to the top of the next stage, beside the helper's pullback, was measured: 7.58 -> 7.63 ms in front of that
+                    //  stage's loads, 7.89 ms behind them — the stores then sit in front of the l-plane loads in the in-order vmcnt queue)
 #pragma unroll
                     for (int i = 0; i < 11; i++) *reinterpret_cast<f32x4v*>(rec + rec_wr[i]) = *reinterpret_cast<const f32x4v*>(stg + stg_rd[i]);
                 }
@@ -3468,6 +3518,23 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                 for (int u = 0; u < 2; u++) { gb2[u] += dZ2[u]; gb3[u] += dO.t[u]; }
                 RT_STAMP(3);
                 // (5) this net's part of the state cotangent, W1_n^T δz1 (6 tiles x 13 k-steps)
+                if constexpr (SPLIT) {
+                    // δz1 as the B operand of two 32-deep k-blocks: element e of k-block kb is quad 8 kb + e of this lane group (padding quads are zero)
+                    const float d80[8] = {dZ1[0][0], dZ1[0][1], dZ1[0][2], dZ1[0][3], dZ1[1][0], dZ1[1][1], dZ1[1][2], dZ1[1][3]};
+                    const float d81[8] = {dZ1[2][0], dZ1[2][1], dZ1[2][2], dZ1[2][3], dZ1[3][0], dZ1[3][1], dZ1[3][2], dZ1[3][3]};
+                    const Bf3 B0 = bf3_split8(d80), B1 = bf3_split8(d81);
+#pragma unroll
+                    for (int tl = 0; tl < 6; tl++) {
+                        Bf3 A0, A1_;
+                        A0.h = Hm[tl * 2 + 0]; A0.m = Hm[tl * 2 + 1]; A0.l = Lr[tl];
+                        A1_.h = Hm[(6 + tl) * 2 + 0]; A1_.m = Hm[(6 + tl) * 2 + 1]; A1_.l = Lr[6 + tl];
+                        f32x4t c2 = (f32x4t)(0.0f);
+                        c2 = mfma16_bf3(A0, B0, c2);
+                        c2 = mfma16_bf3(A1_, B1, c2);
+                        ex[(n * 6 + tl) * 64 + lane] = c2;
+                        RT_SCHED_FENCE();
+                    }
+                } else
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
                     if (q < 2) rt16_fetch_ops<2, 13>(wl, a1[(q + 1) & 1], [&](int c, int k) { return b1T + 32 * (q + 1) + 16 * c + 4 * k * RT_LD1; });
@@ -3612,36 +3679,48 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, false, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true, false, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true, false, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true, false, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true, false, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true, false, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true, false, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -3755,9 +3834,11 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
     return hipGetLastError();
 }
 
+bool rt_adjoint_split_has_bf16(const DevModel& m, bool use_helper) { return use_helper && !m.rkc && m.nst == 4; }
+
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
-                                   int n_col, float* dwtape, bool rich, bool use_helper, hipStream_t stream) {
+                                   int n_col, float* dwtape, bool rich, bool use_helper, bool want_split, hipStream_t stream) {
     // the record formats this kernel reads and writes are tile16's for exactly this shape
     if (!rt_supported(m) || dwtape_row_floats(m) * CT != RT16S_REC || t16_ztape_col_floats(m) * CT != RT16S_ZREC || (m.nst != 4 && !(m.rkc && use_helper)))
         return hipErrorInvalidValue;
@@ -3765,9 +3846,16 @@ hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const f
     const dim3 grid((n_col + 15) / 16), block(192);
     const size_t ldsh = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + (3 * 6 * 64 + 3 * 2 * 64) * 16 + 3 * RT16S_STG * sizeof(float);
     const dim3 blockh(256);
+    // COLNDE_MATRIX_BF16X3_EXACT: the W1^T products on the bf16 pipe (four-wave RK4 kernels); LDS: the fp32 image from W2 on, exchange, staging, the h / m planes
+    const bool split = want_split && rt_adjoint_split_has_bf16(m, use_helper);
+    const size_t ldss = ((((size_t)RT_IMG_FLOATS - RT_W2C) + 3) & ~(size_t)3) * sizeof(float) + (3 * 6 * 64 + 3 * 2 * 64) * 16 + 3 * RT16S_STG * sizeof(float) +
+                        (size_t)RT_NSA_HM_WORDS * 4;
+    if (split) hipLaunchKernelGGL(rt_pack_split_nsadj_kernel, dim3(36), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_NSA_OFF);
 #define RT_ADJS(A)                                                                                                                              \
     do {                                                                                                                                        \
-        if (use_helper && rich && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        if (split && rich) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true, false, true>), grid, blockh, ldss, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else if (split) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false, false, true>), grid, blockh, ldss, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else if (use_helper && rich && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else if (use_helper && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else if (use_helper && rich) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else if (use_helper) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \

@@ -32,7 +32,7 @@ def _fc(n, Nz, **kw):
 CASES = {
     # name: (problem factory, engine, kernel families that have a split kernel there: forward / adjoint / dW)
     "regtile": (lambda: _wm(200, 25), ENGINE_REGTILE, (True, True, True)),
-    "net_split_auto": (lambda: _wm(40, 33), 0, (True, False, True)),
+    "net_split_auto": (lambda: _wm(40, 33), 0, (True, True, True)),
     "tile16_wind_mixing": (lambda: _wm(40, 9), ENGINE_TILE16, (False, False, True)),
     "tile16_smoothing": (lambda: _wm(21, 9, **{"smooth_NN": True}), 0, (False, False, True)),
     "fc32_32": (lambda: _fc(70, 32), 0, None),                        # (fc32's families: whatever the build has; checked for consistency only)

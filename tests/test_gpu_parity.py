@@ -532,6 +532,39 @@ def test_net_split_forward_on_the_bf16_pipe_with_exact_operand_splitting(rich, m
     assert _rel(gsp, g) < max(1.5 * _rel(g32, g), 2e-6)
 
 
+@pytest.mark.parametrize("name", [None, "diurnal", "relu", "conv_adj_branch", "weights/4"])
+@pytest.mark.parametrize("rich", ["0", "1"])
+def test_net_split_adjoint_on_the_bf16_pipe_with_exact_operand_splitting(rich, name, monkeypatch):
+    """The adjoint kernel of the net-split pair alone on the split arithmetic: rt16sh_adjoint_kernel<ACT, RICH, false, true> forms every net wave's part
+    of x̄, W1ₙᵀ δz1ₙ — 78 of a stage's 114 fp32 MFMAs — with v_mfma_f32_16x16x32_bf16 from exact three-way splits (W1ₙᵀ planes h, m in LDS, l from
+    L2; δz1 split in registers, two 32-deep k-blocks with the padding quads zero).  x̄ feeds λ: every later stage sees the difference.  Same handle, same
+    tapes (plain and rich): the gradient differs from the fp32-MFMA kernel's by float32 round-off (stated: 2e-6 relative L2), the loss is bit-identical
+    (the forward is untouched), a repeat is bit-identical, and against the float64 oracle the split kernel is as close (within 1.5x)."""
+    monkeypatch.setenv("COLNDE_T16_SPLIT_RICH", rich)
+    kw = VARIANTS[name] if name in VARIANTS else {}
+    p = synthetic.wind_mixing_problem(40, n_frames=73 if name is None else 25, weight_divisor=4.0 if name == "weights/4" else 1e2, **kw)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = np.array([1.0, 0.8, 1.2, 5e-3, 4e-3, 6e-3])
+    tot, terms, g, _ = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, p.n_columns) as nde:
+        nde.set_problem(p.x0, p.bcs, truth)
+        _arith(monkeypatch, nde)
+        t32, _, g32 = nde.loss_grad(p.weights, sc)
+        plan32 = nde.plan()
+        _arith(monkeypatch, nde, adj=True)
+        tsp, _, gsp = nde.loss_grad(p.weights, sc)
+        again = nde.loss_grad(p.weights, sc)[2]
+        plan = nde.plan()
+    assert plan["split_adjoint"] and plan["bf16x3_adjoint"] and not plan["bf16x3_forward"] and not plan["bf16x3_dw"] and not plan32["bf16x3_adjoint"]
+    assert plan["split_rich_tape"] == (rich == "1")
+    assert t32 == tsp and np.array_equal(again, gsp)
+    d = _rel(gsp, g32.astype(np.float64))
+    e32, esp = _rel(g32, g), _rel(gsp, g)
+    _record("test_net_split_adj_split/rich%s/%s" % (rich, name), split_vs_fp32=d, fp32_vs_oracle=e32, split_vs_oracle=esp)
+    assert 0.0 < d < 2e-6
+    assert esp < max(1.5 * e32, 2e-6)
+
+
 # ---- the net-split kernels of the latency points (engine AUTO up to 8,192 columns of the regtile shape) -----------------
 @pytest.mark.parametrize("name", ["mpp_zero_weights", "mpp_bc_faces", "diurnal", "conv_adj_branch", "swish", "raw", "dRi_small", "relu",
                                   "tanh", "leakyrelu"])
