@@ -406,20 +406,39 @@ def free_convection_workload(args, world, rank, local_rank, dev, comm, dist):
         per_gpu_tf = flop * cs / (elapsed / args.steps) / 1e12 / world
         dom = max(("forward", "adjoint", "dw1"), key=lambda k: km[k])
         dom_tf = 4 * mlp * ncol * p.cfg.n_steps / (km[dom] * 1e-3) / 1e12
+        plan = nde.plan()
+        on_bf16 = {"forward": plan.get("bf16x3_forward"), "adjoint": plan.get("bf16x3_adjoint"), "dw1": plan.get("bf16x3_dw")}
+        # executed MFMA flop per RHS evaluation and column: the 63-row output layer runs as 64 rows; under the exact three-way split every
+        # f32 product is SIX bf16 products (csrc/engine_fc_split.hip, dw_gemm_split_kernel), else one f32 MFMA product
+        mlp_exec = 2 * (64 * 256 + 256 * 256 + 256 * 64)
+        def pipe_frac(k):
+            ex = 4 * mlp_exec * ncol * p.cfg.n_steps
+            t = km[k] * 1e-3
+            return (6 * ex / (PEAK_BF16_MFMA_TFLOPS * 1e12) if on_bf16[k] else ex / (PEAK_FP32_MFMA_TFLOPS * 1e12)) / t if t > 0 else None
+        dom_frac = pipe_frac(dom)
+        names = {"forward": "fcs_forward_kernel" if on_bf16["forward"] else "fc_forward_kernel",
+                 "adjoint": "fcs_adjoint_kernel" if on_bf16["adjoint"] else "fc_adjoint_kernel",
+                 "dw1": "dw_gemm_split_kernel" if on_bf16["dw1"] else "dw_gemm_lds_kernel"}
+        step_ms = elapsed / args.steps * 1e3
         print(json.dumps({
             "metric": "column-timesteps/sec (fwd+adjoint), 64-level free-convection NDE (BASELINE configs[3])",
             "value": cs * args.steps / elapsed, "unit": "column-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "free_convection NDE training (BASELINE configs[3]: 65536 columns x 64 levels on 4 GPUs): %d columns/GPU x 64 levels x 129 save "
                                    "points x 4 RK4 sub-steps, FreeConvectionNDE, 64-256-256-63 relu, single MSE loss" % ncol,
                        "columns_per_gpu": ncol, "levels": 64, "rk4_steps": p.cfg.n_steps, "n_params": p.cfg.n_params, "parallelism": "columns sharded x%d" % world,
+                       "matrix_arithmetic": nde.matrix_arithmetic,
                        "exchange": "none (one rank)" if (comm is None and dist is None) else ("colnde_comm (RCCL behind the C ABI)" if comm is not None else "torch.distributed nccl (RCCL)")},
-            "roofline": {"kernel": {"forward": "fc_forward_kernel", "adjoint": "fc_adjoint_kernel", "dw1": "dw_gemm_lds_kernel"}[dom], "bound": "mfma",
-                         "achieved": dom_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "avg_launch_ms": km[dom], "kernel_ms": km,
+            # achieved = ALGORITHMIC f32-equivalent TFLOP/s of the dominant kernel; frac = the time its EXECUTED MFMA instructions need on the matrix
+            # pipe (bf16 flop / 2.5 PF, f32 flop / 157.3 TF) over its duration; peak = achieved / frac (same convention as the headline line)
+            "roofline": {"kernel": names[dom], "bound": "mfma",
+                         "achieved": dom_tf, "peak": (dom_tf / dom_frac) if dom_frac else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_frac, "traffic": None,
+                         "frac_is": "matrix-pipe time fraction of the executed MFMA instruction mix", "avg_launch_ms": km[dom], "kernel_ms": km,
+                         "kernels": {k: {"kernel": names[k], "on_bf16_pipe": bool(on_bf16[k]), "avg_launch_ms": km[k], "matrix_pipe_time_frac": pipe_frac(k)}
+                                     for k in ("forward", "adjoint", "dw1")},
                          "whole_step": {"algorithmic_flop_per_column_timestep": flop, "achieved": per_gpu_tf, "unit": "TFLOP/s per GPU",
-                                        "frac": per_gpu_tf / PEAK_FP32_MFMA_TFLOPS},
-                         "plan": nde.plan()},
+                                        "matrix_pipe_time_frac": sum((pipe_frac(k) or 0.0) * km[k] for k in ("forward", "adjoint", "dw1")) / step_ms},
+                         "plan": plan},
             "multi_gpu": None if spread is None else {"allreduce_floats": nde.n_params + 8, "weights_checksum_spread_over_ranks": spread},
             "cpu_baseline": None, "loss_total": float(res[nde.n_params + 6]), "grad_l2": float(np.linalg.norm(res[:nde.n_params])),
         }), flush=True)

@@ -1398,31 +1398,20 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
         for (int t = 0; t < 4; t++) acc[q][t] = (dwf32x16)(0.0f);
     }
     // asynchronous copy of up to RPB records into an LDS buffer: 1 KB per wave instruction, lanes contiguous
-    // part `part` of `nparts`: the copy of a stage is issued in slices between the blocks of the stage before it (DW_SPREAD), so that the
-    // 256 CUs do not all ask HBM for their whole next stage at the same moment
-    auto fetch = [&](size_t r, int dst /* float offset of the buffer inside smem */, int part = 0, int nparts = 1) {
+    // (issuing a stage's copy in slices between the blocks of the stage before it was measured slower: 56.4 -> 67.3 ms, profiles/r03s_gemm_spread.log)
+    auto fetch = [&](size_t r, int dst /* float offset of the buffer inside smem */) {
         const size_t nrec = r1 - r < (size_t)RPB ? r1 - r : (size_t)RPB;
         const int nfl = (int)nrec * rec_floats;
         const float* src = dwtape + r * (size_t)rec_floats;
-        int c = 0;
-        for (int o = wave * 256; o < nfl; o += NW * 256, c++) {
-#ifndef DW_PROBE_NO_DMA
-            if (c % nparts == part && o + lane * 4 < nfl)
-                __builtin_amdgcn_global_load_lds(src + o + lane * 4, smem + dst + o, 16, 0, 0);
-#endif
-        }
+        for (int o = wave * 256; o < nfl; o += NW * 256)
+            if (o + lane * 4 < nfl) __builtin_amdgcn_global_load_lds(src + o + lane * 4, smem + dst + o, 16, 0, 0);
     };
     if (r0 < r1) fetch(r0, 0);
     __syncthreads();
     int cur = 0;                                         // float offset of the buffer being contracted
     for (size_t r = r0; r < r1; r += RPB) {
-#ifndef DW_SPREAD
         if (r + RPB < r1) fetch(r + RPB, stage_floats - cur);
-#endif
         const int nv = (int)(r1 - r < (size_t)RPB ? r1 - r : (size_t)RPB);
-#ifdef DW_PROBE_NO_MFMA
-        if (nv > 1000)
-#endif
 #pragma unroll
         for (int rr = 0; rr < RPB; rr++) {
             if (rr >= nv) break;                         // wave-uniform: the last stage of a slice may hold fewer records
@@ -1440,9 +1429,6 @@ dw_gemm_lds_kernel(const float* __restrict__ dwtape, size_t n_records, int R, co
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 if (t + 1 < T) load(t + 1, op[(t + 1) & 1]);
-#ifdef DW_SPREAD
-                if ((t & 7) == 0 && r + RPB < r1) fetch(r + RPB, stage_floats - cur, rr * MAXM + (t >> 3), RPB * MAXM);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 const int q = t >> 3;
                 const float a0 = op[t & 1][0], d0 = op[t & 1][1], a1 = op[t & 1][2], d1 = op[t & 1][3];
@@ -1535,9 +1521,6 @@ dw_gemm_split_kernel(const float* __restrict__ dwtape, size_t n_records, int R, 
             for (int c = 0; c < 8; c++) dst[k][c] = *reinterpret_cast<const dws_f32x2*>(rec + src_off[k] + c * R);
     };
     auto sp = [&](const dws_f32x2 (&src)[NIT][8], int buf) {
-#ifdef DWS_NO_SPLIT
-        if (src[0][0][0] != 1.2345f) return;
-#endif
 #pragma unroll
         for (int k = 0; k < NIT; k++) {
             if (!live[k]) continue;
@@ -1566,9 +1549,6 @@ dw_gemm_split_kernel(const float* __restrict__ dwtape, size_t n_records, int R, 
     const bool shared_d = MAXM == 2 && mc[0].ni_rem > 32 && mc[MAXM - 1].ni_rem > 32 && mc[0].no_rem > 32 && mc[MAXM - 1].no_rem > 32 &&
                           mc[0].d_feat == mc[MAXM - 1].d_feat;
     auto products = [&](int buf) {
-#ifdef DWS_NO_MFMA
-        return;
-#endif
         if (MAXM == 2 && shared_d) {
             // four a tiles against the same two d tiles: the next a tile is read while the current one is multiplied
             const Bf3 d0 = ld(buf, mc[0].d_feat), d1 = ld(buf, mc[0].d_feat + 32);
