@@ -62,6 +62,61 @@ def pipe_time_fraction(kernel, arithmetic, stages32, seconds):
     return (stages32 * bf / (PEAK_BF16_MFMA_TFLOPS * 1e12) + stages32 * f32 / (PEAK_FP32_MFMA_TFLOPS * 1e12)) / seconds if seconds > 0 else None
 
 
+class GpuSensors:
+    """Shader clock and board power of THIS rank's GPU, read from the amdgpu sysfs nodes (hwmon freq1_input / power1_input of the PCI device
+    torch reports) by a host thread every 20 ms while a loop runs.  Round 4 found the training steps POWER-limited on MI355X (about 1.3 kW, the
+    shader clock at 2.0-2.2 GHz instead of 2.4): every roofline fraction in this line is quoted against the 2.4 GHz peaks, and this block says
+    what the clock really was.  Never inside the timed region that produces `value`; None when the nodes are not readable."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.samples, self._stop, self._thread, self.dir = [], False, None, None
+        self._threading = threading
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            hw = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+            if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                self.dir = hw[0]
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            return float(open(os.path.join(self.dir, name)).read())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            f, pw = self._read("freq1_input"), self._read("power1_input")
+            if pw is None:
+                pw = self._read("power1_average")
+            self.samples.append((f, pw))
+            time.sleep(0.02)
+
+    def start(self):
+        if self.dir is not None:
+            self._thread = self._threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop = True
+        self._thread.join()
+        fs = [f / 1e6 for f, _ in self.samples if f]
+        ps = [pw / 1e6 for _, pw in self.samples if pw]
+        if not fs:
+            return None
+        return {"shader_clock_MHz_mean": sum(fs) / len(fs), "shader_clock_MHz_min": min(fs), "shader_clock_MHz_max": max(fs),
+                "board_power_W_mean": (sum(ps) / len(ps)) if ps else None, "samples": len(fs), "peak_clock_MHz_the_rooflines_assume": 2400,
+                "source": self.dir, "sampled_over": "the second (untimed-for-value) pass of the same K steps"}
+
+
 def measured_copy_bandwidth(dev, gib=4):
     """One device-to-device copy of `gib` GiB, outside every timed region: bytes read + bytes written per second (SURVEY §8d asks for the HBM
     fraction against a copy bandwidth measured on the box beside the vendor figure)."""
@@ -720,11 +775,13 @@ def main():
     nde.set_profiling(False)
     # the same K steps once more with the per-kernel HIP events off (reported beside the headline, never instead of it)
     barrier()
+    sensors = GpuSensors(dev).start() if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed_plain = max_over_ranks(time.perf_counter() - t0)
+    clock = sensors.stop() if sensors is not None else None
     res = out.cpu().numpy()
     per_rank_ms = allreduce_ms = None
     if comm is not None or dist is not None:
@@ -829,6 +886,9 @@ def main():
                                                    step_flop * colsteps_per_step / (elapsed / args.steps) / 1e12 / world / PEAK_FP32_MFMA_TFLOPS},
                 "avg_launch_ms": adj_s * 1e3, "launches": n_adj,
                 "kernels": kb,
+                # the step runs power-limited: at the measured clock the matrix pipe's peak is (clock / 2400) of the figure `frac` is quoted against
+                "clock": clock,
+                "frac_at_measured_clock": (dom_frac * 2400.0 / clock["shader_clock_MHz_mean"]) if (clock and dom_frac) else None,
                 "hbm": {"achieved": ab["adjoint"] * units_per_launch / adj_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": ab["adjoint"] * units_per_launch / adj_s / 1e9 / PEAK_HBM_GBPS,
                         "algorithmic_bytes_per_column_timestep": ab["adjoint"],
@@ -860,18 +920,20 @@ def main():
                 torch.cuda.synchronize()
                 nde.set_profiling(True)
                 nde.reset_kernel_times()
+                sens32 = GpuSensors(dev).start()
                 t0 = time.perf_counter()
                 for _ in range(3):
                     step()
                 torch.cuda.synchronize()
                 t_f32 = (time.perf_counter() - t0) / 3
+                clock32 = sens32.stop()
                 km = {k: nde.kernel_time(k)[0] / max(nde.kernel_time(k)[1], 1) for k in ("forward", "adjoint", "dw1")}
                 g32 = out[:nde.n_params]
                 third = nde.n_params // 3
                 l1 = lambda g: torch.cat([g[n * third:n * third + 4850] for n in range(3)]).double()
                 line["opt_out"] = {"f32_mfma": {
                     "switch": "colnde_config.matrix_arithmetic = COLNDE_MATRIX_F32_MFMA (colnde_set_matrix_arithmetic on the same handle)",
-                    "ms_per_step": t_f32 * 1e3, "value": colsteps_per_step / t_f32, "kernel_ms": km,
+                    "ms_per_step": t_f32 * 1e3, "value": colsteps_per_step / t_f32, "kernel_ms": km, "clock": clock32,
                     "adjoint_kernel_of_f32_mfma_peak": adj_flop * units_per_launch / (km["adjoint"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                     "default_vs_f32_mfma": {
                         "gradient_rel_l2": float((gd.double() - g32.double()).norm() / g32.double().norm()),
@@ -902,6 +964,8 @@ def main():
             return {"value": ln["value"], "ms_per_step": ln["ms_per_step"], "matrix_arithmetic": ln["config"]["matrix_arithmetic"],
                     "opt_out_f32_mfma_value": oo.get("value"), "opt_out_f32_mfma_ms_per_step": oo.get("ms_per_step"),
                     "dominant_kernel_ms": ln["roofline"]["avg_launch_ms"], "matrix_pipe_time_frac": ln["roofline"]["frac"],
+                    "shader_clock_MHz_mean": (ln["roofline"].get("clock") or {}).get("shader_clock_MHz_mean"),
+                    "board_power_W_mean": (ln["roofline"].get("clock") or {}).get("board_power_W_mean"),
                     "self_check": ln.get("self_check")}
         if world == 1 and not args.no_configs:
             # The side configs run after the headline's timed region with its tapes released.  The headline is safe before they start: on stderr
