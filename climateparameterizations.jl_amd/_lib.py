@@ -66,6 +66,7 @@ SYMBOLS = [
     ("colnde_comm_allreduce_dev", ctypes.c_int, [_V, _V, ctypes.c_int64, ctypes.c_int, _V]),
     ("colnde_allreduce_result_dev", ctypes.c_int, [_V, _V, _V]),
     ("colnde_plan", ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int)]),
+    ("colnde_describe", ctypes.c_int, [_V, ctypes.c_char_p, ctypes.c_int]),
     ("colnde_set_profiling", ctypes.c_int, [_V, ctypes.c_int]),
     ("colnde_kernel_time", ctypes.c_int, [_V, ctypes.c_int, _F, ctypes.POINTER(ctypes.c_int)]),
     ("colnde_reset_kernel_times", ctypes.c_int, [_V]),

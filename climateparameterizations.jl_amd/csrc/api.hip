@@ -1766,6 +1766,52 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
     return 0;
 }
 
+// Every environment variable some part of the library reads (api.hip, engine_*.hip): the list colnde_describe reports from.
+static const char* const COLNDE_ENV_SWITCHES[] = {
+    "COLNDE_FWD_SPLIT", "COLNDE_ADJ_SPLIT", "COLNDE_DW_SPLIT", "COLNDE_ADJ_GEOM", "COLNDE_FWD_WLDS", "COLNDE_FWD_THREADS", "COLNDE_T16_FWD_HELPER",
+    "COLNDE_T16_ADJ_HELPER", "COLNDE_T16_FWD_SPLIT", "COLNDE_T16_ADJ_SPLIT", "COLNDE_FC", "COLNDE_FC_CW", "COLNDE_FC_BLOCK", "COLNDE_FC_SEG",
+    "COLNDE_RT_ZTAPE", "COLNDE_RT_BLOCK", "COLNDE_RT_FWD", "COLNDE_ALLOW_UNSTABLE_DT", "COLNDE_T16_DWTAPE", "COLNDE_T16_ZTAPE", "COLNDE_T16_SPLIT_RICH",
+    "COLNDE_T16_BLOCK", "COLNDE_T16_DWLDS", "COLNDE_T16_TAPE_THREADS", "COLNDE_T16_TAPE_WLDS"};
+
+extern "C" int colnde_describe(const colnde_handle* h, char* buf, int capacity) {
+    if (!h) { fail("null argument"); return -1; }
+    int info[8];
+    if (colnde_plan(h, info)) return -1;
+    std::string s;
+    char t[256];
+    const char* eng = info[0] == COLNDE_ENGINE_MFMA ? "regtile" : info[0] == COLNDE_ENGINE_FC32 ? "fc32" : ((info[6] & 1) ? "tile16+net-split" : "tile16");
+    snprintf(t, sizeof t, "engine=%s columns=%d stepper=%s substeps=%d%s", eng, h->cfg.n_columns, h->cfg.stepper == COLNDE_STEPPER_RKC2 ? "rkc2" : "rk4",
+             h->cfg.substeps, h->auto_substeps ? "(chosen from reltol)" : "");
+    s += t;
+    if (h->cfg.stepper == COLNDE_STEPPER_RKC2) { snprintf(t, sizeof t, " rkc_stages=%d", h->cfg.rkc_stages); s += t; }
+    snprintf(t, sizeof t, " matrix_arithmetic=%s forward=%s adjoint=%s dw=%s", h->cfg.matrix_arithmetic == COLNDE_MATRIX_BF16X3_EXACT ? "bf16x3_exact" : "f32_mfma",
+             (info[7] & 2) ? "bf16x3" : "f32", (info[7] & 4) ? "bf16x3" : "f32", (info[7] & 8) ? "bf16x3" : "f32");
+    s += t;
+    if (info[1]) { snprintf(t, sizeof t, " block=%dx%d", info[1], info[2]); s += t; } else s += " block=(not planned yet)";
+    if (info[0] == COLNDE_ENGINE_MFMA) { snprintf(t, sizeof t, " z1_tape=%d", info[3]); s += t; }
+    if (info[0] == COLNDE_ENGINE_FC32) { snprintf(t, sizeof t, " time_segments=%d tile_width=%d dw_slices=%d", info[3], h->fc_cw, info[5]); s += t; }
+    if (info[0] == COLNDE_ENGINE_GENERIC) {
+        snprintf(t, sizeof t, " dw_taped=%d dw_slices=%d net_split_forward=%d net_split_adjoint=%d rich_tape=%d", info[4], info[5], info[6] & 1, (info[6] >> 1) & 1, (info[6] >> 2) & 1);
+        s += t;
+    }
+    snprintf(t, sizeof t, " gradient=%s", (info[7] & 1) ? "one-switch-pattern RKC2 pullback (approximate)" : "exact discrete adjoint");
+    s += t;
+    s += " | env";
+    bool any = false;
+    for (const char* name : COLNDE_ENV_SWITCHES) {
+        const char* e = getenv(name);
+        if (e && *e) { s += " "; s += name; s += "="; s += e; any = true; }
+    }
+    if (!any) s += " (none set)";
+    const int need = (int)s.size() + 1;
+    if (buf && capacity > 0) {
+        const int n = need <= capacity ? need - 1 : capacity - 1;
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return need;
+}
+
 // Diagnostic builds (-DCOLNDE_STAMPS) only; not part of include/colnde.h.  Returns zeros in the shipped library.
 extern "C" int colnde_debug_stamps(colnde_handle* h, unsigned long long* out16) {
     if (!h || !out16) return fail("null argument");

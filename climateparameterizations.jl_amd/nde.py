@@ -129,6 +129,15 @@ class ColumnNDE:
                     bf16x3_forward=bool(info[7] & 2), bf16x3_adjoint=bool(info[7] & 4), bf16x3_dw=bool(info[7] & 8),
                     matrix_arithmetic=self.matrix_arithmetic)
 
+    def describe(self) -> str:
+        """`colnde_describe`: the plan spelled out, plus every COLNDE_* tuning switch set in this process that the library reads."""
+        need = self._L.colnde_describe(self._h, None, 0)
+        if need < 0:
+            _lib.check(1)
+        buf = ctypes.create_string_buffer(need)
+        self._L.colnde_describe(self._h, buf, need)
+        return buf.value.decode()
+
     def pretrain_flux(self, flux_type: int, theta, m, v, profiles, bcs, fluxes, order, gradient_scaling: float, opt, update: bool = True):
         """`colnde_pretrain_flux_dev`: one `Flux.train!` pass (one ADAM update per sample, in `order`) over device tensors; `opt` is a
         flux_compat.ADAM whose running powers are advanced.  Returns the mean per-sample loss (update=False: at fixed weights)."""

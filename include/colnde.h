@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define COLNDE_VERSION 104
+#define COLNDE_VERSION 105
 #define COLNDE_MAX_LAYERS 8
 
 enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_training.jl:56-165 */
@@ -307,6 +307,13 @@ int  colnde_allreduce_result_dev(colnde_handle* h, colnde_comm* comm, float* d_o
  * bits 1, 2, 3 = the forward-solve / adjoint / weight-gradient kernels of the handle's engine run BF16X3_EXACT (a cleared bit: F32_MFMA — the
  * configured arithmetic, a test override, or no split kernel for this engine and shape). */
 int colnde_plan(const colnde_handle* h, int info[8]);
+
+/* The same, spelled out, plus every tuning switch the library honours: one text line
+ *   "engine=regtile stepper=rk4 substeps=2 matrix_arithmetic=bf16x3_exact forward=bf16x3 adjoint=bf16x3 dw=bf16x3 block=32768x1 ... | env COLNDE_RT_BLOCK=8192 ..."
+ * The part after "| env" lists each COLNDE_* environment variable that is SET in this process and that the library reads (INTEGRATION.md has the
+ * table): they are tuning and test aids, read when the handle is created or when it plans its tapes, never per call — and this is where a caller sees
+ * that one of them shaped the handle.  buf may be NULL; returns the number of bytes the full line needs (including the terminating 0), or -1. */
+int colnde_describe(const colnde_handle* h, char* buf, int capacity);
 
 /* ---- measurement: HIP-event timing of the handle's kernels on its stream.
  * which: 0 = forward solve kernel, 1 = adjoint kernel, 2 = gradient reduce, 3 = rhs, 4 = inference,

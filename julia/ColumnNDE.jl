@@ -265,6 +265,15 @@ function plan(h::Handle)
      approximate_gradient=(info[8] & 1) != 0, bf16x3_forward=(info[8] & 2) != 0, bf16x3_adjoint=(info[8] & 4) != 0, bf16x3_dw=(info[8] & 8) != 0)
 end
 
+"""The plan spelled out, plus every COLNDE_* tuning switch set in this process that the library reads — colnde_describe."""
+function describe(h::Handle)
+    need = ccall((:colnde_describe, libcolnde), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), h.ptr, C_NULL, 0)
+    need > 0 || error(unsafe_string(ccall((:colnde_last_error, libcolnde), Cstring, ())))
+    buf = Vector{UInt8}(undef, need)
+    ccall((:colnde_describe, libcolnde), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), h.ptr, buf, need)
+    return unsafe_string(pointer(buf))
+end
+
 "The reference's closures at the reference's ARITIES, closed over a handle: what `ODEProblem`, `OptimizationFunction` and `Flux.train!` are handed
 today.  `NDE(x, p, t)` (NDE_training.jl:56), `NDE!(dx, x, p, t)` (training_postprocessing.jl:131; create that handle with inplace_variant = 1),
 `loss_NDE(weights, BCs)` / `loss_gradient_NDE(weights, BCs)` (NDE_training.jl:290-323; BCs were given to set_problem! and are ignored here, as the

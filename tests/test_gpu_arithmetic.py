@@ -5,6 +5,8 @@ operands near FLT_MIN, where the low planes fall into or below the subnormal ran
 
 Reference semantics being preserved: the Float32 `Dense` products of `predict_flux` (wind_mixing/src/NDE_training.jl:94-96) and of the
 free-convection networks (free_convection/src/free_convection_nde.jl:33)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,6 +102,42 @@ def test_config_field_is_validated_and_switchable():
         assert nde.matrix_arithmetic == "f32_mfma" and not nde.plan()["bf16x3_forward"]
         with pytest.raises(colnde.ColndeError, match="matrix_arithmetic"):
             _lib.check(nde._L.colnde_set_matrix_arithmetic(nde._h, 5))
+
+
+def test_describe_spells_out_the_plan_and_lists_the_environment_switches_in_force(monkeypatch):
+    """colnde_describe: the tuning switches are environment variables read at creation / planning — this is where a caller of the ABI sees them."""
+    p = synthetic.wind_mixing_problem(40, n_frames=3)
+    for k in list(os.environ):
+        if k.startswith("COLNDE_"):
+            monkeypatch.delenv(k)
+    with colnde.ColumnNDE(p.cfg, 40, engine=ENGINE_REGTILE) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        nde.set_problem(p.x0, p.bcs, nde.forward(p.weights_truth))
+        nde.loss_grad(p.weights, [1, 1, 1, 0, 0, 0])
+        d = nde.describe()
+        assert "engine=regtile" in d and "matrix_arithmetic=bf16x3_exact" in d and "adjoint=bf16x3" in d and "z1_tape=1" in d and "block=" in d
+        assert d.endswith("| env (none set)") and "exact discrete adjoint" in d
+        # the truncating form: capacity smaller than the line
+        import ctypes
+        buf = ctypes.create_string_buffer(16)
+        need = nde._L.colnde_describe(nde._h, buf, 16)
+        assert need == len(d) + 1 and buf.value.decode() == d[:15]
+    monkeypatch.setenv("COLNDE_RT_ZTAPE", "0")
+    monkeypatch.setenv("COLNDE_ADJ_SPLIT", "0")
+    with colnde.ColumnNDE(p.cfg, 40, engine=ENGINE_REGTILE) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        nde.set_problem(p.x0, p.bcs, nde.forward(p.weights_truth))
+        nde.loss_grad(p.weights, [1, 1, 1, 0, 0, 0])
+        d = nde.describe()
+        assert "z1_tape=0" in d and "adjoint=f32" in d and "forward=bf16x3" in d
+        assert "COLNDE_RT_ZTAPE=0" in d.split("| env")[1] and "COLNDE_ADJ_SPLIT=0" in d.split("| env")[1]
+    p = synthetic.free_convection_problem(33, Nz=32, n_save=3, convective_adjustment=True)
+    with colnde.ColumnNDE(p.cfg.with_(stepper="rkc2", substeps=1), 33) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        nde.set_problem(p.x0, p.bcs, nde.forward(p.weights_truth))
+        nde.loss_grad(p.weights, [0, 0, 1, 0, 0, 0])
+        d = nde.describe()
+        assert "engine=fc32" in d and "stepper=rkc2" in d and "rkc_stages=" in d and "approximate" in d and "tile_width=" in d
 
 
 @pytest.mark.parametrize("engine", [ENGINE_REGTILE, 0])

@@ -19,6 +19,7 @@ for c in range(cases):
     frames = int(rng.choice([2, 3, 5, 9, 17]))
     sub = int(rng.choice([1, 2, 3, 5]))
     rich = str(int(rng.integers(2)))
+    arith = str(rng.choice(["bf16x3_exact", "bf16x3_exact", "f32_mfma"]))        # of the two engines under test (tile16, the reference here, runs f32 MFMA)
     p = synthetic.wind_mixing_problem(ncol, n_frames=frames, weight_divisor=1e2, **VARIANTS[name])      # (weights/1e3 and smaller: the loss sinks into float32 round-off of the trajectories and relative errors mean nothing)
     cfg = p.cfg.with_(substeps=max(sub, p.cfg.substeps if "conv_adj" in name else sub))
     sc = np.concatenate([rng.uniform(0.5, 1.5, 3), rng.uniform(0, 1e-2, 3) * (rng.integers(2))])
@@ -27,7 +28,7 @@ for c in range(cases):
     for label, eng in (("tile16", 1), ("auto", 0), ("regtile", 2)):
         os.environ["COLNDE_T16_SPLIT_RICH"] = rich
         try:
-            with colnde.ColumnNDE(cfg, ncol, engine=eng) as nde:
+            with colnde.ColumnNDE(cfg, ncol, engine=eng, matrix_arithmetic="f32_mfma" if label == "tile16" else arith) as nde:
                 nde.set_problem(p.x0, p.bcs)
                 if truth is None:
                     truth = nde.forward(p.weights_truth)          # one truth for all three engines
@@ -41,7 +42,7 @@ for c in range(cases):
     if res["auto"] is None or res["tile16"] is None:
         print("case %d %s ncol %d frames %d sub %d: refused (%s)" % (c, name, ncol, frames, sub, msg)); continue
     ref = res["tile16"]
-    line = "case %2d %-16s ncol %3d frames %2d sub %d rich %s split %s loss %.1e:" % (c, name, ncol, frames, cfg.substeps, rich, res["auto"][3]["split_adjoint"], ref[1])
+    line = "case %2d %-16s ncol %3d frames %2d sub %d rich %s split %s %s loss %.1e:" % (c, name, ncol, frames, cfg.substeps, rich, res["auto"][3]["split_adjoint"], arith, ref[1])
     for label in ("auto", "regtile"):
         r = res[label]
         if r is None: continue
