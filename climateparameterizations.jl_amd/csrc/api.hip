@@ -1374,9 +1374,10 @@ static int choose_substeps_impl(colnde_handle* h, const float* d_weights, float 
         est = e * richardson_factor(h);
         if (!(est == est) || est > 3.0e38f) { rc = fail("the solve is not finite at %d sub-steps per save interval: no sub-step count can be chosen", S); break; }
         if (est <= reltol || S >= 4096) break;
-        // halving a fourth-order step divides the error by ~16 (second order: 4); an estimate that no longer falls by even a factor 2 is float32
-        // round-off of the two solves it compares (more steps only add to it): the tolerance is below what this arithmetic resolves
-        if (prev > 0.0f && est > 0.5f * prev) { floor_hit = true; break; }
+        // halving a fourth-order step divides the error by ~16 (second order: 4; a switch in the right-hand side — ConvectiveAdjustmentNDE — makes it ~2);
+        // an estimate that falls by less than a fifth is float32 round-off of the two solves it compares (more steps only add to it): the tolerance is
+        // below what this arithmetic resolves
+        if (prev > 0.0f && est > 0.8f * prev) { floor_hit = true; break; }
         prev = est;
         S *= 2;                      // the solution at 2S is already there: it is the next candidate's own
         cur ^= 1;

@@ -156,6 +156,39 @@ def test_choose_substeps_and_the_automatic_mode():
         synthetic.wind_mixing_problem(4, n_frames=3).cfg.with_(reltol=2.0).validate()
 
 
+def test_error_estimate_and_choice_for_the_free_convection_models():
+    """The same boundary for `solve_nde` (free_convection/src/solve.jl:4, reltol = 1e-4).  ConvectiveAdjustmentNDE under the stabilised RKC2 stepper (second order:
+    Richardson factor 4/3; the switch makes the error large and its convergence first-order — 0.32 at 4 steps per save interval, 0.12 at 8, 0.05 at 16 on
+    these 40 columns): the estimate agrees with the float64 oracle's within 2x, and a tolerance of 0.2 chooses what the oracle's estimates choose.  FreeConvectionNDE under RK4 is smooth: its error at ONE sub-step (3e-7) is far below
+    the reference's tolerance, and the choice is the stability bound itself."""
+    p = synthetic.free_convection_problem(40, Nz=32, n_save=5, convective_adjustment=True)
+    est64 = {}
+    for S in (1, 2, 4, 8, 16):
+        cfg = p.cfg.with_(stepper="rkc2", substeps=S)
+        est64[S] = O.error_estimate(cfg, p.x0, p.bcs, p.weights)
+        if S in (4, 8):
+            with colnde.ColumnNDE(cfg, 40) as nde:
+                nde.set_problem(p.x0, p.bcs)
+                est = nde.error_estimate(p.weights)
+            _record("error_estimate/rkc2/%d" % S, estimate=est, oracle_estimate=est64[S])
+            assert 0.5 * est64[S] < est < 2.0 * est64[S], (S, est, est64[S])
+    want = min(S for S, e in est64.items() if e <= 0.2)
+    assert want > 1 and not any(0.16 < e < 0.25 for e in est64.values())
+    with colnde.ColumnNDE(p.cfg.with_(stepper="rkc2", substeps=1), 40) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        S, est = nde.choose_substeps(p.weights, 0.2)
+        assert S == want == nde.substeps and est <= 0.2
+    p = synthetic.free_convection_problem(40, Nz=32, n_save=5)
+    need = colnde.min_substeps(p.cfg)
+    with colnde.ColumnNDE(p.cfg.with_(substeps=max(need, 1)), 40) as nde:
+        nde.set_problem(p.x0, p.bcs)
+        S, est = nde.choose_substeps(p.weights, 1e-4)
+        pow2 = 1
+        while pow2 < need:
+            pow2 *= 2
+        assert S == pow2 and est < 1e-5                                   # (float32 round-off of the two solves, not discretisation error)
+
+
 def test_error_estimate_reports_a_non_finite_solve_as_infinite():
     p = synthetic.wind_mixing_problem(9, n_frames=5, weight_divisor=1e2)
     x0 = p.x0.copy()

@@ -4,7 +4,7 @@ import collections, re, sys, textwrap, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
 path = args[0] if len(args) > 0 else os.path.join(ROOT, "climateparameterizations.jl_amd/csrc/_build/engine_regtile.s")
-name = args[1] if len(args) > 1 else "_Z17rt_adjoint_kernelILi2ELb1EEv"
+name = args[1] if len(args) > 1 else "_Z17rt_adjoint_kernelILi2ELb1ELb1EEv"
 s = open(path).read()
 start = s.index(name); start = s.index(":", start)
 end = s.index(".Lfunc_end", start)
