@@ -444,11 +444,15 @@ def free_convection_workload(args, world, rank, local_rank, dev, comm, dist):
     barrier()
     nde.set_profiling(True)
     nde.reset_kernel_times()
+    sensors = GpuSensors(dev).start() if rank == 0 else None     # (a host thread reading two sysfs nodes every 20 ms: nothing on the GPU)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     te = torch.tensor([time.perf_counter() - t0], dtype=torch.float32, device=dev)
+    clock = sensors.stop() if sensors is not None else None
+    if clock:
+        clock["sampled_over"] = "the timed K steps"
     reduce_(te, "max")
     torch.cuda.synchronize()
     elapsed = float(te.item())
@@ -489,6 +493,8 @@ def free_convection_workload(args, world, rank, local_rank, dev, comm, dist):
             "roofline": {"kernel": names[dom], "bound": "mfma",
                          "achieved": dom_tf, "peak": (dom_tf / dom_frac) if dom_frac else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_frac, "traffic": None,
                          "frac_is": "matrix-pipe time fraction of the executed MFMA instruction mix", "avg_launch_ms": km[dom], "kernel_ms": km,
+                         # the step runs power-limited: the peaks behind `frac` assume 2,400 MHz
+                         "clock": clock, "frac_at_measured_clock": (dom_frac * 2400.0 / clock["shader_clock_MHz_mean"]) if (clock and dom_frac) else None,
                          "kernels": {k: {"kernel": names[k], "on_bf16_pipe": bool(on_bf16[k]), "avg_launch_ms": km[k], "matrix_pipe_time_frac": pipe_frac(k)}
                                      for k in ("forward", "adjoint", "dw1")},
                          "whole_step": {"algorithmic_flop_per_column_timestep": flop, "achieved": per_gpu_tf, "unit": "TFLOP/s per GPU",
