@@ -453,6 +453,8 @@ def free_convection_workload(args, world, rank, local_rank, dev, comm, dist):
     clock = sensors.stop() if sensors is not None else None
     if clock:
         clock["sampled_over"] = "the timed K steps"
+        if clock.get("board_power_W_mean"):
+            clock["energy_J_per_step"] = clock["board_power_W_mean"] * float(te.item()) / args.steps
     reduce_(te, "max")
     torch.cuda.synchronize()
     elapsed = float(te.item())
@@ -788,6 +790,8 @@ def main():
     barrier()
     elapsed_plain = max_over_ranks(time.perf_counter() - t0)
     clock = sensors.stop() if sensors is not None else None
+    if clock and clock.get("board_power_W_mean"):
+        clock["energy_J_per_step"] = clock["board_power_W_mean"] * elapsed_plain / args.steps       # what a power-limited board makes the figure of merit
     res = out.cpu().numpy()
     per_rank_ms = allreduce_ms = None
     if comm is not None or dist is not None:
@@ -933,6 +937,8 @@ def main():
                 torch.cuda.synchronize()
                 t_f32 = (time.perf_counter() - t0) / 3
                 clock32 = sens32.stop()
+                if clock32 and clock32.get("board_power_W_mean"):
+                    clock32["energy_J_per_step"] = clock32["board_power_W_mean"] * t_f32
                 km = {k: nde.kernel_time(k)[0] / max(nde.kernel_time(k)[1], 1) for k in ("forward", "adjoint", "dw1")}
                 g32 = out[:nde.n_params]
                 third = nde.n_params // 3
