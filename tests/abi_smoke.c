@@ -84,6 +84,39 @@ int main(int argc, char** argv) {
     for (int q = 0; q < 6; q++) tsum += terms[q];
     const double egrad = sqrt(num / den), etot = fabs((double)total - total_ref[0]) / total_ref[0];
 
+    /* round-4 entry points, from plain C: loss_per_tstep averages to loss_NDE's terms (NDE_training.jl:308-317); predict_flux's faces difference to the
+     * tendencies of colnde_rhs for T (dT/dt = -(tau/H)(sigma_wT/sigma_T) Dc wT, NDE_training.jl:162); the Richardson estimate is finite and small; the handle describes itself */
+    double eterms = 0.0, eflux = 0.0;
+    float est = -1.0f;
+    char desc[1024];
+    {
+        float* lpt = (float*)malloc(sizeof(float) * NCOL * 6 * NSAVE);
+        CHECK(colnde_loss_per_tstep(h, w, lpt));
+        for (int q = 0; q < 6; q++) {
+            double m = 0.0;
+            for (int col = 0; col < NCOL; col++)
+                for (int s = 0; s < NSAVE; s++) m += lpt[((size_t)col * 6 + q) * NSAVE + s];
+            m = m / (NCOL * NSAVE) * scal[q];
+            if (terms[q] != 0.0f) eterms = fmax(eterms, fabs(m - terms[q]) / fabs(terms[q]));
+        }
+        float* flux = (float*)malloc(sizeof(float) * NCOL * 3 * (NZ + 1));
+        float* dx = (float*)malloc(sizeof(float) * NCOL * NS);
+        CHECK(colnde_flux(h, x0, w, bcs, 0.0f, flux, NCOL));
+        CHECK(colnde_rhs(h, x0, w, bcs, 0.0f, dx, NCOL));
+        const double cT = (double)c.tau / c.H * c.sigma[5] / c.sigma[2];
+        for (int col = 0; col < NCOL; col++)
+            for (int k = 0; k < NZ; k++) {
+                const float* wT = flux + ((size_t)col * 3 + 2) * (NZ + 1);
+                const double want = -cT * ((double)wT[k + 1] - wT[k]) * NZ, got = dx[(size_t)col * NS + 2 * NZ + k];
+                eflux = fmax(eflux, fabs(want - got) / (1e-3 + fabs(got)));
+            }
+        CHECK(colnde_error_estimate(h, w, &est));
+        if (colnde_describe(h, desc, (int)sizeof desc) <= 0) { fprintf(stderr, "colnde_describe failed: %s\n", colnde_last_error()); return 1; }
+        free(lpt); free(flux); free(dx);
+    }
+    printf("abi_smoke: loss_per_tstep vs terms %.2e, Dc(flux) vs rhs %.2e, error estimate %.2e, substeps %d\n  %s\n", eterms, eflux, est, colnde_substeps(h), desc);
+    if (!(eterms < 5e-4) || !(eflux < 1e-4) || !(est > 0.0f && est < 1e-2f) || strstr(desc, "engine=") == NULL) return 1;
+
     /* a config the library must refuse, with a message */
     colnde_config bad = c;
     bad.layer_sizes[3] = 30;
