@@ -1,0 +1,95 @@
+"""Handle life cycle: every device allocation a handle makes (weight images, tapes, slabs, the scratch of colnde_error_estimate /
+colnde_choose_substeps, the split-arithmetic images) is returned by colnde_destroy, and a refused colnde_create or a failed call leaves
+nothing behind.  One handle = one GPU = one host thread (include/colnde.h); a training script creates and destroys handles per stage of the
+reference's schedule (train_NDE's epochs x optimisers, NDE_training.jl:335-372), so a leak here is a crash after a few hours there."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import colnde
+from colnde import _lib, synthetic
+from colnde.config import to_c_config
+from colnde.nde import ENGINE_REGTILE, ENGINE_TILE16
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info(0)[0]
+
+
+def _cases():
+    wm = synthetic.wind_mixing_problem(70, n_frames=5, weight_divisor=1e2)
+    fc = synthetic.free_convection_problem(70, Nz=32, n_save=9)
+    ca = synthetic.free_convection_problem(40, Nz=64, n_save=5, convective_adjustment=True)
+    return [
+        ("regtile", wm, wm.cfg, dict(engine=ENGINE_REGTILE), [1, 1, 1, 5e-3, 5e-3, 5e-3], {}),
+        ("net-split (AUTO)", wm, wm.cfg, dict(), [1, 1, 1, 5e-3, 5e-3, 5e-3], {}),
+        ("tile16, f32 MFMA", wm, wm.cfg, dict(engine=ENGINE_TILE16, matrix_arithmetic="f32_mfma"), [1, 1, 1, 0, 0, 0], {}),
+        ("fc32, time segments + column blocks", fc, fc.cfg, dict(), [0, 0, 1, 0, 0, 0], {"COLNDE_FC_SEG": "3", "COLNDE_FC_BLOCK": "32"}),
+        ("fc32 64 levels, RKC2", ca, ca.cfg.with_(stepper="rkc2", substeps=2), dict(), [0, 0, 1, 0, 0, 0], {}),
+    ]
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_create_use_destroy_returns_all_device_memory(case, monkeypatch):
+    name, p, cfg, kw, sc, env = _cases()[case]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = p.x0.shape[0]
+
+    def cycle():
+        with colnde.ColumnNDE(cfg, n, **kw) as nde:
+            nde.set_problem(p.x0, p.bcs)
+            truth = nde.forward(p.weights_truth)
+            nde.set_problem(p.x0, p.bcs, truth)
+            nde.error_estimate(p.weights)
+            if cfg.stepper != "rkc2":
+                nde.choose_substeps(p.weights, 0.5)                      # (before the tapes are planned)
+            tot, terms, grad = nde.loss_grad(p.weights, sc)
+            nde.set_matrix_arithmetic("f32_mfma" if nde.matrix_arithmetic == "bf16x3_exact" else "bf16x3_exact")
+            tot2, _, grad2 = nde.loss_grad(p.weights, sc)
+            nde.loss_per_tstep(p.weights)
+            assert np.isfinite(tot) and np.isfinite(grad).all() and abs(tot2 - tot) <= 1e-4 * abs(tot)
+            return nde.describe()
+
+    cycle()                                                              # (first use: the runtime's own pools, code objects)
+    before = _free_bytes()
+    for _ in range(24):
+        d = cycle()
+    after = _free_bytes()
+    assert before - after <= (8 << 20), (name, before - after, d)          # (free memory may GROW: the runtime returns pool blocks of the first cycle)
+
+
+def test_refused_create_and_failed_calls_leave_nothing_behind():
+    p = synthetic.wind_mixing_problem(33, n_frames=3)
+    L = _lib.lib()
+    c, keep = to_c_config(p.cfg, 33)
+    c.layer_sizes[3] = 30                                                # refused by validation
+    h = ctypes.c_void_p()
+    L.colnde_create(ctypes.byref(c), ctypes.byref(h))                    # (warm-up of the error path)
+    before = _free_bytes()
+    for _ in range(20):
+        h = ctypes.c_void_p()
+        assert L.colnde_create(ctypes.byref(c), ctypes.byref(h)) != 0 and not h.value
+    # an engine that does not cover the configuration: refused after the device was selected
+    from colnde.nde import ENGINE_FC32
+    for _ in range(5):
+        with pytest.raises(colnde.ColndeError):
+            colnde.ColumnNDE(p.cfg, 33, engine=ENGINE_FC32)
+    # calls that fail on a live handle: no problem set, a time step outside the stability region
+    with colnde.ColumnNDE(p.cfg, 33) as nde:
+        for _ in range(5):
+            with pytest.raises(colnde.ColndeError):
+                nde.loss_grad(p.weights, [1, 1, 1, 0, 0, 0])
+            with pytest.raises(colnde.ColndeError):
+                nde.error_estimate(p.weights)
+    with pytest.raises(colnde.ColndeError):
+        with colnde.ColumnNDE(p.cfg.with_(substeps=1), 33) as nde:
+            nde.set_problem(p.x0, p.bcs)
+            nde.forward(p.weights)
+    after = _free_bytes()
+    assert before - after <= (8 << 20), before - after
