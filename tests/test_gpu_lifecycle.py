@@ -93,3 +93,46 @@ def test_refused_create_and_failed_calls_leave_nothing_behind():
             nde.forward(p.weights)
     after = _free_bytes()
     assert before - after <= (8 << 20), before - after
+
+
+def test_two_handles_in_two_host_threads_do_not_disturb_each_other():
+    """include/colnde.h: one handle = one host thread AT A TIME; two handles may be driven by two threads at once (ctypes releases the GIL
+    for the call).  Their results are bit-identical to the serial ones and colnde_last_error stays per thread."""
+    import threading
+    wm = synthetic.wind_mixing_problem(40, n_frames=5, weight_divisor=1e2)
+    fc = synthetic.free_convection_problem(40, Nz=32, n_save=5)
+    jobs = [(wm, dict(engine=ENGINE_REGTILE), [1, 1, 1, 5e-3, 5e-3, 5e-3]), (fc, dict(), [0, 0, 1, 0, 0, 0]), (wm, dict(), [1, 1, 1, 0, 0, 0])]
+
+    def prepare(p, kw):
+        nde = colnde.ColumnNDE(p.cfg, 40, **kw)
+        nde.set_problem(p.x0, p.bcs)
+        nde.set_problem(p.x0, p.bcs, nde.forward(p.weights_truth))
+        return nde
+
+    handles = [prepare(p, kw) for p, kw, _ in jobs]
+    try:
+        serial = [h.loss_grad(p.weights, sc) for h, (p, _, sc) in zip(handles, jobs)]
+        results, errors = [None] * len(jobs), [None] * len(jobs)
+
+        def work(i):
+            h, (p, _, sc) = handles[i], jobs[i]
+            try:
+                for _ in range(12):
+                    r = h.loss_grad(p.weights, sc)
+                    with pytest.raises(colnde.ColndeError, match="matrix_arithmetic"):          # an error of THIS thread, with its own message
+                        _lib.check(h._L.colnde_set_matrix_arithmetic(h._h, 9))
+                results[i] = r
+            except BaseException as e:                                                          # noqa: BLE001 (reported below, in the main thread)
+                errors[i] = e
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert errors == [None] * len(jobs), errors
+        for (t0, terms0, g0), (t1, terms1, g1) in zip(serial, results):
+            assert t0 == t1 and np.array_equal(g0, g1) and np.array_equal(terms0, terms1)
+    finally:
+        for h in handles:
+            h.close()
