@@ -113,7 +113,8 @@ class GpuSensors:
         if not fs:
             return None
         return {"shader_clock_MHz_mean": sum(fs) / len(fs), "shader_clock_MHz_min": min(fs), "shader_clock_MHz_max": max(fs),
-                "board_power_W_mean": (sum(ps) / len(ps)) if ps else None, "samples": len(fs), "peak_clock_MHz_the_rooflines_assume": 2400,
+                "board_power_W_mean": (sum(ps) / len(ps)) if ps else None, "board_power_cap_W": (self._read("power1_cap") or 0) / 1e6 or None,
+                "samples": len(fs), "peak_clock_MHz_the_rooflines_assume": 2400,
                 "source": self.dir, "sampled_over": "the second (untimed-for-value) pass of the same K steps"}
 
 
