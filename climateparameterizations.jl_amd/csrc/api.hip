@@ -1742,7 +1742,7 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
         bf_adj = h->sp_adj && fc_split_supported(h->fc_cw);
         bf_dw = h->sp_dw && (h->d_dwtape ? !h->dw_split.passes.empty() : true);
     } else {
-        bf_fwd = h->sp_fwd && h->fwd_split && h->fwd_helper && h->cfg.stepper == COLNDE_STEPPER_RK4;
+        bf_fwd = h->sp_fwd && h->fwd_split && h->fwd_helper;
         bf_adj = h->sp_adj && h->adj_split && rt_adjoint_split_has_bf16(h->m, h->adj_helper) && (h->t16_dwtape < 0 || (h->t16_dwtape == 1 && h->d_t16_ztape));
         bf_dw = h->sp_dw && h->t16_dwtape == 1 && !h->dw_split.passes.empty();
     }
@@ -1784,7 +1784,7 @@ extern "C" int colnde_describe(const colnde_handle* h, char* buf, int capacity) 
     snprintf(t, sizeof t, "engine=%s columns=%d stepper=%s substeps=%d%s", eng, h->cfg.n_columns, h->cfg.stepper == COLNDE_STEPPER_RKC2 ? "rkc2" : "rk4",
              h->cfg.substeps, h->auto_substeps ? "(chosen from reltol)" : "");
     s += t;
-    if (h->cfg.stepper == COLNDE_STEPPER_RKC2) { snprintf(t, sizeof t, " rkc_stages=%d", h->cfg.rkc_stages); s += t; }
+    if (h->cfg.stepper == COLNDE_STEPPER_RKC2) { snprintf(t, sizeof t, " rkc_stages=%d%s", h->m.nst, h->cfg.rkc_stages ? "" : "(automatic)"); s += t; }
     snprintf(t, sizeof t, " matrix_arithmetic=%s forward=%s adjoint=%s dw=%s", h->cfg.matrix_arithmetic == COLNDE_MATRIX_BF16X3_EXACT ? "bf16x3_exact" : "f32_mfma",
              (info[7] & 2) ? "bf16x3" : "f32", (info[7] & 4) ? "bf16x3" : "f32", (info[7] & 8) ? "bf16x3" : "f32");
     s += t;

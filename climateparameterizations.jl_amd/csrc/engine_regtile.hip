@@ -2264,7 +2264,7 @@ rt16s_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __
 // The same solve with a FOURTH wavefront (the workgroup's idle SIMD) as helper: it evaluates the Richardson-number closure of all three variables
 // once per stage — the diffusive face fluxes go to LDS, the rich tape's nine pullback coefficients to HBM — while the three net waves run their
 // chains; a second bare barrier per stage (B) hands the fluxes over.  Every wave executes exactly the barriers (B) and (A) in every stage.
-// SPLIT (COLNDE_MATRIX_BF16X3_EXACT, RK4 only): layers 1 and 2 on v_mfma_f32_16x16x32_bf16 from exact three-way operand splits (rt16_forward_kernel<ACT, true>;
+// SPLIT (COLNDE_MATRIX_BF16X3_EXACT; RK4 and, since round 4, RKC2): layers 1 and 2 on v_mfma_f32_16x16x32_bf16 from exact three-way operand splits (rt16_forward_kernel<ACT, true>;
 // image RT_SIMG2_*: rt_pack_split_ns_kernel); layer 3 and the biases stay on the tail of the fp32 image
 template <int ACT, bool RICH, bool RKC = false, bool SPLIT = false>
 __global__ void __launch_bounds__(256)
@@ -3156,7 +3156,6 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                       const float* __restrict__ sol, const float* __restrict__ truth, const float* __restrict__ t16_tape,
                       const float* __restrict__ t16_ztape, LossWeights lw, float* __restrict__ slab, int n_col,
                       float* __restrict__ dwtape) {
-    static_assert(!(SPLIT && RKC), "the split net-split adjoint is built for RK4");
     // SPLIT: LDS holds the fp32 image from W2 on (addressed through wl as before: wl[RT_W2C + x]), no fp32 W1
     constexpr int IMG0 = SPLIT ? RT_W2C : 0;
     constexpr int IMGF = ((RT_IMG_FLOATS - IMG0) + 3) & ~3;
@@ -3631,6 +3630,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, false, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, false, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_IDENTITY, true, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false>));
@@ -3639,6 +3640,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, false, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_RELU, true, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false>));
@@ -3647,6 +3650,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, false, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_MISH, true, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false>));
@@ -3655,6 +3660,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, false, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_SWISH, true, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false>));
@@ -3663,6 +3670,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, false, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_TANH, true, true, true>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16s_forward_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false>));
@@ -3671,6 +3680,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false, false, true>));
     RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true, false, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, false, true, true>));
+    RT_SETATTR((rt16sh_forward_kernel<COLNDE_ACT_LEAKYRELU, true, true, true>));
     RT_SETATTR(rt_dw1_kernel);
     RT_SETATTR(rt_dw1_split_kernel);
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
@@ -3681,6 +3692,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, false, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, false, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_IDENTITY, true, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_RELU, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false>));
@@ -3689,6 +3702,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, false, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_RELU, true, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_MISH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -3697,6 +3712,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, false, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_MISH, true, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_SWISH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false>));
@@ -3705,6 +3722,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, false, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_SWISH, true, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_TANH, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false>));
@@ -3713,6 +3732,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, false, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_TANH, true, true, true>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
     RT_SETATTR((rt16s_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false>));
@@ -3721,6 +3742,8 @@ hipError_t rt_set_attributes() {
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false, false, true>));
     RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true, false, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, false, true, true>));
+    RT_SETATTR((rt16sh_adjoint_kernel<COLNDE_ACT_LEAKYRELU, true, true, true>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_IDENTITY, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_RELU, false>));
     RT_SETATTR((rt_adjoint_kernel<COLNDE_ACT_MISH, false>));
@@ -3806,13 +3829,15 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
     const size_t ldsh = lds + 384 * 16;
     const dim3 blockh(256);
     if (m.nst != 4 && !(m.rkc && use_helper)) return hipErrorInvalidValue;      // RKC2 lives in the four-wave kernels only
-    // layers 1 and 2 on the bf16 pipe with exact three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT; four-wave RK4 kernels only)
-    const bool split = want_split && use_helper && !m.rkc;
+    // layers 1 and 2 on the bf16 pipe with exact three-way operand splitting (COLNDE_MATRIX_BF16X3_EXACT; the four-wave kernels, RK4 and RKC2)
+    const bool split = want_split && use_helper;
     const size_t ldss = ((size_t)RT_SIMG2_WORDS + ((RT_IMG_FLOATS - RT_W3C + 3) & ~3)) * sizeof(float) + 3 * 384 * 16;
     if (split) hipLaunchKernelGGL(rt_pack_split_ns_kernel, dim3(41), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_SIMG2_OFF);
 #define RT_FWDS(A)                                                                                                                              \
     do {                                                                                                                                        \
-        if (split && rich) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true, false, true>), grid, blockh, ldss, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        if (split && rich && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true, true, true>), grid, blockh, ldss, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else if (split && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false, true, true>), grid, blockh, ldss, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
+        else if (split && rich) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true, false, true>), grid, blockh, ldss, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else if (split) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false, false, true>), grid, blockh, ldss, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else if (use_helper && rich && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, true, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
         else if (use_helper && m.rkc) hipLaunchKernelGGL((rt16sh_forward_kernel<A, false, true>), grid, blockh, ldsh, stream, m, wimg, x0, bcs, save_times, n_save, substeps, sol, t16_tape, t16_ztape, n_col); \
@@ -3834,7 +3859,7 @@ hipError_t rt_launch_forward_split(const DevModel& m, const float* wimg, const f
     return hipGetLastError();
 }
 
-bool rt_adjoint_split_has_bf16(const DevModel& m, bool use_helper) { return use_helper && !m.rkc && m.nst == 4; }
+bool rt_adjoint_split_has_bf16(const DevModel& m, bool use_helper) { return use_helper && (m.rkc || m.nst == 4); }
 
 hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const float* save_times, int n_save, int substeps, const float* sol,
                                    const float* truth, const float* t16_tape, const float* t16_ztape, const LossWeights& lw, float* slab,
@@ -3846,14 +3871,16 @@ hipError_t rt_launch_adjoint_split(const DevModel& m, const float* wimg, const f
     const dim3 grid((n_col + 15) / 16), block(192);
     const size_t ldsh = (((size_t)RT_IMG_FLOATS + 3) & ~(size_t)3) * sizeof(float) + (3 * 6 * 64 + 3 * 2 * 64) * 16 + 3 * RT16S_STG * sizeof(float);
     const dim3 blockh(256);
-    // COLNDE_MATRIX_BF16X3_EXACT: the W1^T products on the bf16 pipe (four-wave RK4 kernels); LDS: the fp32 image from W2 on, exchange, staging, the h / m planes
+    // COLNDE_MATRIX_BF16X3_EXACT: the W1^T products on the bf16 pipe (four-wave kernels, RK4 and RKC2); LDS: the fp32 image from W2 on, exchange, staging, the h / m planes
     const bool split = want_split && rt_adjoint_split_has_bf16(m, use_helper);
     const size_t ldss = ((((size_t)RT_IMG_FLOATS - RT_W2C) + 3) & ~(size_t)3) * sizeof(float) + (3 * 6 * 64 + 3 * 2 * 64) * 16 + 3 * RT16S_STG * sizeof(float) +
                         (size_t)RT_NSA_HM_WORDS * 4;
     if (split) hipLaunchKernelGGL(rt_pack_split_nsadj_kernel, dim3(36), dim3(256), 0, stream, wimg, reinterpret_cast<unsigned*>(const_cast<float*>(wimg)) + RT_NSA_OFF);
 #define RT_ADJS(A)                                                                                                                              \
     do {                                                                                                                                        \
-        if (split && rich) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true, false, true>), grid, blockh, ldss, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        if (split && rich && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true, true, true>), grid, blockh, ldss, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else if (split && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false, true, true>), grid, blockh, ldss, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
+        else if (split && rich) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true, false, true>), grid, blockh, ldss, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else if (split) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false, false, true>), grid, blockh, ldss, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else if (use_helper && rich && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, true, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
         else if (use_helper && m.rkc) hipLaunchKernelGGL((rt16sh_adjoint_kernel<A, false, true>), grid, blockh, ldsh, stream, m, wimg, save_times, n_save, substeps, sol, truth, t16_tape, t16_ztape, lw, slab, n_col, dwtape); \
