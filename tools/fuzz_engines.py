@@ -22,6 +22,9 @@ for c in range(cases):
     arith = str(rng.choice(["bf16x3_exact", "bf16x3_exact", "f32_mfma"]))        # of the two engines under test (tile16, the reference here, runs f32 MFMA)
     p = synthetic.wind_mixing_problem(ncol, n_frames=frames, weight_divisor=1e2, **VARIANTS[name])      # (weights/1e3 and smaller: the loss sinks into float32 round-off of the trajectories and relative errors mean nothing)
     cfg = p.cfg.with_(substeps=max(sub, p.cfg.substeps if "conv_adj" in name else sub))
+    rkc = bool(rng.integers(4) == 0)                                             # a quarter of the cases under the stabilised RKC2 stepper (net-split kernels and tile16; regtile refuses it)
+    if rkc:
+        cfg = cfg.with_(stepper="rkc2", substeps=int(rng.choice([1, 2])))
     sc = np.concatenate([rng.uniform(0.5, 1.5, 3), rng.uniform(0, 1e-2, 3) * (rng.integers(2))])
     res = {}
     truth = None
@@ -42,7 +45,7 @@ for c in range(cases):
     if res["auto"] is None or res["tile16"] is None:
         print("case %d %s ncol %d frames %d sub %d: refused (%s)" % (c, name, ncol, frames, sub, msg)); continue
     ref = res["tile16"]
-    line = "case %2d %-16s ncol %3d frames %2d sub %d rich %s split %s %s loss %.1e:" % (c, name, ncol, frames, cfg.substeps, rich, res["auto"][3]["split_adjoint"], arith, ref[1])
+    line = "case %2d %-16s ncol %3d frames %2d sub %d rich %s split %s %s%s loss %.1e:" % (c, name, ncol, frames, cfg.substeps, rich, res["auto"][3]["split_adjoint"], arith, " rkc2" if rkc else "", ref[1])
     for label in ("auto", "regtile"):
         r = res[label]
         if r is None: continue
