@@ -15,7 +15,8 @@ hipError_t fc_set_kernel_attributes();
 // problems that cannot fill 32-column tiles on every CU); the operand images depend on it
 int fc_tile_width(int n_col);
 // simgf / simgb (fc_split_image_words(Nz) words each, or null): the operand images of COLNDE_MATRIX_BF16X3_EXACT — every weight split exactly into three
-// bf16 planes, in each wave's stream order — packed beside the f32 images when the tile width is 32 (fc_split_supported)
+// bf16 planes, in each wave's stream order — packed beside the f32 images (fc_split_supported: tile width 32 -> engine_fc_split.hip's kernels, 16 -> the
+// SPLIT instantiations of engine_fc.hip's; the two orders differ, the size does not)
 size_t fc_split_image_words(int Nz);
 bool fc_split_supported(int cw);
 hipError_t fc_launch_pack(const DevModel& m, int cw, const float* w, float* imgf, float* imgb, float* bias, unsigned int* simgf, unsigned int* simgb,

@@ -23,7 +23,13 @@
 //    reads back nothing but those bits, back-propagates through W3ᵀ, W2ᵀ, W1ᵀ and fills the record's dz part; tile16's split-K dW GEMM
 //    contracts the records unchanged.  Per column and stage: 4.9 KB of tape against tile16's 7.2 KB.
 //  * Everything is summed in a fixed order: bit-reproducible gradients.
+//  * COLNDE_MATRIX_BF16X3_EXACT (round 4): the 32-column tiles have kernels of their own (engine_fc_split.hip); the 16-column tiles of the latency sizes
+//    (up to 4,096 columns) run THIS file's kernels with the operand stream swapped (FcStream<NZ, 16, true>): pre-split weight planes through the same kind
+//    of ring, activations split by the wave that reads them (one split per 32-deep k-block, shared by its four / two row tiles, software-pipelined under
+//    the previous block's MFMAs), v_mfma_f32_16x16x32_bf16.  Tapes, masks, epilogues, physics: unchanged.  8 simulations x 64 levels: 30.3 -> 24.6 ms.
+#include <type_traits>
 #include "engine_fc.h"
+#include "split_bf16.h"
 
 typedef float fc16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32;
@@ -75,6 +81,19 @@ struct Fc {
     static constexpr int R = NZ + 2 * ACT4;                      // floats per column of a delta-tape record (dwtape_row_floats)
     static constexpr int OWN = CW * NZ / 256;                    // state items (column, level) per thread
     static_assert(P % FC_PF == 0, "the ring must close over one stage");
+    // ---- COLNDE_MATRIX_BF16X3_EXACT on the 16-column tiles (round 4; the 32-column tiles have their own kernels, engine_fc_split.hip): the same sections
+    // on v_mfma_f32_16x16x32_bf16 from exact three-way operand splits (split_bf16.h).  The A operand is pre-split: per (16-row tile, 32-deep k-block) three
+    // planes (h, m, l) of [64 lanes][8 bf16], lane (m = lane % 16, kq = lane / 16) holding k = 32 kb + 8 kq + i.  A wave's stream is contiguous per
+    // section, k-block outer, its row tiles (jobs) inner, planes innermost: the B operand (8 consecutive floats of the column's activation row, split
+    // in registers: 44 vector instructions) is shared by the wave's jobs.  Unit below: one SLOT = one plane fragment (64 lanes x 16 bytes).
+    static constexpr int KB_IN = NZ / 32, KB_H = H / 32, KB3 = KB_H / KS3;          // k-blocks per chain: K = NZ, K = 4 NZ, the narrow layer's K part
+    static constexpr int SF1 = 0, SF1_SZ = MT * KB_IN * 3 * 256;                    // u32 words
+    static constexpr int SF2 = SF1 + SF1_SZ, SF2_SZ = MT * KB_H * 3 * 256;
+    static constexpr int SF3 = SF2 + SF2_SZ, SF3_SZ = MT3 * KB_H * 3 * 256;
+    static constexpr int SIMG = SF3 + SF3_SZ;                                       // words per split operand image (1.5 x IMG: engine_fc_split's size)
+    static constexpr int PS0 = JH * 3 * KB_IN, PS1 = JH * 3 * KB_H, PS2 = 3 * KB3, PS = PS0 + PS1 + PS2;   // slots per stage and wave
+    static constexpr int PFS = 12;                                                  // ring depth in slots
+    static_assert(CW != 16 || (PS % PFS == 0 && KB_IN >= 1), "the split ring must close over one stage");
     typedef float acc_t __attribute__((ext_vector_type(ACCN)));
     // first row (within the row tile) of accumulator quad q for this lane's hq
     __device__ static constexpr int qrow(int q, int hq) { return (CW == 32 ? 8 * q : 0) + 4 * hq; }
@@ -129,6 +148,124 @@ __device__ __forceinline__ void fc_section(f32x4 (&ring)[FC_PF], const f32x4* co
     }
 }
 
+// slot position of the split stream (16-column tiles) -> section, and offset in 16-byte units from the wave's base of that section
+template <int NZ> __host__ __device__ constexpr int fc16s_sec(int p) {
+    p %= Fc<NZ, 16>::PS;
+    return p < Fc<NZ, 16>::PS0 ? 0 : (p < Fc<NZ, 16>::PS0 + Fc<NZ, 16>::PS1 ? 1 : 2);
+}
+template <int NZ> __host__ __device__ constexpr int fc16s_off(int p) {
+    using S = Fc<NZ, 16>;
+    p %= S::PS;
+    return (p < S::PS0 ? p : (p < S::PS0 + S::PS1 ? p - S::PS0 : p - S::PS0 - S::PS1)) * 64;
+}
+
+__device__ __forceinline__ f32x4 fc_mfma16_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// The split twin of fc_section on 16-column tiles: NJ jobs of NKB 32-deep k-blocks, stream position P0 (slots).  Per k-block: two 16-byte LDS reads
+// (the 8 floats of column n this lane multiplies), ONE exact three-way split of them (shared by the jobs), and per job three ring slots (the
+// pre-split planes of the weight fragment) and six bf16 MFMAs, smallest products first; every slot is refilled PFS positions ahead as it is consumed.
+template <int NZ, int P0, int NJ, int NKB, int PFS, class Epi>
+__device__ __forceinline__ void fc_section_bf(u32x4 (&ring)[PFS], const u32x4* const (&base)[3], int lane, const float* brow, Epi&& epi) {
+    using S = Fc<NZ, 16>;
+    static_assert(PFS == S::PFS, "ring depth");
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) acc[j] = (f32x4)(0.0f);
+    // Software pipeline over the k-blocks: the split of block kb + 1 is issued in pieces BETWEEN the jobs' MFMA groups of block kb (one wave per SIMD at the
+    // latency sizes: nothing else hides those 44 vector instructions), its eight floats were requested one block earlier still.
+    f32x4 lo = *reinterpret_cast<const f32x4*>(brow), hi = *reinterpret_cast<const f32x4*>(brow + 4);
+    f32x4 lo1 = lo, hi1 = hi;
+    if (NKB > 1) {
+        lo1 = *reinterpret_cast<const f32x4*>(brow + 32);
+        hi1 = *reinterpret_cast<const f32x4*>(brow + 36);
+    }
+    Bf3 B;
+    {
+        const float x8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        B = bf3_split8(x8);
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++) {
+        const float n8[8] = {lo1.x, lo1.y, lo1.z, lo1.w, hi1.x, hi1.y, hi1.z, hi1.w};      // block kb + 1 (landed during block kb - 1)
+        if (kb + 2 < NKB) {
+            lo1 = *reinterpret_cast<const f32x4*>(brow + 32 * (kb + 2));
+            hi1 = *reinterpret_cast<const f32x4*>(brow + 32 * (kb + 2) + 4);
+        }
+        Bf3 Bn = B;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int p = P0 + (kb * NJ + j) * 3;
+            const u32x4 Ah = ring[p % PFS], Am = ring[(p + 1) % PFS], Al = ring[(p + 2) % PFS];
+            ring[p % PFS] = (base[fc16s_sec<NZ>(p + PFS)] + fc16s_off<NZ>(p + PFS))[lane];
+            ring[(p + 1) % PFS] = (base[fc16s_sec<NZ>(p + 1 + PFS)] + fc16s_off<NZ>(p + 1 + PFS))[lane];
+            ring[(p + 2) % PFS] = (base[fc16s_sec<NZ>(p + 2 + PFS)] + fc16s_off<NZ>(p + 2 + PFS))[lane];
+            f32x4 c = acc[j];
+            c = fc_mfma16_bf(Am, B.m, c);
+            c = fc_mfma16_bf(Al, B.h, c);
+            c = fc_mfma16_bf(Ah, B.l, c);
+            c = fc_mfma16_bf(Am, B.h, c);
+            c = fc_mfma16_bf(Ah, B.m, c);
+            c = fc_mfma16_bf(Ah, B.h, c);
+            acc[j] = c;
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < NKB) {
+                // this job's share of the next block's split: pairs [4 j / NJ, 4 (j + 1) / NJ)
+#pragma unroll
+                for (int q = 4 * j / NJ; q < 4 * (j + 1) / NJ; q++) bf3_split_pair(n8[2 * q], n8[2 * q + 1], q, Bn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        B = Bn;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) epi(j, acc[j]);
+}
+
+// The operand stream of one wave behind one interface: f32 MFMA (fc_section: ring of FC_PF float4 groups) or, SPLIT (16-column tiles), bf16 MFMA on exact
+// three-way splits (fc_section_bf: ring of PFS plane fragments).  `rows` is the LDS row of column n (B operand); section 2 starts at the wave's K part.
+template <int NZ, int CW, bool SPLIT>
+struct FcStream {
+    using S = Fc<NZ, CW>;
+    static_assert(!SPLIT || CW == 16, "this file's split path is the 16-column one (32 columns: engine_fc_split.hip)");
+    typedef typename std::conditional<SPLIT, u32x4, f32x4>::type slot_t;
+    static constexpr int DEPTH = SPLIT ? S::PFS : FC_PF;
+    slot_t ring[DEPTH];
+    const slot_t* base[3];
+
+    __device__ __forceinline__ void init(const void* img, int w, int lane) {
+        if constexpr (SPLIT) {
+            const u32x4* im = reinterpret_cast<const u32x4*>(img);
+            base[0] = im + S::SF1 / 4 + w * S::PS0 * 64;
+            base[1] = im + S::SF2 / 4 + w * S::PS1 * 64;
+            base[2] = im + S::SF3 / 4 + w * S::PS2 * 64;
+#pragma unroll
+            for (int q = 0; q < DEPTH; q++) ring[q] = (base[fc16s_sec<NZ>(q)] + fc16s_off<NZ>(q))[lane];
+        } else {
+            const float* im = reinterpret_cast<const float*>(img);
+            base[0] = reinterpret_cast<const f32x4*>(im + S::F1) + (w * S::S_IN) * 64;
+            base[1] = reinterpret_cast<const f32x4*>(im + S::F2) + (w * S::S_H) * 64;
+            base[2] = reinterpret_cast<const f32x4*>(im + S::F3) + ((w % S::MT3) * S::S_H + (w / S::MT3) * S::G3) * 64;
+#pragma unroll
+            for (int q = 0; q < DEPTH; q++) ring[q] = (base[fc_sec<NZ, CW>(q)] + fc_off<NZ, CW>(q))[lane];
+        }
+    }
+    // SEC 0: K = NZ hidden section, 1: K = 4 NZ hidden section, 2: the narrow layer (this wave's K part); h = lane / CW
+    template <int SEC, class Epi>
+    __device__ __forceinline__ void section(const slot_t* const (&sb)[3], int lane, int h, int w, const float* rows, Epi&& epi) {
+        if constexpr (SPLIT) {
+            if constexpr (SEC == 0) fc_section_bf<NZ, 0, S::JH, S::KB_IN>(ring, sb, lane, rows + 8 * h, epi);
+            else if constexpr (SEC == 1) fc_section_bf<NZ, S::PS0, S::JH, S::KB_H>(ring, sb, lane, rows + 8 * h, epi);
+            else fc_section_bf<NZ, S::PS0 + S::PS1, 1, S::KB3>(ring, sb, lane, rows + (w / S::MT3) * S::KB3 * 32 + 8 * h, epi);
+        } else {
+            if constexpr (SEC == 0) fc_section<NZ, CW, 0, S::JH, S::S_IN>(ring, sb, lane, rows + 4 * h, epi);
+            else if constexpr (SEC == 1) fc_section<NZ, CW, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, rows + 4 * h, epi);
+            else fc_section<NZ, CW, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, rows + (w / S::MT3) * S::G3 * S::KG + 4 * h, epi);
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // operand images.  Flux.destructure: W_l[o][i] (out o, in i) at w_off[l] + i*no + o, b_l[o] at b_off[l] + o.
 //   forward  section (rows = outputs):  A[row = mt*CW + lane%CW][k = KG*S + 4(lane/CW) + j] = W_l[row][k]
@@ -175,6 +312,55 @@ __global__ void __launch_bounds__(256) fc_pack_kernel(FcOffsets o, const float* 
     }
 }
 
+// The split images of the 16-column tiles (COLNDE_MATRIX_BF16X3_EXACT): the same two operand matrices as fc_pack_kernel's, every weight split exactly into
+// three bf16 (x = h + m + l by truncation: split_bf16.h), laid out as each WAVE streams them — image[section][wave][k-block][job][plane][lane][8 bf16]:
+// lane (m = lane % 16, kq = lane / 16), element i <-> k = 32 kb + 8 kq + i of row 16 (wave + 4 job) + m (sections 0, 1); section 2: row tile
+// wave % MT3, k-blocks (wave / MT3) KB3 + g.
+template <int NZ>
+__global__ void __launch_bounds__(256) fc_pack_split16_kernel(FcOffsets o, const float* __restrict__ w, u32* __restrict__ simgf, u32* __restrict__ simgb) {
+    using S = Fc<NZ, 16>;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 2 * S::SIMG; idx += gridDim.x * 256) {
+        const bool fwd = idx < S::SIMG;
+        const int e = fwd ? idx : idx - S::SIMG;
+        const int sec = e < S::SF2 ? 0 : (e < S::SF3 ? 1 : 2);
+        const int r = e - (sec == 0 ? S::SF1 : (sec == 1 ? S::SF2 : S::SF3));
+        const int i2 = r & 3, lane = (r >> 2) & 63, slot = r >> 8;                  // word of the fragment, lane, plane fragment
+        const int per_wave = sec == 0 ? S::PS0 : (sec == 1 ? S::PS1 : S::PS2);
+        const int wv = slot / per_wave, q = slot - wv * per_wave;
+        const int pl = q % 3;
+        int tile, kb;
+        if (sec < 2) {
+            const int j = (q / 3) % S::JH;
+            kb = q / (3 * S::JH);
+            tile = wv + 4 * j;
+        } else {
+            tile = wv % S::MT3;
+            kb = (wv / S::MT3) * S::KB3 + q / 3;
+        }
+        const int row = tile * 16 + (lane & 15);
+        u32 word = 0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int k = 32 * kb + 8 * (lane >> 4) + 2 * i2 + t;
+            float v = 0.0f;
+            if (fwd) {
+                const int no = sec == 2 ? S::NO : S::H;                              // sections: W1 (NZ -> H), W2 (H -> H), W3 (H -> NO)
+                if (row < no) v = w[o.w[sec] + k * no + row];
+            } else {
+                const int l = 2 - sec;                                               // sections: W3^T (k = layer-3 outputs), W2^T, W1^T (rows = state levels)
+                const int no = l == 2 ? S::NO : S::H;
+                if (k < no) v = w[o.w[l] + row * no + k];
+            }
+            const float vh = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+            const float rr = v - vh;
+            const float vm = __uint_as_float(__float_as_uint(rr) & 0xffff0000u);
+            const float part = pl == 0 ? vh : (pl == 1 ? vm : rr - vm);
+            word |= (__float_as_uint(part) >> 16) << (16 * t);                      // element 2 i2 in the low half (Bf3's order)
+        }
+        (fwd ? simgf : simgb)[e] = word;
+    }
+}
+
 // state items owned by a thread: item it = tid + 256 r  ->  (column it / NZ, level it % NZ)
 #define FC_OWNER_INDEX()                                                   \
     int oc[S::OWN];                                                        \
@@ -189,9 +375,9 @@ __global__ void __launch_bounds__(256) fc_pack_kernel(FcOffsets o, const float* 
 // ------------------------------------------------------------------------------------------------
 typedef unsigned long long u64;
 
-template <int NZ, int CW, bool TAPE, bool CA, bool RKC>
+template <int NZ, int CW, bool TAPE, bool CA, bool RKC, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2)
-fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, const float* __restrict__ x0, size_t x0_stride,
+fc_forward_kernel(const void* __restrict__ imgf, const float* __restrict__ bias, const float* __restrict__ x0, size_t x0_stride,
                   const float* __restrict__ bcs, const float* __restrict__ save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float CN,
                   float caKN, int nst, const float* __restrict__ rkc, float* __restrict__ sol, float* __restrict__ dwtape, u32* __restrict__ masks,
                   u64* __restrict__ swtape, int n_col) {
@@ -211,13 +397,9 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
     const int col0 = blockIdx.x * CW;
     FC_OWNER_INDEX();
 
-    const f32x4* base[3];
-    base[0] = reinterpret_cast<const f32x4*>(imgf + S::F1) + (w * S::S_IN) * 64;
-    base[1] = reinterpret_cast<const f32x4*>(imgf + S::F2) + (w * S::S_H) * 64;
-    base[2] = reinterpret_cast<const f32x4*>(imgf + S::F3) + ((w % S::MT3) * S::S_H + (w / S::MT3) * S::G3) * 64;
-    f32x4 ring[FC_PF];
-#pragma unroll
-    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ, CW>(q)] + fc_off<NZ, CW>(q))[lane];
+    typedef FcStream<NZ, CW, SPLIT> Stream;
+    Stream strm;
+    strm.init(imgf, w, lane);
 
     float xn[S::OWN], vst[S::OWN], kv[S::OWN], bcb[S::OWN], bct[S::OWN];
 #pragma unroll
@@ -244,7 +426,7 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
         const bool tp = TAPE && qi >= 0;                              // wave-uniform
         int zero = 0;
         FC_OPAQUE_ZERO(zero);
-        const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
+        const typename Stream::slot_t* const sb[3] = {strm.base[0] + zero, strm.base[1] + zero, strm.base[2] + zero};
         const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
         float* rec = tp ? dwtape + ri * ((size_t)CW * S::R) : nullptr;
         u32* mrec = tp ? masks + ri * 512 + w * 64 + lane : nullptr;
@@ -277,20 +459,20 @@ fc_forward_kernel(const float* __restrict__ imgf, const float* __restrict__ bias
         };
         {
             u32 mb = 0;
-            fc_section<NZ, CW, 0, S::JH, S::S_IN>(ring, sb, lane, X + n * S::LDX + 4 * h,
-                                              [&](int j, const typename S::acc_t& acc) { mb |= hidden(1, A1, j, acc) << (S::ACCN * j); });
+            strm.template section<0>(sb, lane, h, w, X + n * S::LDX,
+                                     [&](int j, const typename S::acc_t& acc) { mb |= hidden(1, A1, j, acc) << (S::ACCN * j); });
             if (tp) FC_STORE(mb, mrec);
         }
         FC_BARRIER();
         {
             u32 mb = 0;
-            fc_section<NZ, CW, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, A1 + n * S::LDH + 4 * h,
-                                                           [&](int j, const typename S::acc_t& acc) { mb |= hidden(2, A2, j, acc) << (S::ACCN * j); });
+            strm.template section<1>(sb, lane, h, w, A1 + n * S::LDH,
+                                     [&](int j, const typename S::acc_t& acc) { mb |= hidden(2, A2, j, acc) << (S::ACCN * j); });
             if (tp) FC_STORE(mb, mrec + 256);
         }
         FC_BARRIER();
         // ---- output layer: row tile w % MT3, K part w / MT3; partial sums to LDS
-        fc_section<NZ, CW, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, A2 + n * S::LDH + (w / S::MT3) * S::G3 * S::KG + 4 * h,
+        strm.template section<2>(sb, lane, h, w, A2 + n * S::LDH,
             [&](int, const typename S::acc_t& acc) {
                 float* pr = PART + ((w / S::MT3) * CW + n) * NZ + (w % S::MT3) * CW;
 #pragma unroll
@@ -495,9 +677,9 @@ fc_infer_kernel(const float* __restrict__ imgf, const float* __restrict__ bias, 
 // ------------------------------------------------------------------------------------------------
 struct FcGrad { int b[3]; int n_params; };
 
-template <int NZ, int CW, bool CA, bool RKC>
+template <int NZ, int CW, bool CA, bool RKC, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2)
-fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save_times, int n_save, int iv_begin, int iv_end, int substeps, float CN,
+fc_adjoint_kernel(const void* __restrict__ imgb, const float* __restrict__ save_times, int n_save, int iv_begin, int iv_end, int substeps, float CN,
                   float caKN, int nst, const float* __restrict__ rkc, const float* __restrict__ sol, const float* __restrict__ truth,
                   float* __restrict__ dwtape, const u32* __restrict__ masks, const u64* __restrict__ swtape, float w_loss, float* __restrict__ lam_io,
                   float* __restrict__ slab, FcGrad go, int n_col) {
@@ -513,13 +695,9 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
     const int col0 = blockIdx.x * CW;
     FC_OWNER_INDEX();
 
-    const f32x4* base[3];
-    base[0] = reinterpret_cast<const f32x4*>(imgb + S::F1) + (w * S::S_IN) * 64;
-    base[1] = reinterpret_cast<const f32x4*>(imgb + S::F2) + (w * S::S_H) * 64;
-    base[2] = reinterpret_cast<const f32x4*>(imgb + S::F3) + ((w % S::MT3) * S::S_H + (w / S::MT3) * S::G3) * 64;
-    f32x4 ring[FC_PF];
-#pragma unroll
-    for (int q = 0; q < FC_PF; q++) ring[q] = (base[fc_sec<NZ, CW>(q)] + fc_off<NZ, CW>(q))[lane];
+    typedef FcStream<NZ, CW, SPLIT> Stream;
+    Stream strm;
+    strm.init(imgb, w, lane);
 
     float lam[S::OWN], xb[S::OWN], kb[S::OWN], db3[S::OWN];
     u32 swp = 0;                                 // switch bits of this thread's items: bit 2r = face oi, bit 2r + 1 = face oi + 1 of item r
@@ -541,7 +719,7 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
     auto pull = [&](int qi) {
         int zero = 0;
         FC_OPAQUE_ZERO(zero);
-        const f32x4* const sb[3] = {base[0] + zero, base[1] + zero, base[2] + zero};
+        const typename Stream::slot_t* const sb[3] = {strm.base[0] + zero, strm.base[1] + zero, strm.base[2] + zero};
         const size_t ri = (size_t)blockIdx.x * n_steps * nst + qi;
         float* rec = dwtape + ri * ((size_t)CW * S::R);
         const u32* mrec = masks + ri * 512 + w * 64 + lane;
@@ -577,7 +755,7 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
             }
         };
         // ---- dz2 = relu'(z2) ∘ W3ᵀ dz3
-        fc_section<NZ, CW, 0, S::JH, S::S_IN>(ring, sb, lane, DZ3 + n * S::LDX + 4 * h,
+        strm.template section<0>(sb, lane, h, w, DZ3 + n * S::LDX,
                                           [&](int j, const typename S::acc_t& acc) { hidden(2, DZ2, m2, j, acc); });
         FC_BARRIER();
         // bias gradients: hidden unit tid's column sum of the finished dz rows, straight from LDS (16 accumulator registers per row tile
@@ -595,12 +773,12 @@ fc_adjoint_kernel(const float* __restrict__ imgb, const float* __restrict__ save
         };
         if (S::H == 256 || tid < S::H) db2 += colsum(DZ2);
         // ---- dz1 = relu'(z1) ∘ W2ᵀ dz2
-        fc_section<NZ, CW, S::JH * S::S_IN, S::JH, S::S_H>(ring, sb, lane, DZ2 + n * S::LDH + 4 * h,
+        strm.template section<1>(sb, lane, h, w, DZ2 + n * S::LDH,
                                                        [&](int j, const typename S::acc_t& acc) { hidden(1, DZ1, m1, j, acc); });
         FC_BARRIER();
         if (S::H == 256 || tid < S::H) db1 += colsum(DZ1);
         // ---- x̄ = W1ᵀ dz1: row tile w % MT3, K part w / MT3
-        fc_section<NZ, CW, S::JH * (S::S_IN + S::S_H), 1, S::G3>(ring, sb, lane, DZ1 + n * S::LDH + (w / S::MT3) * S::G3 * S::KG + 4 * h,
+        strm.template section<2>(sb, lane, h, w, DZ1 + n * S::LDH,
             [&](int, const typename S::acc_t& acc) {
                 float* pr = XBP + ((w / S::MT3) * CW + n) * NZ + (w % S::MT3) * CW;
 #pragma unroll
@@ -754,6 +932,12 @@ template <int NZ, int CW> static size_t fc_lds_adj() { return (size_t)(2 * CW * 
                            FC_FOR_EACH_SHAPE(M, true, true, false) FC_FOR_EACH_SHAPE(M, false, true, false)   \
                            FC_FOR_EACH_SHAPE(M, true, true, true) FC_FOR_EACH_SHAPE(M, false, true, true)
 #define FC_FOR_EACH_ADJ(M) FC_FOR_EACH_SHAPE(M, false, false) FC_FOR_EACH_SHAPE(M, true, false) FC_FOR_EACH_SHAPE(M, true, true)
+// ... and their COLNDE_MATRIX_BF16X3_EXACT twins on 16-column tiles (this file; the 32-column ones: engine_fc_split.hip)
+#define FC_FOR_EACH_SHAPE16(M, ...) M(64, 16, __VA_ARGS__) M(32, 16, __VA_ARGS__)
+#define FC_FOR_EACH_FWD16(M) FC_FOR_EACH_SHAPE16(M, true, false, false) FC_FOR_EACH_SHAPE16(M, false, false, false) \
+                             FC_FOR_EACH_SHAPE16(M, true, true, false) FC_FOR_EACH_SHAPE16(M, false, true, false)   \
+                             FC_FOR_EACH_SHAPE16(M, true, true, true) FC_FOR_EACH_SHAPE16(M, false, true, true)
+#define FC_FOR_EACH_ADJ16(M) FC_FOR_EACH_SHAPE16(M, false, false) FC_FOR_EACH_SHAPE16(M, true, false) FC_FOR_EACH_SHAPE16(M, true, true)
 
 hipError_t fc_set_kernel_attributes() {
     hipError_t e;
@@ -763,6 +947,12 @@ hipError_t fc_set_kernel_attributes() {
     FC_FOR_EACH_FWD(FC_ATTR_F)
     FC_FOR_EACH_ADJ(FC_ATTR_A)
     FC_FOR_EACH_SHAPE(FC_ATTR_I, 0)
+#define FC_ATTR_FS(N, W, T, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_forward_kernel<N, W, T, C, K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_fwd<N, W>())) != hipSuccess) return e;
+#define FC_ATTR_AS(N, W, C, K) if ((e = hipFuncSetAttribute((const void*)(fc_adjoint_kernel<N, W, C, K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds_adj<N, W>())) != hipSuccess) return e;
+    FC_FOR_EACH_FWD16(FC_ATTR_FS)
+    FC_FOR_EACH_ADJ16(FC_ATTR_AS)
+#undef FC_ATTR_FS
+#undef FC_ATTR_AS
 #undef FC_ATTR_F
 #undef FC_ATTR_A
 #undef FC_ATTR_I
@@ -780,9 +970,12 @@ hipError_t fc_launch_pack(const DevModel& m, int cw, const float* w, float* imgf
                           hipStream_t stream) {
     FcOffsets o;
     for (int l = 0; l < 3; l++) { o.w[l] = m.w_off[l]; o.b[l] = m.b_off[l]; }
-    if (simgf && simgb && fc_split_supported(cw)) {        // the split images of COLNDE_MATRIX_BF16X3_EXACT beside the f32 ones (the biases are shared)
+    if (simgf && simgb && cw == 32) {                      // the split images of COLNDE_MATRIX_BF16X3_EXACT beside the f32 ones (the biases are shared)
         const hipError_t es = fcs_launch_pack(m, w, simgf, simgb, stream);
         if (es != hipSuccess) return es;
+    } else if (simgf && simgb && cw == 16) {               // ... in the 16-column kernels' stream order (same size)
+        if (m.Nz == 64) hipLaunchKernelGGL((fc_pack_split16_kernel<64>), dim3(256), dim3(256), 0, stream, o, w, simgf, simgb);
+        else hipLaunchKernelGGL((fc_pack_split16_kernel<32>), dim3(128), dim3(256), 0, stream, o, w, simgf, simgb);
     }
     bool launched = false;
 #define FC_PACK(N, W, X) if (!launched && m.Nz == N && cw == W) { hipLaunchKernelGGL((fc_pack_kernel<N, W>), dim3(N == 64 ? 256 : 128), dim3(256), 0, stream, o, w, imgf, imgb, bias); launched = true; }
@@ -807,7 +1000,7 @@ hipError_t fc_launch_forward(const DevModel& m, int cw, const float* imgf, const
                              const float* bcs, const float* save_times, int n_save, int iv_begin, int iv_end, int tape_iv0, int substeps, float* sol,
                              float* dwtape, unsigned int* masks, unsigned long long* swtape, int n_col, hipStream_t stream) {
     if (n_col < 1 || iv_begin < 0 || iv_end > n_save - 1 || iv_begin >= iv_end || tape_iv0 < iv_begin || tape_iv0 >= iv_end) return hipErrorInvalidValue;
-    if (simgf && fc_split_supported(cw)) {                  // COLNDE_MATRIX_BF16X3_EXACT: the same solve on the bf16 pipe (engine_fc_split.hip)
+    if (simgf && cw == 32) {                                // COLNDE_MATRIX_BF16X3_EXACT: the same solve on the bf16 pipe (engine_fc_split.hip)
         if (dwtape && (!masks || (m.model == COLNDE_MODEL_CONV_ADJ_NDE && !swtape))) return hipErrorInvalidValue;
         if (m.rkc && m.model != COLNDE_MODEL_CONV_ADJ_NDE) return hipErrorInvalidValue;
         return fcs_launch_forward(m, simgf, bias, x0, x0_stride, bcs, save_times, n_save, iv_begin, iv_end, tape_iv0, substeps, sol, dwtape, masks, swtape, n_col, stream);
@@ -818,9 +1011,20 @@ hipError_t fc_launch_forward(const DevModel& m, int cw, const float* imgf, const
     if (tape && (!masks || (ca && !swtape))) return hipErrorInvalidValue;
     if (rk && !ca) return hipErrorInvalidValue;
     bool launched = false;
+    if (simgf && cw == 16) {                                // ... and on 16-column tiles: the SPLIT instantiations of this file's kernels
+#define FC_FWDS(N, W, T, C, K)                                                                                                                       \
+    if (!launched && m.Nz == N && tape == T && ca == C && rk == K) {                                                                                 \
+        hipLaunchKernelGGL((fc_forward_kernel<N, W, T, C, K, true>), grid, block, (fc_lds_fwd<N, W>()), stream, (const void*)simgf, bias, x0, x0_stride, bcs, save_times, n_save, \
+                           iv_begin, iv_end, tape_iv0, substeps, CN, caKN, m.nst, m.rkc, sol, dwtape, masks, swtape, n_col);                         \
+        launched = true;                                                                                                                             \
+    }
+        FC_FOR_EACH_FWD16(FC_FWDS)
+#undef FC_FWDS
+        return launched ? hipGetLastError() : hipErrorInvalidValue;
+    }
 #define FC_FWD(N, W, T, C, K)                                                                                                                        \
     if (!launched && m.Nz == N && cw == W && tape == T && ca == C && rk == K) {                                                                      \
-        hipLaunchKernelGGL((fc_forward_kernel<N, W, T, C, K>), grid, block, (fc_lds_fwd<N, W>()), stream, imgf, bias, x0, x0_stride, bcs, save_times, n_save, \
+        hipLaunchKernelGGL((fc_forward_kernel<N, W, T, C, K>), grid, block, (fc_lds_fwd<N, W>()), stream, (const void*)imgf, bias, x0, x0_stride, bcs, save_times, n_save, \
                            iv_begin, iv_end, tape_iv0, substeps, CN, caKN, m.nst, m.rkc, sol, dwtape, masks, swtape, n_col);                         \
         launched = true;                                                                                                                             \
     }
@@ -834,7 +1038,7 @@ hipError_t fc_launch_adjoint(const DevModel& m, int cw, const float* imgb, const
                              float w_loss, float* lam_io, float* slab, int n_col, hipStream_t stream) {
     if (n_col < 1 || !dwtape || !masks || iv_begin < 0 || iv_end > n_save - 1 || iv_begin >= iv_end) return hipErrorInvalidValue;
     if ((iv_begin > 0 || iv_end < n_save - 1) && !lam_io) return hipErrorInvalidValue;
-    if (simgb && fc_split_supported(cw)) {
+    if (simgb && cw == 32) {
         if ((m.model == COLNDE_MODEL_CONV_ADJ_NDE && !swtape) || (m.rkc && m.model != COLNDE_MODEL_CONV_ADJ_NDE)) return hipErrorInvalidValue;
         return fcs_launch_adjoint(m, simgb, save_times, n_save, iv_begin, iv_end, substeps, sol, truth, dwtape, masks, swtape, w_loss, lam_io, slab, n_col, stream);
     }
@@ -846,9 +1050,20 @@ hipError_t fc_launch_adjoint(const DevModel& m, int cw, const float* imgb, const
     for (int l = 0; l < 3; l++) go.b[l] = m.b_off[l];
     go.n_params = m.n_params;
     bool launched = false;
+    if (simgb && cw == 16) {
+#define FC_ADJS(N, W, C, K)                                                                                                                          \
+    if (!launched && m.Nz == N && ca == C && rk == K) {                                                                                              \
+        hipLaunchKernelGGL((fc_adjoint_kernel<N, W, C, K, true>), grid, block, (fc_lds_adj<N, W>()), stream, (const void*)simgb, save_times, n_save, iv_begin, iv_end, substeps, \
+                           CN, caKN, m.nst, m.rkc, sol, truth, dwtape, masks, swtape, w_loss, lam_io, slab, go, n_col);                              \
+        launched = true;                                                                                                                             \
+    }
+        FC_FOR_EACH_ADJ16(FC_ADJS)
+#undef FC_ADJS
+        return launched ? hipGetLastError() : hipErrorInvalidValue;
+    }
 #define FC_ADJ(N, W, C, K)                                                                                                                           \
     if (!launched && m.Nz == N && cw == W && ca == C && rk == K) {                                                                                   \
-        hipLaunchKernelGGL((fc_adjoint_kernel<N, W, C, K>), grid, block, (fc_lds_adj<N, W>()), stream, imgb, save_times, n_save, iv_begin, iv_end, substeps, \
+        hipLaunchKernelGGL((fc_adjoint_kernel<N, W, C, K>), grid, block, (fc_lds_adj<N, W>()), stream, (const void*)imgb, save_times, n_save, iv_begin, iv_end, substeps, \
                            CN, caKN, m.nst, m.rkc, sol, truth, dwtape, masks, swtape, w_loss, lam_io, slab, go, n_col);                              \
         launched = true;                                                                                                                             \
     }

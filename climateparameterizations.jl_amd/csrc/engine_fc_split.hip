@@ -659,7 +659,7 @@ fcs_adjoint_kernel(const u32* __restrict__ simgb, const float* __restrict__ save
 // host side (engine_fc.hip's launchers hand over when the split images are given)
 // ------------------------------------------------------------------------------------------------
 size_t fc_split_image_words(int Nz) { return Nz == 64 ? Fs<64>::SIMG : Fs<32>::SIMG; }
-bool fc_split_supported(int cw) { return cw == 32; }
+bool fc_split_supported(int cw) { return cw == 32 || cw == 16; }       // 32: this file; 16: the SPLIT instantiations of engine_fc.hip (same image size)
 
 #define FCS_FOR_EACH_SHAPE(M, ...) M(64, __VA_ARGS__) M(32, __VA_ARGS__)
 #define FCS_FOR_EACH_FWD(M) FCS_FOR_EACH_SHAPE(M, true, false, false) FCS_FOR_EACH_SHAPE(M, false, false, false) \

@@ -27,6 +27,15 @@ __device__ __forceinline__ Bf3 bf3_split8(const float* x) {
     return o;
 }
 
+// one pair of the eight: elements 2 p, 2 p + 1 of the three planes (for callers that spread a split between other work)
+__device__ __forceinline__ void bf3_split_pair(float a, float b, int p, Bf3& o) {
+    const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+    const float la = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), lb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+    o.h[p] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    o.m[p] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+    o.l[p] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+}
+
 __device__ __forceinline__ sp_f32x16 mfma_bf(u32x4 a, u32x4 b, sp_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

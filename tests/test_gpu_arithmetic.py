@@ -37,8 +37,8 @@ CASES = {
     "net_split_auto": (lambda: _wm(40, 33), 0, (True, True, True)),
     "tile16_wind_mixing": (lambda: _wm(40, 9), ENGINE_TILE16, (False, False, True)),
     "tile16_smoothing": (lambda: _wm(21, 9, **{"smooth_NN": True}), 0, (False, False, True)),
-    "fc32_32": (lambda: _fc(70, 32), 0, None),                        # (fc32's families: whatever the build has; checked for consistency only)
-    "fc32_64": (lambda: _fc(45, 64), 0, None),
+    "fc32_32": (lambda: _fc(70, 32), 0, (True, True, True)),          # (16-column tiles at these sizes: the SPLIT instantiations of engine_fc.hip)
+    "fc32_64": (lambda: _fc(45, 64), 0, (True, True, True)),
     "tile16_free_convection": (lambda: _fc(33, 32), ENGINE_TILE16, (False, False, True)),
 }
 
