@@ -2459,11 +2459,10 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                 Bf3 XB[3];
                 if constexpr (SPLIT) {
                     asm volatile("" : "+v"(lz));          // operand addresses stay (lane base + immediate): see rt16_forward_kernel
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        const float x8[8] = {Xs[q].t[0][0], Xs[q].t[0][1], Xs[q].t[0][2], Xs[q].t[0][3], Xs[q].t[1][0], Xs[q].t[1][1], Xs[q].t[1][2], Xs[q].t[1][3]};
-                        XB[q] = bf3_split8(x8);
-                    }
+                    // only the first k-block's split stands in front of the products: those of blocks 1 and 2 follow tile 0's MFMAs of the block before
+                    // (one wave per SIMD: nothing else hides their 88 vector instructions)
+                    const float x8[8] = {Xs[0].t[0][0], Xs[0].t[0][1], Xs[0].t[0][2], Xs[0].t[0][3], Xs[0].t[1][0], Xs[0].t[1][1], Xs[0].t[1][2], Xs[0].t[1][3]};
+                    XB[0] = bf3_split8(x8);
                 }
                 f32x4t A1[4];
 #pragma unroll
@@ -2485,6 +2484,11 @@ rt16sh_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                                 A.h = simg[at]; A.m = simg[at + (live3 ? 8 : 0)]; A.l = simg[at + (live3 ? 16 : 0)];
                             }
                             acc = mfma16_bf3(A, XB[q], acc);
+                            if (t == 0 && q < 2) {
+                                const int qn = q < 2 ? q + 1 : 2;
+                                const float n8[8] = {Xs[qn].t[0][0], Xs[qn].t[0][1], Xs[qn].t[0][2], Xs[qn].t[0][3], Xs[qn].t[1][0], Xs[qn].t[1][1], Xs[qn].t[1][2], Xs[qn].t[1][3]};
+                                XB[qn] = bf3_split8(n8);
+                            }
                         }
                         __builtin_amdgcn_s_setprio(0);
                         RT_SCHED_FENCE();
@@ -3521,16 +3525,28 @@ rt16sh_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* _
                     // δz1 as the B operand of two 32-deep k-blocks: element e of k-block kb is quad 8 kb + e of this lane group (padding quads are zero)
                     const float d80[8] = {dZ1[0][0], dZ1[0][1], dZ1[0][2], dZ1[0][3], dZ1[1][0], dZ1[1][1], dZ1[1][2], dZ1[1][3]};
                     const float d81[8] = {dZ1[2][0], dZ1[2][1], dZ1[2][2], dZ1[2][3], dZ1[3][0], dZ1[3][1], dZ1[3][2], dZ1[3][3]};
-                    const Bf3 B0 = bf3_split8(d80), B1 = bf3_split8(d81);
+                    // the first k-block over all six tiles, the second k-block's split issued in pieces between them (one wave per SIMD: nothing else hides
+                    // its 44 vector instructions), then the second k-block
+                    const Bf3 B0 = bf3_split8(d80);
+                    Bf3 B1 = B0;
+                    f32x4t c2[6];
 #pragma unroll
                     for (int tl = 0; tl < 6; tl++) {
-                        Bf3 A0, A1_;
+                        Bf3 A0;
                         A0.h = Hm[tl * 2 + 0]; A0.m = Hm[tl * 2 + 1]; A0.l = Lr[tl];
+                        c2[tl] = mfma16_bf3(A0, B0, (f32x4t)(0.0f));
+                        RT_SCHED_FENCE();
+                        if (tl < 4) {
+                            bf3_split_pair(d81[2 * tl], d81[2 * tl + 1], tl, B1);
+                            RT_SCHED_FENCE();
+                        }
+                    }
+#pragma unroll
+                    for (int tl = 0; tl < 6; tl++) {
+                        Bf3 A1_;
                         A1_.h = Hm[(6 + tl) * 2 + 0]; A1_.m = Hm[(6 + tl) * 2 + 1]; A1_.l = Lr[6 + tl];
-                        f32x4t c2 = (f32x4t)(0.0f);
-                        c2 = mfma16_bf3(A0, B0, c2);
-                        c2 = mfma16_bf3(A1_, B1, c2);
-                        ex[(n * 6 + tl) * 64 + lane] = c2;
+                        c2[tl] = mfma16_bf3(A1_, B1, c2[tl]);
+                        ex[(n * 6 + tl) * 64 + lane] = c2[tl];
                         RT_SCHED_FENCE();
                     }
                 } else
