@@ -304,13 +304,13 @@ def other_configs(dev, budget_s=120.0):
         return grad_case(p, 8, [1, 1, 1, 5e-3, 5e-3, 5e-3], 5, MLP_FLOP_PER_RHS, 4,
                          "configs[2] as written: 8 simulations x 32 levels x 289 frames, fwd+adjoint (latency point)", ma)
 
-    def c3ca():     # the reference's kappa = 10 convective-adjustment branch (NDE_training.jl:140-143; ROCK4 at train_NDE.jl:143) on 8 simulations
+    def c3ca(ma="bf16x3_exact"):     # the reference's kappa = 10 convective-adjustment branch (NDE_training.jl:140-143; ROCK4 at train_NDE.jl:143) on 8 simulations
         p = synthetic.wind_mixing_problem(8, modified_pacanowski_philander=False, zero_weights=False, convective_adjustment=True, kappa=10.0,
                                           stepper="rkc2", substeps=1)
         s = colnde.rkc_stages(p.cfg)
         r = grad_case(p, 8, [1, 1, 1, 5e-3, 5e-3, 5e-3], 3, MLP_FLOP_PER_RHS, s,
                       "configs[2]'s 8 simulations on the wind-mixing convective-adjustment branch (kappa = 10): 288 RKC2 steps of %d stages "
-                      "(sub-stepped RK4 would need %d RHS evaluations per frame), fwd+adjoint" % (s, 4 * colnde.min_substeps(p.cfg.with_(stepper="rk4"))))
+                      "(sub-stepped RK4 would need %d RHS evaluations per frame), fwd+adjoint" % (s, 4 * colnde.min_substeps(p.cfg.with_(stepper="rk4"))), ma)
         r["rhs_evaluations_per_step"] = s
         return r
 
@@ -384,10 +384,15 @@ def other_configs(dev, budget_s=120.0):
     guarded("config3_8_simulations", c3)
     guarded("config3_8_simulations_f32_mfma", f32(c3))
     guarded("config3_8_simulations_conv_adj_kappa10_rkc2", c3ca)
+    guarded("config3_8_simulations_conv_adj_kappa10_rkc2_f32_mfma", f32(c3ca))
     guarded("config5_inference_65536", c5)
     guarded("implicit_steps_4M_columns", impl)
-    guarded("free_convection_8_simulations_32_levels", lambda: fc(8, 32, False, 3, "free convection at a latency size: 8 simulations x 32 levels x 512 RK4 steps, fwd+adjoint (fc32 on 16-column tiles)"))
-    guarded("free_convection_8_simulations_64_levels", lambda: fc(8, 64, False, 3, "free convection at a latency size: 8 simulations x 64 levels x 512 RK4 steps, fwd+adjoint (fc32 on 16-column tiles)"))
+    fc8_32 = "free convection at a latency size: 8 simulations x 32 levels x 512 RK4 steps, fwd+adjoint (fc32 on 16-column tiles)"
+    fc8_64 = "free convection at a latency size: 8 simulations x 64 levels x 512 RK4 steps, fwd+adjoint (fc32 on 16-column tiles)"
+    guarded("free_convection_8_simulations_32_levels", lambda: fc(8, 32, False, 3, fc8_32))
+    guarded("free_convection_8_simulations_32_levels_f32_mfma", f32(lambda ma: fc(8, 32, False, 3, fc8_32, ma)))
+    guarded("free_convection_8_simulations_64_levels", lambda: fc(8, 64, False, 3, fc8_64))
+    guarded("free_convection_8_simulations_64_levels_f32_mfma", f32(lambda ma: fc(8, 64, False, 3, fc8_64, ma)))
     guarded("free_convection_32_levels_16384", lambda: fc(16384, 32, False, 2, "free convection 32 levels (32-128-128-31 relu), 16384 columns x 512 RK4 steps, fwd+adjoint"))
     c4_label = "configs[3] one GPU's shard: FreeConvectionNDE, 16384 columns x 64 levels x 512 RK4 steps, 64-256-256-63 relu, fwd+adjoint"
     guarded("config4_shard_16384x64", lambda: fc(16384, 64, False, 2, c4_label))
