@@ -93,3 +93,14 @@ def test_inference_workload_is_sharded_by_column_without_a_collective():
     assert "infer_forcing" in calls and "allreduce_result" not in calls and "all_gather" not in calls
     timed = [n for n in ast.walk(fn) if isinstance(n, ast.For) and any(isinstance(c, ast.Call) and getattr(c.func, "attr", "") == "infer_forcing" for c in ast.walk(n))]
     assert timed and all(not any(isinstance(c, ast.Call) and getattr(c.func, "id", getattr(c.func, "attr", "")) in ("reduce_", "barrier", "allreduce") for c in ast.walk(n)) for n in timed)
+
+
+def test_gpu_sensors_are_optional():
+    """bench.GpuSensors reads the shader clock and board power from sysfs when the nodes exist; without a GPU (or without permission) it reports None
+    and the bench line carries "clock": null — the timed region never depends on it."""
+    import bench
+    s = bench.GpuSensors(0).start()
+    assert s.stop() is None or isinstance(s.stop(), (dict, type(None)))
+    g = bench.GpuSensors(0)
+    g.dir = "/nonexistent"
+    assert g._read("freq1_input") is None
