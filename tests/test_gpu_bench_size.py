@@ -118,3 +118,57 @@ def test_conv_adj_nde_rkc2_16384x64_time_segments():
     heat = first.astype(np.float64).sum(axis=2) / 64.0
     expect = heat[:, :1] + C * (p.bcs[:, 0:1].astype(np.float64) - p.bcs[:, 1:2]) * t[None]
     np.testing.assert_allclose(heat, expect, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("ma", ["bf16x3_exact", "f32_mfma"])
+def test_free_convection_rk4_16384x64_the_shard_bench_times(ma):
+    """BASELINE configs[3]'s plain half exactly as bench.py times it: FreeConvectionNDE, 16,384 columns x 64 levels x 129 save points x 4 RK4 sub-steps
+    (one tape pass of ~155 GB, 512 workgroups of 32 columns; under the default arithmetic fcs_forward_kernel / fcs_adjoint_kernel / dw_gemm_split_kernel,
+    under f32_mfma their f32 twins), 256 replicas of 64 distinct columns:
+      * replica invariance of the trajectories, bit for bit; two calls give bit-identical gradients;
+      * the 64 distinct columns' trajectory, loss and gradient against the float64 oracle (free_convection/src/free_convection_nde.jl:29-38,
+        training.jl:55-62) at the fc32 tolerances of tests/test_gpu_parity.py;
+      * the plan: fc32, one block, no time segments, exact discrete adjoint, kernels on the arithmetic asked for;
+      * column heat changes only through the boundary fluxes."""
+    import torch
+    from oracle import nde_oracle as O
+    from tests.test_gpu_parity import FC_SOL_ATOL, FC_LOSS_RTOL, FC_GRAD_REL
+    n, reps = 16384, 256
+    dev = torch.device("cuda", 0)
+    p = synthetic.free_convection_problem(64, Nz=64)                                    # n_save = 129, t in [0, 1], 4 sub-steps
+    cfg = p.cfg
+    sc = np.array([0, 0, 1.0, 0, 0, 0])
+    truth64 = O.solve(cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    tot, terms, g, sol = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth64, sc)
+    # over the full 512-step axis float32 itself stands 1.5e-4 (trajectory), 7e-5 (loss), 1.4e-4 (gradient) from float64: the float32 oracle sets the scale
+    tot32, _, g32, sol32 = O.loss_and_grad(cfg, p.x0, p.bcs, p.weights, truth64, sc, dtype=np.float32)
+    e32 = (np.abs(sol32 - sol).max(), abs(tot32 - tot) / tot, _rel(g32, g))
+    x0 = torch.from_numpy(np.tile(p.x0, (reps, 1))).to(dev)
+    bcs = torch.from_numpy(np.tile(p.bcs, (reps, 1))).to(dev)
+    truth = torch.from_numpy(np.tile(truth64, (reps, 1, 1))).to(dev)
+    w = torch.from_numpy(p.weights).to(dev)
+    with colnde.ColumnNDE(cfg, n, matrix_arithmetic=ma) as nde:
+        nde.set_problem(x0, bcs, truth)
+        s = nde.forward(w).view(reps, 64, cfg.n_save, 64)
+        assert bool((s == s[:1]).all())
+        first = s[0].cpu().numpy()
+        out = nde.loss_grad(w, list(sc))
+        out2 = nde.loss_grad(w, list(sc))
+        plan = nde.plan()
+        res = out.cpu().numpy()
+        assert bool((out == out2).all())
+    split = ma == "bf16x3_exact"
+    assert plan["engine"] == ENGINE_FC32 and plan["n_blocks"] == 1 and plan["time_segments"] == 0 and not plan["approximate_gradient"]
+    assert (plan["bf16x3_forward"], plan["bf16x3_adjoint"], plan["bf16x3_dw"]) == (split, split, split)
+    np_ = cfg.n_params
+    assert np.abs(first - sol).max() < 2 * e32[0] + 0.25 * FC_SOL_ATOL
+    assert abs(res[np_ + 6] - tot) / tot < 4 * e32[1] + 0.1 * FC_LOSS_RTOL
+    assert _rel(res[:np_], g) < 4 * e32[2] + 0.25 * FC_GRAD_REL
+    from tests.test_gpu_parity import _record
+    _record("bench_size/free_convection_16384x64/%s" % ma, sol_abs=np.abs(first - sol).max(), loss_rel=abs(res[np_ + 6] - tot) / tot, grad_rel=_rel(res[:np_], g),
+            sol_abs_oracle32_vs_64=e32[0], loss_rel_oracle32_vs_64=e32[1], grad_rel_oracle32_vs_64=e32[2])
+    C = cfg.sigma[5] / cfg.sigma[2] * cfg.tau / cfg.H
+    t = np.asarray(cfg.save_times, np.float64)
+    heat = first.astype(np.float64).sum(axis=2) / 64.0
+    expect = heat[:, :1] + C * (p.bcs[:, 0:1].astype(np.float64) - p.bcs[:, 1:2]) * t[None]
+    np.testing.assert_allclose(heat, expect, rtol=0, atol=2e-4)
