@@ -59,14 +59,14 @@ class WindMixingNDE:
 
     def __init__(self, cfg: NDEConfig, uvT0, BCs, uvT_trains=None, device: int = 0,
                  gradient_scaling: float = 5e-3, training_fractions: Optional[dict] = None,
-                 weights0=None):
+                 weights0=None, matrix_arithmetic: str = "bf16x3_exact"):
         if cfg.model != WIND_MIXING:
             raise ValueError("WindMixingNDE needs a wind-mixing config")
         self.cfg = cfg
         uvT0 = np.ascontiguousarray(uvT0, dtype=np.float32)
         self.n_simulations = uvT0.shape[0]
         self.BCs = np.ascontiguousarray(BCs, dtype=np.float32)
-        self.engine = ColumnNDE(cfg, self.n_simulations, device=device)
+        self.engine = ColumnNDE(cfg, self.n_simulations, device=device, matrix_arithmetic=matrix_arithmetic)
         self.engine.set_problem(uvT0, self.BCs, uvT_trains)
         self._rhs_engine = None
         # determine_loss_scalings (NDE_training.jl:256-288)

@@ -66,6 +66,55 @@ def test_headline_launch_32768_columns_576_steps(ma):
     assert _rel(parts[:np_], a[:np_]) < 2e-5                                # the same columns in other tiles and slab rows: summation order only
 
 
+@pytest.mark.parametrize("ma", ["bf16x3_exact", "f32_mfma"])
+def test_headline_gradient_against_float64_oracle_512_replicas_of_64_columns(ma):
+    """VERDICT r4 task 2a — the headline launch's GRADIENT against the oracle, not against itself.  The loss is a mean over simulations
+    (NDE_training.jl:303-317), so 512 replicas of 64 distinct columns have exactly the six loss terms and the gradient of the 64: the GPU runs the
+    bench's own launch (32,768 columns x 576 RK4 steps, regtile, one ~130 GB tape block, 1,024 wave tiles, the dW1 streaming GEMM over 75 M
+    records) and the float64 oracle evaluates the 64.  Weights/1e2 so the nets matter; tolerances are the long-horizon ones of
+    tests/test_gpu_parity.py (LONG_*[1e2]: 2e-5 on the loss and on each term, 4e-5 relative L2 on the gradient).  Also: every replica's
+    trajectory is bit-identical to the first's (same arithmetic in every tile, workgroup and XCD)."""
+    import torch
+    from oracle import nde_oracle as O
+    from tests.test_gpu_parity import LONG_SOL_ATOL, LONG_LOSS_RTOL, LONG_TERMS_RTOL, LONG_GRAD_REL, _record
+    n, reps = 32768, 512
+    dev = torch.device("cuda", 0)
+    q = synthetic.wind_mixing_problem(64, n_frames=289, weight_divisor=1e2)
+    assert q.cfg.n_steps == 576
+    truth64 = O.solve(q.cfg, q.x0, q.bcs, q.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(q.cfg)
+    tot, terms, g, sol = O.loss_and_grad(q.cfg, q.x0, q.bcs, q.weights, truth64, sc)
+    x0 = torch.from_numpy(np.tile(q.x0, (reps, 1))).to(dev)
+    bcs = torch.from_numpy(np.tile(q.bcs, (reps, 1))).to(dev)
+    truth = torch.from_numpy(np.tile(truth64, (reps, 1, 1))).to(dev)
+    w = torch.from_numpy(q.weights).to(dev)
+    with colnde.ColumnNDE(q.cfg, n, engine=ENGINE_REGTILE, matrix_arithmetic=ma) as nde:
+        nde.set_problem(x0, bcs, truth)
+        s = nde.forward(w).view(reps, 64, q.cfg.n_save, 96)
+        assert bool((s == s[:1]).all())                                     # replica invariance, bit for bit
+        first = s[0].cpu().numpy()
+        del s
+        torch.cuda.empty_cache()
+        res = nde.loss_grad(w, list(sc)).cpu().numpy()
+        plan = nde.plan()
+    assert plan["engine"] == ENGINE_REGTILE and plan["n_blocks"] == 1 and plan["block_columns"] == n and plan["z1_taped"]
+    assert plan["bf16x3_forward"] == plan["bf16x3_adjoint"] == plan["bf16x3_dw"] == (ma == "bf16x3_exact")
+    np_ = q.cfg.n_params
+    terms_g, tot_g, grad_g = res[np_:np_ + 6], res[np_ + 6], res[:np_]
+    _record("bench_size/headline_32768x576_gradient/%s" % ma, sol_abs=np.abs(first - sol).max(), loss_rel=abs(tot_g - tot) / tot,
+            terms_rel=np.abs(terms_g / terms - 1).max(), grad_rel=_rel(grad_g, g))
+    assert np.abs(first - sol).max() < LONG_SOL_ATOL
+    np.testing.assert_allclose(terms_g, terms, rtol=LONG_TERMS_RTOL[1e2], atol=0)
+    assert np.isclose(tot_g, tot, rtol=LONG_LOSS_RTOL[1e2], atol=0)
+    assert _rel(grad_g, g) < LONG_GRAD_REL[1e2]
+    # each net's layer blocks separately (a wrong dW1 slab row or a wrong W3 block hides in the whole vector's norm)
+    third = np_ // 3
+    for net in range(3):
+        lo = net * third
+        for a, b in ((0, 4800), (4800, 4850), (4850, 5850), (5850, 5870), (5870, 6490), (6490, 6521)):      # W1 b1 W2 b2 W3 b3 (Flux.destructure order)
+            assert _rel(grad_g[lo + a:lo + b], g[lo + a:lo + b]) < 4 * LONG_GRAD_REL[1e2], (net, a, b)
+
+
 def test_conv_adj_nde_rkc2_16384x64_time_segments():
     """configs[3]'s stiff half as bench.py times it: ConvectiveAdjustmentNDE (K = 10), 16,384 columns x 64 levels, the 129-point axis, RKC2 with
     the automatic stage count, tapes cut into time segments.  The batch is 256 replicas of 64 distinct columns (one of them with an inverted
