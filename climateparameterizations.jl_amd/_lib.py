@@ -33,6 +33,7 @@ SYMBOLS = [
     ("colnde_error_estimate_dev", ctypes.c_int, [_V, _V, _F]),
     ("colnde_choose_substeps", ctypes.c_int, [_V, _V, ctypes.c_float, ctypes.POINTER(ctypes.c_int), _F]),
     ("colnde_substeps", ctypes.c_int, [_V]),
+    ("colnde_set_substeps", ctypes.c_int, [_V, ctypes.c_int]),
     ("colnde_flux", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
     ("colnde_flux_dev", ctypes.c_int, [_V, _V, _V, _V, ctypes.c_float, _V, ctypes.c_int]),
     ("colnde_loss_per_tstep", ctypes.c_int, [_V, _V, _V]),

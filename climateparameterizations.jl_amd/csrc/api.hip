@@ -97,6 +97,8 @@ struct colnde_handle {
     int min_substeps = 1;           // least RK4 sub-steps per save interval inside the diffusive stability bound
     bool auto_substeps = false;     // cfg.substeps = 0 at creation: the first solve call chooses the sub-step count from cfg.reltol (choose_substeps)
     float last_estimate = -1.0f;    // ... and the error estimate it settled on
+    std::vector<float> rkc_host;    // host copy of the RKC2 coefficient table in use (refresh_rkc)
+    bool substeps_chosen = false;   // the count in use came out of choose_substeps_impl (colnde_describe says so, with the estimate)
     float* d_rkc = nullptr;         // RKC2 coefficient table (DevModel::rkc)
     std::vector<PendingEvent> pending;
     double ms[K_COUNT] = {};
@@ -328,6 +330,29 @@ static void resolve_arithmetic(colnde_handle* h) {
     h->sp_dw = ov("COLNDE_DW_SPLIT");
 }
 
+// The RKC2 coefficient table for the sub-step count now in h->cfg: with rkc_stages = 0 the stage count FOLLOWS the step (least s with 0.9 beta(s) >= lambda dt),
+// so colnde_choose_substeps / colnde_set_substeps / the doubled solve of colnde_error_estimate each run with the stage count their own step needs (a table
+// frozen at creation would be too short for a longer step — unstable — and wastefully long for a shorter one).  Uploaded in stream order.
+static int refresh_rkc(colnde_handle* h) {
+    if (h->cfg.stepper != COLNDE_STEPPER_RKC2) return 0;
+    const int s = colnde_rkc_stages(&h->cfg);
+    if (s < 2) return 1;
+    if (s == h->m.nst && !h->rkc_host.empty()) return 0;
+    std::vector<double> tab;
+    rkc_tables(s, &tab);
+    h->rkc_host.assign((size_t)6 * RKC_LD, 0.0f);
+    for (int q = 0; q < 5; q++)
+        for (int j = 0; j <= s; j++) h->rkc_host[(size_t)q * RKC_LD + j] = (float)tab[(size_t)q * (s + 1) + j];
+    // 1 - mu_j - nu_j (~ 1/s^2: formed in double — in float32 the cancellation would cost four digits of the Y_0 weight)
+    for (int j = 0; j <= s; j++) h->rkc_host[(size_t)5 * RKC_LD + j] = (float)(1.0 - tab[j] - tab[(size_t)(s + 1) + j]);
+    // (the previous table may still be read by kernels in flight on the stream; the host vector is reused, so the copy is completed before returning)
+    if (hipMemcpyAsync(h->d_rkc, h->rkc_host.data(), h->rkc_host.size() * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+        return fail("uploading the RKC coefficient table failed");
+    h->m.nst = s;
+    return 0;
+}
+
 extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     if (!out) return fail("null out pointer");
     *out = nullptr;
@@ -367,21 +392,12 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
     h->m.nst = 4;
     h->m.rkc = nullptr;
     if (cfg->stepper == COLNDE_STEPPER_RKC2) {
-        const int s = colnde_rkc_stages(&h->cfg);
-        std::vector<double> tab;
-        rkc_tables(s, &tab);
-        std::vector<float> ft((size_t)6 * RKC_LD, 0.0f);
-        for (int q = 0; q < 5; q++)
-            for (int j = 0; j <= s; j++) ft[(size_t)q * RKC_LD + j] = (float)tab[(size_t)q * (s + 1) + j];
-        // 1 - mu_j - nu_j (~ 1/s^2: formed in double — in float32 the cancellation would cost four digits of the Y_0 weight)
-        for (int j = 0; j <= s; j++) ft[(size_t)5 * RKC_LD + j] = (float)(1.0 - tab[j] - tab[(size_t)(s + 1) + j]);
-        if (hipMalloc((void**)&h->d_rkc, ft.size() * sizeof(float)) != hipSuccess ||
-            hipMemcpy(h->d_rkc, ft.data(), ft.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMalloc((void**)&h->d_rkc, (size_t)6 * RKC_LD * sizeof(float)) != hipSuccess) {
             delete h;
             return fail("allocating the RKC coefficient table failed");
         }
-        h->m.nst = s;
         h->m.rkc = h->d_rkc;
+        if (refresh_rkc(h)) { delete h; return 1; }
     }
     std::vector<TileDesc> tiles;
     std::vector<int> bz, bg;
@@ -805,9 +821,20 @@ static int check_stability(const colnde_handle* h) {
 
 static int choose_substeps_impl(colnde_handle* h, const float* d_weights, float reltol, int* chosen, float* estimate);
 
+// substeps = 0 picks the count from THIS handle's columns.  On a column shard (colnde_set_global_columns > the local count) every rank would settle on its
+// own count: the SUM-all-reduced gradient would mix discretisations and the tapes would differ per rank.  The sharded recipe is explicit:
+// colnde_choose_substeps on every rank, MAX over ranks, colnde_set_substeps (colnde.distributed.agree_substeps does exactly that).
+static int refuse_auto_on_a_shard(const colnde_handle* h) {
+    if (h->n_col_total > h->n_col)
+        return fail("substeps = 0 (chosen from reltol) on a column shard (%d of %lld columns): each rank would choose its own count — call colnde_choose_substeps "
+                    "on every rank, take the MAX over ranks and impose it with colnde_set_substeps", h->n_col, (long long)h->n_col_total);
+    return 0;
+}
+
 static int forward_impl(colnde_handle* h, const float* d_weights, float* d_sol, bool with_tape) {
     if (!h->have_problem) return fail("colnde_set_problem has not been called");
     if (h->auto_substeps) {           // substeps = 0 at creation: settle the count now, from these weights and cfg.reltol
+        if (refuse_auto_on_a_shard(h)) return 1;
         h->auto_substeps = false;
         if (choose_substeps_impl(h, d_weights, h->cfg.reltol, nullptr, nullptr)) { h->auto_substeps = true; return 1; }
     }
@@ -1103,6 +1130,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
     HIPCHK(hipSetDevice(h->device));
     if (h->auto_substeps) {
         if (!h->have_problem) return fail("colnde_set_problem has not been called");
+        if (refuse_auto_on_a_shard(h)) return 1;
         h->auto_substeps = false;
         if (choose_substeps_impl(h, d_weights, h->cfg.reltol, nullptr, nullptr)) { h->auto_substeps = true; return 1; }
     }
@@ -1303,23 +1331,35 @@ static int forward_at(colnde_handle* h, const float* d_weights, float* d_sol, in
     h->cfg.substeps = substeps;
     const bool au = h->auto_substeps;
     h->auto_substeps = false;
-    const int rc = forward_impl(h, d_weights, d_sol, false);
+    int rc = refresh_rkc(h);
+    if (!rc) rc = forward_impl(h, d_weights, d_sol, false);
     h->cfg.substeps = keep;
     h->auto_substeps = au;
+    if (refresh_rkc(h)) rc = 1;
     return rc;
 }
 
 static int tapes_planned(const colnde_handle* h) { return h->d_rt_tape || h->d_dwtape || h->d_tape; }
 
 // estimate at `substeps` given its solution d_a; d_b receives the solution at 2 x substeps; *d_est (device) the estimate
-static int estimate_from(colnde_handle* h, const float* d_weights, const float* d_a, float* d_b, int substeps, float* d_est) {
+static int estimate_from(colnde_handle* h, const float* d_weights, const float* d_a, float* d_b, int substeps, float* d_est, float floor_) {
     if (forward_at(h, d_weights, d_b, 2 * substeps)) return 1;
-    hipError_t e = launch_rel_diff_max(d_a, d_b, (long)h->n_col * h->cfg.n_save, h->m.ns, 1e-3f, h->d_partial, d_est, h->stream);
+    hipError_t e = launch_rel_diff_max(d_a, d_b, (long)h->n_col * h->cfg.n_save, h->m.ns, floor_, h->d_partial, d_est, h->stream);
     if (e != hipSuccess) return fail("error-estimate launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 
-static float richardson_factor(const colnde_handle* h) { return h->cfg.stepper == COLNDE_STEPPER_RKC2 ? 4.0f / 3.0f : 16.0f / 15.0f; }
+// 2^p / (2^p - 1) with the order the right-hand side lets the stepper reach: a SWITCHING right-hand side (ConvectiveAdjustmentNDE's min(0, K dT/dz),
+// the wind-mixing convective-adjustment branch) converges at about first order through its kinks whatever the stepper's nominal order (measured:
+// profiles/r05_rkc2_conditioning.json), so the conservative factor 2 is used there (p = 4 / 2 understated the error by up to 2x);
+// smooth closures keep p = 4 (RK4) and p = 2 (RKC2).
+static float richardson_factor(const colnde_handle* h) {
+    if (h->m.ca || h->cfg.model == COLNDE_MODEL_CONV_ADJ_NDE) return 2.0f;
+    return h->cfg.stepper == COLNDE_STEPPER_RKC2 ? 4.0f / 3.0f : 16.0f / 15.0f;
+}
+// abstol / reltol of the integrator's accept test rms(err / (abstol + reltol |u|)) <= 1, OrdinaryDiffEq's default abstol = 1e-6: 1e-3 at the wind-mixing
+// reltol = 1e-3 (NDE_training.jl:291), 1e-2 at free convection's 1e-4 (solve.jl:4)
+static float norm_floor(float reltol) { return 1e-6f / (reltol > 0.0f ? reltol : 1e-3f); }
 
 extern "C" int colnde_error_estimate_dev(colnde_handle* h, const float* d_weights, float* max_rel_err) {
     if (!h) return fail("null handle");
@@ -1330,7 +1370,7 @@ extern "C" int colnde_error_estimate_dev(colnde_handle* h, const float* d_weight
     float* d_b = nullptr;
     HIPCHK(hipMalloc((void**)&d_b, (n + 4) * sizeof(float)));
     int rc = forward_at(h, d_weights, h->d_sol, h->cfg.substeps);
-    if (!rc) rc = estimate_from(h, d_weights, h->d_sol, d_b, h->cfg.substeps, d_b + n);
+    if (!rc) rc = estimate_from(h, d_weights, h->d_sol, d_b, h->cfg.substeps, d_b + n, norm_floor(h->cfg.reltol));
     float est = 0.0f;
     if (!rc && (hipMemcpyAsync(&est, d_b + n, sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess))
         rc = fail("error estimate: device-to-host copy failed");
@@ -1364,7 +1404,7 @@ static int choose_substeps_impl(colnde_handle* h, const float* d_weights, float 
     int cur = 0;
     bool floor_hit = false;
     while (!rc) {
-        rc = estimate_from(h, d_weights, buf[cur], buf[cur ^ 1], S, d_b + 2 * n);
+        rc = estimate_from(h, d_weights, buf[cur], buf[cur ^ 1], S, d_b + 2 * n, norm_floor(reltol));
         if (rc) break;
         float e = 0.0f;
         if (hipMemcpyAsync(&e, d_b + 2 * n, sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
@@ -1389,7 +1429,9 @@ static int choose_substeps_impl(colnde_handle* h, const float* d_weights, float 
                                "%g at half as many)", reltol, est, S, prev);
     if (est > reltol) return fail("reltol = %g is not met with %d sub-steps per save interval (estimate %g): the right-hand side is too stiff for this stepper", reltol, S, est);
     h->cfg.substeps = S;
+    if (refresh_rkc(h)) return 1;
     h->last_estimate = est;
+    h->substeps_chosen = true;
     if (chosen) *chosen = S;
     if (estimate) *estimate = est;
     return 0;
@@ -1409,6 +1451,26 @@ extern "C" int colnde_choose_substeps(colnde_handle* h, const float* weights, fl
 }
 
 extern "C" int colnde_substeps(const colnde_handle* h) { return h ? h->cfg.substeps : -1; }
+
+// Impose a sub-step count (e.g. the MAX over ranks of what colnde_choose_substeps chose on each shard).  Refused once the tapes are planned (the count
+// sizes them) and outside the stepper's stability bound; clears a pending substeps = 0.
+extern "C" int colnde_set_substeps(colnde_handle* h, int substeps) {
+    if (!h) return fail("null handle");
+    if (substeps < 1) return fail("substeps must be >= 1");
+    if (substeps == h->cfg.substeps && !h->auto_substeps) return 0;
+    if (tapes_planned(h)) return fail("the sub-step count sizes the tapes: set it before the first colnde_loss_grad of this handle");
+    colnde_config c = h->cfg;
+    c.substeps = substeps;
+    const int need = colnde_min_substeps(&c);
+    if (need < 0) return 1;
+    if (substeps < need && !getenv("COLNDE_ALLOW_UNSTABLE_DT"))
+        return fail("substeps = %d is outside the stepper's stability bound: need >= %d (colnde_min_substeps)", substeps, need);
+    h->cfg.substeps = substeps;
+    h->auto_substeps = false;
+    h->substeps_chosen = false;
+    h->last_estimate = -1.0f;
+    return refresh_rkc(h);
+}
 
 // ---- flux diagnostics: predict_flux and loss_per_tstep ---------------------------------------------------------------------------------
 extern "C" int colnde_flux_dev(colnde_handle* h, const float* d_x, const float* d_weights, const float* d_bcs, float t, float* d_flux, int n_columns) {
@@ -1781,8 +1843,11 @@ extern "C" int colnde_describe(const colnde_handle* h, char* buf, int capacity) 
     std::string s;
     char t[256];
     const char* eng = info[0] == COLNDE_ENGINE_MFMA ? "regtile" : info[0] == COLNDE_ENGINE_FC32 ? "fc32" : ((info[6] & 1) ? "tile16+net-split" : "tile16");
+    char why[96] = "";
+    if (h->auto_substeps) snprintf(why, sizeof why, "(stability bound; pending: the first solve chooses from reltol=%g)", h->cfg.reltol);
+    else if (h->substeps_chosen) snprintf(why, sizeof why, "(chosen from reltol, estimate=%.3g)", h->last_estimate);
     snprintf(t, sizeof t, "engine=%s columns=%d stepper=%s substeps=%d%s", eng, h->cfg.n_columns, h->cfg.stepper == COLNDE_STEPPER_RKC2 ? "rkc2" : "rk4",
-             h->cfg.substeps, h->auto_substeps ? "(chosen from reltol)" : "");
+             h->cfg.substeps, why);
     s += t;
     if (h->cfg.stepper == COLNDE_STEPPER_RKC2) { snprintf(t, sizeof t, " rkc_stages=%d%s", h->m.nst, h->cfg.rkc_stages ? "" : "(automatic)"); s += t; }
     snprintf(t, sizeof t, " matrix_arithmetic=%s forward=%s adjoint=%s dw=%s", h->cfg.matrix_arithmetic == COLNDE_MATRIX_BF16X3_EXACT ? "bf16x3_exact" : "f32_mfma",
@@ -1804,6 +1869,14 @@ extern "C" int colnde_describe(const colnde_handle* h, char* buf, int capacity) 
         if (e && *e) { s += " "; s += name; s += "="; s += e; any = true; }
     }
     if (!any) s += " (none set)";
+    // an environment override that contradicts the arithmetic selected through the API (colnde_config.matrix_arithmetic / colnde_set_matrix_arithmetic) wins —
+    // say so, by name (it used to outrank the API call silently)
+    {
+        const bool split = h->cfg.matrix_arithmetic == COLNDE_MATRIX_BF16X3_EXACT;
+        const struct { const char* name; bool v; } fam[3] = {{"COLNDE_FWD_SPLIT", h->sp_fwd}, {"COLNDE_ADJ_SPLIT", h->sp_adj}, {"COLNDE_DW_SPLIT", h->sp_dw}};
+        for (const auto& f : fam)
+            if (f.v != split) { snprintf(t, sizeof t, " | WARNING %s=%d overrides matrix_arithmetic=%s for its kernels", f.name, f.v ? 1 : 0, split ? "bf16x3_exact" : "f32_mfma"); s += t; }
+    }
     const int need = (int)s.size() + 1;
     if (buf && capacity > 0) {
         const int n = need <= capacity ? need - 1 : capacity - 1;

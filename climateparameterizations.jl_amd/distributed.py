@@ -181,3 +181,24 @@ def weights_in_sync(theta, rank_allreduce_max, tol: float = 0.0):
     t = t.cpu()
     spread = float((t[:6] + t[6:]).abs().max())
     return spread <= tol, spread
+
+
+def agree_substeps(choose_local, impose, rank_allreduce_max, device=None) -> int:
+    """One sub-step count for every rank of a column-sharded run.  `substeps = 0` / `colnde_choose_substeps` pick the count from the
+    columns a handle holds, so ranks would settle on different counts: the SUM-all-reduced gradient would mix discretisations, step times would be
+    unbalanced and tape sizes differ per rank — a handle that holds a shard therefore refuses the automatic choice.  The recipe instead:
+
+        agree_substeps(lambda: nde.choose_substeps(w, reltol)[0], nde.set_substeps, lambda t: comm.allreduce(t, "max"))
+
+    every rank chooses from its shard (`choose_local() -> int`), ONE 1-element MAX all-reduce (`rank_allreduce_max(t)` reduces the float32
+    tensor in place: Comm.allreduce(t, "max") or torch.distributed.all_reduce with ReduceOp.MAX), every rank imposes the maximum
+    (`impose(count)` = `ColumnNDE.set_substeps`).  Before the first `loss_grad` of the handle.  Returns the agreed count."""
+    import torch
+    local = int(choose_local())
+    t = torch.tensor([float(local)], dtype=torch.float32, device=device)
+    rank_allreduce_max(t)
+    agreed = int(round(float(t.cpu()[0])))
+    if agreed < local:
+        raise RuntimeError("agree_substeps: the MAX over ranks (%d) is below this rank's own count (%d)" % (agreed, local))
+    impose(agreed)
+    return agreed

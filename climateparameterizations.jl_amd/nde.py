@@ -260,6 +260,16 @@ class ColumnNDE:
         """Sub-steps per save interval in use (cfg.substeps, or what the handle chose from reltol)."""
         return int(self._L.colnde_substeps(self._h))
 
+    def set_substeps(self, substeps: int) -> None:
+        """colnde_set_substeps: impose a sub-step count (the MAX over ranks of what each shard chose — colnde.distributed.agree_substeps); before the
+        first loss_grad of this handle."""
+        _lib.check(self._L.colnde_set_substeps(self._h, int(substeps)))
+
+    @property
+    def n_steps(self) -> int:
+        """Time steps of one solve with the sub-step count IN USE (cfg.n_steps is 0 for a config created with substeps = 0)."""
+        return (self.cfg.n_save - 1) * self.substeps
+
     def error_estimate(self, weights) -> float:
         """Richardson estimate of the solve's error at the current sub-step count against one at twice the count, in the integrator's mixed norm
         max |e| / (1e-3 + |u|) (include/colnde.h: colnde_error_estimate) — what `reltol` bounds."""

@@ -155,10 +155,13 @@ int colnde_forward(colnde_handle* h, const float* weights, float* sol);
 /* ---- what `reltol` means here.  The reference integrates with an ADAPTIVE stepper (solve(prob, ROCK4(); reltol=1f-3, saveat=...): wind_mixing/src/
  * NDE_training.jl:291,304,403; reltol=1e-4: free_convection/src/solve.jl:4); this path steps at a fixed `substeps` per save interval, and the tolerance is
  * enforced a posteriori.  colnde_error_estimate: one more forward solve at 2 x substeps and Richardson's estimate of the error of the solve at `substeps`,
- *   e = (u_S - u_2S) 2^p / (2^p - 1)   (p = 4: RK4, p = 2: RKC2),   *max_rel_err = max over columns and save points of rms_i(e_i / (1e-3 + |u_i|))
- * (rms over the state's components) — the integrator's accept test rms(err / (abstol + reltol |u|)) <= 1 with OrdinaryDiffEq's default abstol = 1e-6
- * and the reference's reltol = 1e-3, divided through by reltol, applied to the whole save interval instead of one adaptive step; +inf when a solve
- * is not finite.  colnde_choose_substeps: the least
+ *   e = (u_S - u_2S) 2^p / (2^p - 1),   *max_rel_err = max over columns and save points of rms_i(e_i / (abstol / reltol + |u_i|))
+ * (rms over the state's components) — the integrator's accept test rms(err / (abstol + reltol |u|)) <= 1 with OrdinaryDiffEq's default abstol = 1e-6,
+ * divided through by reltol, applied to the whole save interval instead of one adaptive step; +inf when a solve is not finite.  The floor
+ * abstol / reltol follows the tolerance in force (cfg.reltol for colnde_error_estimate, the argument for colnde_choose_substeps): 1e-3 at wind mixing's
+ * reltol = 1e-3, 1e-2 at free convection's 1e-4.  p is the order the RIGHT-HAND SIDE lets the stepper reach: 4 (RK4) and 2 (RKC2) for smooth closures,
+ * 1 (factor 2) for the switching ones — ConvectiveAdjustmentNDE's min(0, K dT/dz) and the wind-mixing convective-adjustment branch converge at about
+ * first order through their kinks whatever the stepper (measured: profiles/r05_rkc2_conditioning.json).  colnde_choose_substeps: the least
  * power-of-two sub-step count, not below colnde_min_substeps, whose estimate is <= reltol (reltol <= 0: cfg.reltol); the handle keeps it (call it before
  * the first colnde_loss_grad: the sub-step count sizes the tapes).  A handle created with substeps = 0 does this by itself in its first solve call, with
  * the weights of that call; later calls reuse the count (a training loop re-checks with colnde_error_estimate when it wants to).  colnde_substeps: the
@@ -169,6 +172,15 @@ int colnde_error_estimate(colnde_handle* h, const float* weights, float* max_rel
 int colnde_error_estimate_dev(colnde_handle* h, const float* d_weights, float* max_rel_err /* host */);
 int colnde_choose_substeps(colnde_handle* h, const float* weights, float reltol, int* substeps /* nullable */, float* estimate /* nullable */);
 int colnde_substeps(const colnde_handle* h);
+/* Impose a sub-step count.  The column-sharded recipe (one handle per GPU, colnde_set_global_columns): substeps = 0 would let every rank choose from its own
+ * columns — the SUM-all-reduced gradient would mix discretisations and the tapes would differ per rank — so a handle that knows it holds a shard REFUSES the
+ * automatic choice; instead every rank calls colnde_choose_substeps, the host takes the MAX over ranks (one MAX all-reduce of one integer) and every rank
+ * calls colnde_set_substeps with it.  Refused once the gradient path has sized its tapes, and outside the stability bound (colnde_min_substeps).  With the
+ * RKC2 stepper and rkc_stages = 0 the stage count follows the new step (the least s with 0.9 beta(s) >= lambda dt), as it does inside
+ * colnde_choose_substeps / colnde_error_estimate.  Float32 and the stage count: at a FIXED step, 17 ... 136 stages stand equally far from float64 (the
+ * increment-form recurrence is internally stable); what separates float32 from float64 on ConvectiveAdjustmentNDE is the switch, and it shrinks with the
+ * STEP, not the stage count — see the table in DESIGN section 2 (tools/rkc_conditioning.py). */
+int colnde_set_substeps(colnde_handle* h, int substeps);
 
 /* predict_flux(uvT, BCs, ...) (wind_mixing/src/NDE_training.jl:83-147; exported at wind_mixing/src/WindMixing.jl:6): the face fluxes whose divergence the
  * RHS takes — uw, vw, wT on the Nz + 1 faces, NN output minus the closure's diffusive flux (MPP) or convective-adjustment flux, boundary faces as the

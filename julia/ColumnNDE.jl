@@ -239,6 +239,8 @@ function choose_substeps!(h::Handle, weights::Vector{Float32}, reltol=0f0)
     Int(s[]), est[]
 end
 substeps(h::Handle) = ccall((:colnde_substeps, libcolnde), Cint, (Ptr{Cvoid},), h.ptr)
+"impose a sub-step count (column shards: choose_substeps! on every rank, MAX over ranks, set_substeps! — colnde_set_substeps)"
+set_substeps!(h::Handle, n::Integer) = (check(ccall((:colnde_set_substeps, libcolnde), Cint, (Ptr{Cvoid}, Cint), h.ptr, n)); h)
 
 "+∂z wT as compute_neural_network_forcing! stores it in params.∂z_wT_NN (double_gyre_nn.jl:165; the forcing function negates it, :135)"
 function compute_∂z_wT!(dz_wT::Matrix{Float32}, h::Handle, weights::Vector{Float32}, T_interior::Matrix{Float32}, surface_flux::Vector{Float32}, Lz)
@@ -282,7 +284,12 @@ function reference_closures(h::Handle, loss_scalings::NamedTuple=(u=1f0, v=1f0, 
     (NDE=(x, p, t) -> NDE(h, x, p, t),
      NDE! =(dx, x, p, t) -> NDE!(h, dx, x, p, t),
      ∂T∂t=(T, p, t) -> ∂T∂t(h, T, p, t),
-     loss_NDE=(weights, BCs) -> loss_gradient_NDE(h, weights, loss_scalings),
+     # loss_NDE (NDE_training.jl:290-301, the train_gradient = false objective) sets ∂u∂z = ∂v∂z = ∂T∂z = 0 before the scalings are applied
+     # (and it returns the UNCHANGED loss_scalings as its third value, :300)
+     loss_NDE=(weights, BCs) -> begin
+         total, scaled, _ = loss_gradient_NDE(h, weights, merge(loss_scalings, (∂u∂z=0f0, ∂v∂z=0f0, ∂T∂z=0f0)))
+         (total, scaled, loss_scalings)
+     end,
      loss_gradient_NDE=(weights, BCs) -> loss_gradient_NDE(h, weights, loss_scalings))
 end
 

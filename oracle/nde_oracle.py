@@ -397,16 +397,21 @@ def loss_per_tstep(cfg, sol, truth):
     return out
 
 
-def error_estimate(cfg, x0, bcs, theta, dtype=np.float64):
+def error_estimate(cfg, x0, bcs, theta, dtype=np.float64, reltol=None):
     """Richardson estimate of the error of the solve at cfg.substeps from one at twice as many (what colnde_error_estimate returns):
-    e = (u_S - u_2S) 2^p / (2^p - 1), p = 4 (RK4) or 2 (RKC2); per column and save point rms_i(e_i / (1e-3 + |u_2S,i|)), then the maximum — the adaptive
-    integrator's accept test rms(err / (abstol + reltol |u|)) <= 1 with OrdinaryDiffEq's default abstol = 1e-6 over the reference's reltol = 1e-3
-    (NDE_training.jl:291), divided through by reltol."""
+    e = (u_S - u_2S) 2^p / (2^p - 1); per column and save point rms_i(e_i / (abstol / reltol + |u_2S,i|)), then the maximum — the adaptive
+    integrator's accept test rms(err / (abstol + reltol |u|)) <= 1 with OrdinaryDiffEq's default abstol = 1e-6, divided through by reltol
+    (`reltol` = the tolerance in force: cfg.reltol, 0 = the reference's 1e-3 of NDE_training.jl:291; 1e-4 at free_convection/src/solve.jl:4).
+    p = the order the right-hand side lets the stepper reach: 4 (RK4), 2 (RKC2), and 1 for the switching closures (ConvectiveAdjustmentNDE, the
+    wind-mixing convective-adjustment branch), which converge at about first order through their kinks."""
     from dataclasses import replace
     a = solve(cfg, x0, bcs, theta, dtype=dtype)
     b = solve(replace(cfg, substeps=2 * cfg.substeps), x0, bcs, theta, dtype=dtype)
-    p = 2 if cfg.stepper == "rkc2" else 4
-    q = (a - b) / (1e-3 + np.abs(b))
+    switching = cfg.model == CONVECTIVE_ADJUSTMENT_NDE or (cfg.model == WIND_MIXING and cfg.convective_adjustment)
+    p = 1 if switching else (2 if cfg.stepper == "rkc2" else 4)
+    if reltol is None:
+        reltol = getattr(cfg, "reltol", 0.0) or 1e-3
+    q = (a - b) / (1e-6 / reltol + np.abs(b))
     return float(np.max(np.sqrt(np.mean(q * q, axis=-1)))) * 2 ** p / (2 ** p - 1)      # rms over the state's components, max over columns and save points
 
 

@@ -51,14 +51,16 @@ def train_NDE(cfg, x0, bcs, truth, weights, scalings, etas, epochs=1, maxiters=5
     return theta, hist
 
 
-def train_neural_differential_equation(cfg, x0, bcs, truth, weights, eta, epochs, beta=(0.9, 0.999), eps=1e-8):
-    """free_convection/src/training.jl:55-71: loss = Flux.mse over the concatenated solutions; `epochs` ADAM steps on one state."""
+def train_neural_differential_equation(cfg, x0, bcs, truth, weights, eta, epochs, beta=(0.9, 0.999), eps=1e-8, dtype=np.float64):
+    """free_convection/src/training.jl:55-71: loss = Flux.mse over the concatenated solutions; `epochs` ADAM steps on one state.
+    dtype = np.float32: the solve and its adjoint in float32 (the optimiser stays float64) — the scale of what float32 itself does to a trajectory
+    through ConvectiveAdjustmentNDE's switch."""
     theta = np.asarray(weights, np.float64).copy()
     m, v, bt = np.zeros_like(theta), np.zeros_like(theta), (beta[0], beta[1])
     hist = []
     sc = np.array([0, 0, 1.0, 0, 0, 0])
     for _ in range(epochs):
-        total, _, g, _ = O.loss_and_grad(cfg, x0, bcs, theta, truth, sc)
+        total, _, g, _ = O.loss_and_grad(cfg, x0, bcs, theta, truth, sc, dtype=dtype)
         hist.append(float(total))
-        theta, m, v, bt = O.adam_step(theta, g, m, v, eta, beta, eps, bt)
+        theta, m, v, bt = O.adam_step(theta, np.asarray(g, np.float64), m, v, eta, beta, eps, bt)
     return theta, hist

@@ -18,6 +18,12 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+# `make -C climateparameterizations.jl_amd/csrc asan_test`: the same suite against the host-sanitizer build of the library (COLNDE_LIB=libcolnde_asan.so)
+if os.environ.get("COLNDE_LIB"):
+    from colnde import _lib as _colnde_lib
+    _colnde_lib.LIB_PATH = os.path.join(ROOT, "climateparameterizations.jl_amd", os.environ["COLNDE_LIB"])
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 import colnde
 from colnde import synthetic
-from colnde.distributed import shard_columns, allreduce_loss_grad, split_result, weights_in_sync
+from colnde.distributed import shard_columns, allreduce_loss_grad, split_result, weights_in_sync, agree_substeps
 from oracle import cref, nde_oracle as O
 
 N_COL = 7   # deliberately not divisible by the world size (ragged shards)
@@ -105,3 +105,22 @@ def test_two_rank_weight_divergence_guard(tmp_path):
         assert same_ok == 1.0 and same_spread == 0.0
         assert ulp_ok == 0.0 and ulp_spread > 0.0
         assert swapped_ok == 0.0
+
+
+def _substeps_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    imposed = []
+    got = agree_substeps(lambda: (4, 16)[rank], imposed.append, lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX))
+    np.save(os.path.join(out_dir, "sub%d.npy" % rank), np.array([got] + imposed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_agree_on_one_substep_count(tmp_path):
+    """shards that would choose 4 and 16 sub-steps from their own columns both end up imposing 16 (one MAX all-reduce of one number)."""
+    world = 2
+    mp.spawn(_substeps_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(tmp_path / ("sub%d.npy" % r)).tolist() == [16, 16]

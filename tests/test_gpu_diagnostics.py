@@ -135,10 +135,14 @@ def test_choose_substeps_and_the_automatic_mode():
             assert np.abs(nde.forward(p.weights) - ref).max() < SOL_ATOL
             S2, _ = nde.choose_substeps(p.weights, 2e-4)                     # a tighter tolerance: more sub-steps
             assert S2 > want and nde.substeps == S2
-            # float32 solves resolve ~1e-4 in this norm (it divides by 1e-3 + |u|, and round-off grows with the step count): a tolerance below that
-            # is refused with the floor named, not chased to thousands of sub-steps
-            with pytest.raises(colnde.ColndeError, match="round-off floor"):
-                nde.choose_substeps(p.weights, 1e-6)
+            # A tolerance float32 cannot resolve is refused with the floor named, not chased to thousands of sub-steps.  Since round 5 the norm's floor is
+            # abstol / reltol of the tolerance ASKED for (1e-6 / reltol, OrdinaryDiffEq's abstol = 1e-6): at reltol = 1e-6 the test is |e| <= 1e-6 (1 + |u|),
+            # which float32 round-off of these O(1) profiles meets or misses by a hair — either a count whose estimate meets it, or the named refusal
+            try:
+                S3, est3 = nde.choose_substeps(p.weights, 1e-6)
+                assert S3 >= S2 and 0 < est3 <= 1e-6
+            except colnde.ColndeError as e:
+                assert "round-off floor" in str(e)
         auto = p.cfg.with_(substeps=0, reltol=1e-3)
         with colnde.ColumnNDE(auto, 24) as nde:
             nde.set_problem(p.x0, p.bcs)
@@ -158,8 +162,8 @@ def test_choose_substeps_and_the_automatic_mode():
 
 def test_error_estimate_and_choice_for_the_free_convection_models():
     """The same boundary for `solve_nde` (free_convection/src/solve.jl:4, reltol = 1e-4).  ConvectiveAdjustmentNDE under the stabilised RKC2 stepper (second order:
-    Richardson factor 4/3; the switch makes the error large and its convergence first-order — 0.32 at 4 steps per save interval, 0.12 at 8, 0.05 at 16 on
-    these 40 columns): the estimate agrees with the float64 oracle's within 2x, and a tolerance of 0.2 chooses what the oracle's estimates choose.  FreeConvectionNDE under RK4 is smooth: its error at ONE sub-step (3e-7) is far below
+    the switch makes the error large and its convergence first-order — 0.32 at 4 steps per save interval, 0.12 at 8, 0.05 at 16 on these 40 columns under
+    the second-order factor 4/3 — so the estimate uses the first-order factor 2): the estimate agrees with the float64 oracle's within 2x, and a tolerance of 0.5 chooses what the oracle's estimates choose.  FreeConvectionNDE under RK4 is smooth: its error at ONE sub-step (3e-7) is far below
     the reference's tolerance, and the choice is the stability bound itself."""
     p = synthetic.free_convection_problem(40, Nz=32, n_save=5, convective_adjustment=True)
     est64 = {}
@@ -172,12 +176,17 @@ def test_error_estimate_and_choice_for_the_free_convection_models():
                 est = nde.error_estimate(p.weights)
             _record("error_estimate/rkc2/%d" % S, estimate=est, oracle_estimate=est64[S])
             assert 0.5 * est64[S] < est < 2.0 * est64[S], (S, est, est64[S])
-    want = min(S for S, e in est64.items() if e <= 0.2)
-    assert want > 1 and not any(0.16 < e < 0.25 for e in est64.values())
+    # colnde_choose_substeps(…, reltol) measures in the norm of THAT tolerance: floor abstol / reltol = 1e-6 / 0.5
+    est_at = {S: O.error_estimate(p.cfg.with_(stepper="rkc2", substeps=S), p.x0, p.bcs, p.weights, reltol=0.5) for S in (1, 2, 4, 8, 16)}
+    want = min(S for S, e in est_at.items() if e <= 0.5)
+    assert want > 1 and not any(0.4 < e < 0.625 for e in est_at.values()), est_at
     with colnde.ColumnNDE(p.cfg.with_(stepper="rkc2", substeps=1), 40) as nde:
         nde.set_problem(p.x0, p.bcs)
-        S, est = nde.choose_substeps(p.weights, 0.2)
-        assert S == want == nde.substeps and est <= 0.2
+        S, est = nde.choose_substeps(p.weights, 0.5)
+        assert S == want == nde.substeps and est <= 0.5
+        # rkc_stages = 0: the stage count followed the step the handle settled on (created at 1 step per interval: 93 stages; now the count of `want`)
+        assert "rkc_stages=%d(automatic)" % colnde.rkc_stages(p.cfg.with_(stepper="rkc2", substeps=want)) in nde.describe()
+        assert "(chosen from reltol, estimate=" in nde.describe()
     p = synthetic.free_convection_problem(40, Nz=32, n_save=5)
     need = colnde.min_substeps(p.cfg)
     with colnde.ColumnNDE(p.cfg.with_(substeps=max(need, 1)), 40) as nde:
@@ -198,3 +207,50 @@ def test_error_estimate_reports_a_non_finite_solve_as_infinite():
         assert nde.error_estimate(p.weights) == np.inf
         with pytest.raises(colnde.ColndeError, match="not finite"):
             nde.choose_substeps(p.weights, 1e-3)
+
+
+def test_set_substeps_and_the_shard_rule():
+    """a handle that holds a column SHARD (colnde_set_global_columns > its own count) refuses the automatic choice of `substeps = 0` — every rank
+    would settle on its own count — and takes the agreed one through colnde_set_substeps (colnde.distributed.agree_substeps: choose on every rank, MAX over
+    ranks, impose).  colnde_set_substeps is refused outside the stability bound and once the tapes are planned; colnde_describe says where the count in
+    use came from."""
+    from colnde.distributed import agree_substeps
+    sc = [1, 1, 1, 5e-3, 5e-3, 5e-3]
+    p = synthetic.wind_mixing_problem(24, n_frames=9, weight_divisor=1.5)
+    auto = p.cfg.with_(substeps=0, reltol=1e-3)
+    with colnde.ColumnNDE(auto, 24) as nde:
+        assert "pending: the first solve chooses from reltol=0.001" in nde.describe() and nde.n_steps == 8 * nde.substeps
+        nde.set_global_columns(48)                                           # this handle is one of two shards
+        nde.set_problem(p.x0, p.bcs)
+        with pytest.raises(colnde.ColndeError, match="column shard"):
+            nde.forward(p.weights)
+        # the recipe: this rank's own choice is 4; the other rank's (a stand-in for the MAX all-reduce) is 8
+        def fake_max(t):
+            t.fill_(max(float(t[0]), 8.0))
+        agreed = agree_substeps(lambda: nde.choose_substeps(p.weights, 1e-3)[0], nde.set_substeps, fake_max)
+        assert agreed == 8 and nde.substeps == 8 and nde.n_steps == 64
+        assert "substeps=8 " in nde.describe() and "chosen from reltol" not in nde.describe()        # imposed, not chosen
+        ref = O.solve(p.cfg.with_(substeps=8), p.x0, p.bcs, p.weights)
+        assert np.abs(nde.forward(p.weights) - ref).max() < SOL_ATOL
+        with pytest.raises(colnde.ColndeError, match="stability bound"):
+            nde.set_substeps(1)
+        truth = nde.forward(p.weights_truth)
+        nde.set_problem(p.x0, p.bcs, truth)
+        tot, _, grad = nde.loss_grad(p.weights, sc)
+        g = O.loss_and_grad(p.cfg.with_(substeps=8), p.x0, p.bcs, p.weights, truth, np.array(sc, float), n_col_total=48)[2]
+        assert _rel(grad, g) < 2e-3
+        with pytest.raises(colnde.ColndeError, match="sizes the tapes"):
+            nde.set_substeps(16)
+        nde.set_substeps(8)                                                  # the count already in use: accepted
+
+
+def test_describe_names_an_environment_override_that_outranks_the_api(monkeypatch):
+    """COLNDE_{FWD,ADJ,DW}_SPLIT outrank colnde_set_matrix_arithmetic; colnde_describe now says so."""
+    p = synthetic.wind_mixing_problem(24, n_frames=3)
+    with colnde.ColumnNDE(p.cfg, 24) as nde:
+        assert "WARNING" not in nde.describe()
+    monkeypatch.setenv("COLNDE_ADJ_SPLIT", "0")
+    with colnde.ColumnNDE(p.cfg, 24) as nde:
+        assert "WARNING COLNDE_ADJ_SPLIT=0 overrides matrix_arithmetic=bf16x3_exact" in nde.describe()
+        nde.set_matrix_arithmetic("f32_mfma")
+        assert "WARNING" not in nde.describe()

@@ -24,13 +24,16 @@ def _free_bytes():
 def _cases():
     wm = synthetic.wind_mixing_problem(70, n_frames=5, weight_divisor=1e2)
     fc = synthetic.free_convection_problem(70, Nz=32, n_save=9)
-    ca = synthetic.free_convection_problem(40, Nz=64, n_save=5, convective_adjustment=True)
+    # ConvectiveAdjustmentNDE at the step bench.py's configs[3] shard takes (save interval 1/128, 4 RKC2 steps of 17 stages: dt = 1/512).  Round 4 ran this case
+    # at dt = 1/8 (2 steps of 132 stages over intervals of 1/4) and had to allow the two arithmetics 2e-2 apart: that step is 400x from converged
+    # (profiles/r05_rkc2_conditioning.json) — the discrete dynamics flips switches on round-off — and the stage count has nothing to do with it
+    ca = synthetic.free_convection_problem(40, Nz=64, n_save=5, t_end=4.0 / 128.0, convective_adjustment=True)
     return [
         ("regtile", wm, wm.cfg, dict(engine=ENGINE_REGTILE), [1, 1, 1, 5e-3, 5e-3, 5e-3], {}),
         ("net-split (AUTO)", wm, wm.cfg, dict(), [1, 1, 1, 5e-3, 5e-3, 5e-3], {}),
         ("tile16, f32 MFMA", wm, wm.cfg, dict(engine=ENGINE_TILE16, matrix_arithmetic="f32_mfma"), [1, 1, 1, 0, 0, 0], {}),
         ("fc32, time segments + column blocks", fc, fc.cfg, dict(), [0, 0, 1, 0, 0, 0], {"COLNDE_FC_SEG": "3", "COLNDE_FC_BLOCK": "32"}),
-        ("fc32 64 levels, RKC2", ca, ca.cfg.with_(stepper="rkc2", substeps=2), dict(), [0, 0, 1, 0, 0, 0], {}),
+        ("fc32 64 levels, RKC2", ca, ca.cfg.with_(stepper="rkc2", substeps=4), dict(), [0, 0, 1, 0, 0, 0], {}),
     ]
 
 
@@ -47,15 +50,15 @@ def test_create_use_destroy_returns_all_device_memory(case, monkeypatch):
             truth = nde.forward(p.weights_truth)
             nde.set_problem(p.x0, p.bcs, truth)
             nde.error_estimate(p.weights)
-            if cfg.stepper != "rkc2":
-                nde.choose_substeps(p.weights, 0.5)                      # (before the tapes are planned)
+            nde.choose_substeps(p.weights, 0.5)                          # (before the tapes are planned; RKC2: the stage table follows the step)
+            if cfg.stepper == "rkc2":
+                nde.set_substeps(cfg.substeps)
             tot, terms, grad = nde.loss_grad(p.weights, sc)
             nde.set_matrix_arithmetic("f32_mfma" if nde.matrix_arithmetic == "bf16x3_exact" else "bf16x3_exact")
             tot2, _, grad2 = nde.loss_grad(p.weights, sc)
             nde.loss_per_tstep(p.weights)
-            # (the 64-level ConvectiveAdjustmentNDE case takes 132-stage RKC2 steps through live switches: float32 noise is amplified to percents there —
-            #  the float32 oracle stands 8 % from the float64 one — so the two arithmetics may differ by that much; elsewhere they agree to 1e-4)
-            assert np.isfinite(tot) and np.isfinite(grad).all() and abs(tot2 - tot) <= (2e-2 if cfg.stepper == "rkc2" else 1e-4) * abs(tot)
+            # the two arithmetics agree to 1e-4 in the loss (ConvectiveAdjustmentNDE through live switches: 1e-3)
+            assert np.isfinite(tot) and np.isfinite(grad).all() and abs(tot2 - tot) <= (1e-3 if cfg.stepper == "rkc2" else 1e-4) * abs(tot)
             return nde.describe()
 
     cycle()                                                              # (first use: the runtime's own pools, code objects)

@@ -34,8 +34,8 @@ FRACTIONS = dict(T=0.8, dTdz=0.8, profile=0.5)                  # train_NDE.jl:1
 ETA, ITERS = 3e-4, 5                                            # train_NDE.jl:140-141
 LOSS_SEQ_RTOL = 1e-4                                            # every iteration's loss against the float64 loop
 SCALINGS_RTOL = 1e-4
-THETA_REL_L2 = {"init_1e5": 2e-4, "init_1e2": 1e-5}             # ‖θ_K − θ_K^oracle‖ / ‖θ_K^oracle‖ (measured: see _record)
-THETA_MAX_STEP_UNITS = 0.5                                      # no single weight ends more than η/2 from the oracle's
+THETA_REL_L2 = {"init_1e5": 4e-4, "init_1e2": 1.5e-4}           # ‖θ_K − θ_K^oracle‖ / ‖θ_K^oracle‖ (measured 4.2e-5 / 1.4e-5: profiles/r05_parity_errors.json)
+THETA_MAX_STEP_UNITS = 0.05                                     # no single weight ends more than η/20 from the oracle's (measured 0.001 η / 0.003 η)
 
 
 def _rel(a, b):
@@ -104,6 +104,7 @@ def test_two_optimizers_two_epochs_follow_the_float64_loop():
         assert len(r.history) == 12
         np.testing.assert_allclose([h["total"] for h in r.history], lo, rtol=LOSS_SEQ_RTOL)
         assert _rel(r.weights, theta_o) < THETA_REL_L2["init_1e2"]
+        assert np.abs(r.weights.astype(np.float64) - theta_o).max() < 0.25 * 3e-4          # four solves, 12 updates: measured 0.06 η
 
 
 @pytest.mark.parametrize("Nz,ca", [(32, False), (32, True)])
@@ -111,8 +112,19 @@ def test_flux_train_trajectory_matches_the_float64_loop(Nz, ca):
     """`train_neural_differential_equation!` (free_convection/src/training.jl:44-74): 6 epochs of ADAM(1e-3) on the single MSE of the
     concatenated solutions, FreeConvectionNDE and ConvectiveAdjustmentNDE, host loop and device loop."""
     p = synthetic.free_convection_problem(6, Nz=Nz, n_save=9, substeps=4, t_end=0.0625, convective_adjustment=ca)
+    if ca:              # K = 10 is stiff (lambda dt = 40 here): the stabilised stepper, as the reference reaches for ROCK4 (test_free_convection_nde.jl:32-35)
+        p.cfg = p.cfg.with_(stepper="rkc2")
+        p.x0[:2, 10:22] = p.x0[:2, 10:22][:, ::-1].copy()       # two columns with an inverted layer: the min(0, K dT/dz) switch is live
     truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
     theta_o, hist_o = TO.train_neural_differential_equation(p.cfg, p.x0, p.bcs, truth, p.weights, 1e-3, 6)
+    gap_loss = gap_theta = 0.0
+    if ca:
+        # Through the live switch float32 ITSELF parts from float64 (DESIGN section 2: the side of min(0, K dT/dz) is decided by round-off on the faces of an
+        # adjusted layer): the same loop with a float32 solve + adjoint sets the scale, as in tests/test_gpu_fc.py (measured: 1.7e-2 on the loss
+        # sequence, 8.7e-2 on θ after 6 epochs — and the HIP path lands on the float32 loop, 1e-4 / 1e-2 from it)
+        theta_32, hist_32 = TO.train_neural_differential_equation(p.cfg, p.x0, p.bcs, truth, p.weights, 1e-3, 6, dtype=np.float32)
+        gap_loss = np.abs(np.array(hist_32) / np.array(hist_o) - 1).max()
+        gap_theta = _rel(theta_32, theta_o)
     for name, loop in (("host", train_neural_differential_equation), ("device", train_neural_differential_equation_device)):
         nde = FreeConvectionNDE(p.cfg, p.x0, p.bcs, truth)
         try:
@@ -121,7 +133,13 @@ def test_flux_train_trajectory_matches_the_float64_loop(Nz, ca):
             nde.close()
         e_loss = np.abs(np.array(hist) / np.array(hist_o) - 1).max()
         e_theta = _rel(theta, theta_o)
-        _record("training/flux_train_%s/Nz%d_ca%d" % (name, Nz, ca), loss_seq_rel=e_loss, theta_rel_l2=e_theta)
-        assert e_loss < 3e-3, (name, hist, hist_o)             # the free-convection loss tolerance of tests/test_gpu_parity.py (FC_LOSS_RTOL)
-        assert e_theta < 2e-3, (name, e_theta)
+        rec = dict(loss_seq_rel=e_loss, theta_rel_l2=e_theta)
+        if ca:
+            rec.update(oracle32_loss_seq_rel=gap_loss, oracle32_theta_rel_l2=gap_theta,
+                       vs_oracle32_loss_seq_rel=np.abs(np.array(hist) / np.array(hist_32) - 1).max(), vs_oracle32_theta_rel_l2=_rel(theta, theta_32))
+        _record("training/flux_train_%s/Nz%d_ca%d" % (name, Nz, ca), **rec)
+        assert e_loss < 3e-3 + 2 * gap_loss, (name, hist, hist_o)  # the free-convection loss tolerance of tests/test_gpu_parity.py (FC_LOSS_RTOL) [+ float32's own gap]
+        assert e_theta < 2e-3 + 2 * gap_theta, (name, e_theta)
+        if ca:
+            assert np.abs(np.array(hist) / np.array(hist_32) - 1).max() < 3e-3, (name, hist, hist_32)
         assert hist_o[-1] < hist_o[0]

@@ -1,0 +1,64 @@
+"""The reference's WIDE wind-mixing architectures (VERDICT r4 task 6): `train_NDE.jl:101-102` (commented alternatives kept in the script) and
+`train_NDE_args.jl:150-166` build 3 x Chain(Dense(96, 400, σ), Dense(400, 400, σ), Dense(400, 31)) and 3 x Chain(Dense(96, 400, σ), Dense(400, 31))
+with σ in {swish, mish, leakyrelu, relu, tanh} (`hidden_units = 400`, train_NDE.jl:97-99).  These shapes run on the generic tile16 engine
+(regtile and the net-split pair are specialised to 96-50-20-31): parity of the RHS, the solve, the six-term loss and the gradient against the
+float64 oracle at 64 columns, under both matrix arithmetics, and the plan bits that say which pipe ran."""
+import numpy as np
+import pytest
+
+import colnde
+from colnde import synthetic
+from colnde.nde import ENGINE_TILE16
+from oracle import nde_oracle as O
+
+from tests.test_gpu_parity import _record, SOL_ATOL, LOSS_RTOL, GRAD_REL
+
+pytestmark = pytest.mark.gpu
+
+WIDE = {
+    "96-400-400-31_swish": dict(layer_sizes=(96, 400, 400, 31), activations=("swish", "swish", "identity")),
+    "96-400-31_mish": dict(layer_sizes=(96, 400, 31), activations=("mish", "identity")),
+    "96-400-400-31_leakyrelu": dict(layer_sizes=(96, 400, 400, 31), activations=("leakyrelu", "leakyrelu", "identity")),
+}
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300)
+
+
+@pytest.mark.parametrize("ma", ["bf16x3_exact", "f32_mfma"])
+@pytest.mark.parametrize("name", sorted(WIDE))
+def test_wide_wind_mixing_networks_against_the_oracle(name, ma):
+    p = synthetic.wind_mixing_problem(64, n_frames=5, weight_divisor=1e2, **WIDE[name])
+    n_hidden = sum(a * b + b for a, b in zip(WIDE[name]["layer_sizes"][:-1], WIDE[name]["layer_sizes"][1:]))
+    assert p.cfg.n_params == 3 * n_hidden
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(p.cfg)
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    dx = O.rhs(p.cfg, p.x0, p.bcs, p.weights)
+    with colnde.ColumnNDE(p.cfg, 64, matrix_arithmetic=ma) as nde:
+        assert nde.engine == ENGINE_TILE16
+        assert _rel(nde.rhs(p.x0, p.weights, p.bcs, 0.0), dx) < 1e-6
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
+        plan = nde.plan()
+    _record("wide/%s/%s" % (name, ma), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g))
+    assert np.abs(sol_g - sol).max() < SOL_ATOL
+    assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(terms_g, terms, rtol=10 * LOSS_RTOL, atol=0)
+    assert _rel(grad_g, g) < GRAD_REL
+    # every layer block of every net (Flux.destructure order: W1 b1 W2 b2 ...)
+    sizes = WIDE[name]["layer_sizes"]
+    off = 0
+    for net in range(3):
+        for a, b in zip(sizes[:-1], sizes[1:]):
+            for n in (a * b, b):
+                assert _rel(grad_g[off:off + n], g[off:off + n]) < 4 * GRAD_REL, (net, a, b, n)
+                off += n
+    assert off == p.cfg.n_params
+    # which pipe ran: the header says what tile16 does with a hidden width of 400 under each arithmetic
+    assert plan["matrix_arithmetic"] == ma and plan["engine"] == ENGINE_TILE16
+    if ma == "f32_mfma":
+        assert not (plan["bf16x3_forward"] or plan["bf16x3_adjoint"] or plan["bf16x3_dw"])
