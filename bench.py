@@ -325,6 +325,14 @@ def other_configs(dev, budget_s=120.0):
         r["rhs_evaluations_per_step"] = rhs_per_step
         return r
 
+    def wide(ma="bf16x3_exact"):    # the reference's wide wind-mixing architecture (train_NDE.jl:101-102, train_NDE_args.jl:150-166): 3 x 96-400-400-31 swish, 4,096 columns
+        p = synthetic.wind_mixing_problem(4096, n_frames=17, weight_divisor=1e2, layer_sizes=(96, 400, 400, 31), activations=("swish", "swish", "identity"))
+        mlp = 3 * 2 * (96 * 400 + 400 * 400 + 400 * 31)
+        r = grad_case(p, 4096, [1, 1, 1, 5e-3, 5e-3, 5e-3], 2, mlp, 4,
+                      "wide wind-mixing networks: 3 x (96-400-400-31 swish), 4096 columns x 32 levels x 32 RK4 steps (17 frames), fwd+adjoint; tile16 with the "
+                      "activation rows in global memory (DevModel::ag), taped dW", ma)
+        return r
+
     def c5():       # BASELINE configs[4]: inference forcing, 256 x 256 columns x 32 levels (one GPU holds the whole grid here)
         cfg, T, tf, w = synthetic.inference_problem(256, 256)
         nde = colnde.ColumnNDE(cfg, 65536)
@@ -385,6 +393,7 @@ def other_configs(dev, budget_s=120.0):
     guarded("config3_8_simulations_f32_mfma", f32(c3))
     guarded("config3_8_simulations_conv_adj_kappa10_rkc2", c3ca)
     guarded("config3_8_simulations_conv_adj_kappa10_rkc2_f32_mfma", f32(c3ca))
+    guarded("wide_wind_mixing_4096", wide)
     guarded("config5_inference_65536", c5)
     guarded("implicit_steps_4M_columns", impl)
     fc8_32 = "free convection at a latency size: 8 simulations x 32 levels x 512 RK4 steps, fwd+adjoint (fc32 on 16-column tiles)"
@@ -666,7 +675,7 @@ def compact_line(full):
         line["side_configs_ms"] = {
             "config2_forward_4096_ms": side("config2_forward_4096"), "config3_8sim_ms": side("config3_8_simulations"),
             "config4_shard_ms": side("config4_shard_16384x64"), "config4_shard_conv_adj_rkc2_ms": side("config4_shard_16384x64_conv_adj_rkc2"),
-            "config5_inference_kernel_ms": side("config5_inference_65536", "kernel_ms"),
+            "config5_inference_kernel_ms": side("config5_inference_65536", "kernel_ms"), "wide_wind_mixing_4096x32steps_ms": side("wide_wind_mixing_4096"),
             "errors": [k for k, v in cfgs.items() if isinstance(v, dict) and ("error" in v or "skipped" in v)] or None}
     line["loss_total"] = full.get("loss_total")
     line["grad_l2"] = full.get("grad_l2")

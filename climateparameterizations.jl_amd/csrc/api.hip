@@ -97,7 +97,10 @@ struct colnde_handle {
     int min_substeps = 1;           // least RK4 sub-steps per save interval inside the diffusive stability bound
     bool auto_substeps = false;     // cfg.substeps = 0 at creation: the first solve call chooses the sub-step count from cfg.reltol (choose_substeps)
     float last_estimate = -1.0f;    // ... and the error estimate it settled on
+    float* d_ag = nullptr;          // DevModel::ag: per-tile activation / delta rows in global memory (networks whose rows do not fit the LDS)
+    size_t ag_tiles = 0;            // ... tiles it holds
     std::vector<float> rkc_host;    // host copy of the RKC2 coefficient table in use (refresh_rkc)
+    bool ag_rows = false;           // the tile16 kernels keep the activation rows in global memory (DevModel::ag)
     bool substeps_chosen = false;   // the count in use came out of choose_substeps_impl (colnde_describe says so, with the estimate)
     float* d_rkc = nullptr;         // RKC2 coefficient table (DevModel::rkc)
     std::vector<PendingEvent> pending;
@@ -330,6 +333,19 @@ static void resolve_arithmetic(colnde_handle* h) {
     h->sp_dw = ov("COLNDE_DW_SPLIT");
 }
 
+// DevModel::ag for `tiles` workgroups (zero-filled once: the pad slots behind a layer's last feature are never written and must read as zero)
+static int ensure_ag(colnde_handle* h, size_t tiles) {
+    if (!h->ag_rows || h->ag_tiles >= tiles) return 0;
+    (void)hipStreamSynchronize(h->stream);
+    if (h->d_ag) { (void)hipFree(h->d_ag); h->d_ag = nullptr; h->m.ag = nullptr; h->ag_tiles = 0; }
+    const size_t bytes = tiles * ag_floats_per_tile(h->m) * sizeof(float);
+    if (hipMalloc((void**)&h->d_ag, bytes) != hipSuccess) { (void)hipGetLastError(); return fail("hipMalloc of the activation rows (%zu B) failed", bytes); }
+    if (hipMemset(h->d_ag, 0, bytes) != hipSuccess) return fail("hipMemset of the activation rows failed");
+    h->ag_tiles = tiles;
+    h->m.ag = h->d_ag;
+    return 0;
+}
+
 // The RKC2 coefficient table for the sub-step count now in h->cfg: with rkc_stages = 0 the stage count FOLLOWS the step (least s with 0.9 beta(s) >= lambda dt),
 // so colnde_choose_substeps / colnde_set_substeps / the doubled solve of colnde_error_estimate each run with the stage count their own step needs (a table
 // frozen at creation would be too short for a longer step — unstable — and wastefully long for a shorter one).  Uploaded in stream order.
@@ -425,10 +441,24 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         if (et && (atoi(et) == 256 || atoi(et) == 512 || atoi(et) == 1024)) h->fwd_threads = atoi(et);
         h->lds_fwd_solve = h->lds_fwd + (h->fwd_wlds ? wl : 0);
     }
+    h->m.ag = nullptr;
     if (h->lds_fwd > lds_cap) {
+        // The reference's wide wind-mixing architectures (3 x 96-400-400-31: wind_mixing/train_NDE.jl:101-102, train_NDE_args.jl:150-166) need 160 KB for the
+        // tile's activation rows alone.  They run with THAT array in global memory (DevModel::ag; L2-resident, one slab per workgroup) and everything else as
+        // before: weights streamed from L2, 256-thread forward, the taped-dW adjoint with the Z tape (no in-register weight-gradient tiles).
         const size_t need = h->lds_fwd;
-        delete h;
-        return fail("network too large for the tile engine: forward needs %zu B of LDS (> %zu)", need, lds_cap);
+        const size_t rest = lds_floats_forward_ag(h->m) * sizeof(float);
+        if (rest > lds_cap || CT * h->m.ns > 2 * 1024) {
+            delete h;
+            return fail("network too large for the tile engine: forward needs %zu B of LDS (> %zu), %zu B even with the activation rows in global memory", need, lds_cap, rest);
+        }
+        h->ag_rows = true;
+        h->lds_fwd = rest;
+        h->lds_fwd_solve = rest;
+        h->fwd_wlds = false;
+        h->fwd_threads = 256;
+        h->geo_ok = false;
+        if (ensure_ag(h, (size_t)h->n_tiles)) { delete h; return 1; }
     }
     if (h->lds_adj > lds_cap) h->geo_ok = false;
     {
@@ -535,7 +565,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     (void)hipSetDevice(h->device);
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
-                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc,
+                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc, h->d_ag,
                     h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks, h->d_fc_switch, h->d_fc_lam, h->d_fc_simgf, h->d_fc_simgb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -662,6 +692,7 @@ extern "C" int colnde_rhs_dev(colnde_handle* h, const float* d_x, const float* d
     if (n_columns < 1) return fail("n_columns must be >= 1");
     HIPCHK(hipSetDevice(h->device));
     if (pack(h, d_weights)) return 1;
+    if (ensure_ag(h, ((size_t)n_columns + CT - 1) / CT)) return 1;
     Timed tm(h, K_RHS);
     hipError_t e = launch_rhs(h->m, h->pk, d_weights, h->d_wf, d_x, d_bcs, t, d_dx, n_columns, 256, h->lds_fwd, h->stream);
     if (e != hipSuccess) return fail("rhs launch failed: %s", hipGetErrorString(e));
@@ -1035,7 +1066,19 @@ static int t16_plan_dwtape(colnde_handle* h) {
     const int n_steps = (h->cfg.n_save - 1) * h->cfg.substeps;
     const size_t R = dwtape_row_floats(m);
     if (want && (size_t)CT * m.ns > 6 * 512) want = false;
-    if (want && (MODEL_FLOATS + lds_floats_adjoint(m)) * sizeof(float) > 160 * 1024) want = false;
+    // LDS of the taped adjoint: with the Z tape (the default) it holds no activation array; a network that fits only that way (3 x 96-400-31: 166 KB with
+    // the array, 83 KB without) then NEEDS the Z tape
+    bool need_z = false;
+    if (want && !h->ag_rows && (MODEL_FLOATS + lds_floats_adjoint(m)) * sizeof(float) > 160 * 1024) {
+        const char* ez = getenv("COLNDE_T16_ZTAPE");
+        if (!(ez && atoi(ez) == 0) && (MODEL_FLOATS + lds_floats_adjoint_noA(m)) * sizeof(float) <= 160 * 1024 && m.n_bias <= 4 * 512) need_z = true;
+        else want = false;
+    }
+    if (h->ag_rows) {       // rows in global memory: the taped adjoint with the Z tape is the ONLY gradient path (1,024 threads: n_bias <= 4 x 1,024, CT ns <= 2 x 1,024)
+        if (!want) return fail("COLNDE_T16_DWTAPE=0: this network's activation rows live in global memory, and only the taped-dW adjoint runs that way");
+        if (m.n_bias > 4 * 1024 || (MODEL_FLOATS + lds_floats_adjoint_ag(m)) * sizeof(float) > 160 * 1024)
+            return fail("network too large for the taped adjoint with rows in global memory (%d biases, %zu B of LDS)", m.n_bias, (MODEL_FLOATS + lds_floats_adjoint_ag(m)) * sizeof(float));
+    }
     // The tapes hold ONE block of columns (a multiple of the 16-column tile; whole rounds of 4,096 columns = one workgroup per CU when
     // possible); larger problems run forward -> adjoint -> dW GEMM block after block.  COLNDE_T16_BLOCK=<columns> forces a size.
     const size_t per_col = (size_t)n_steps * m.nst * (R + t16_ztape_col_floats(m) + m.ns) * sizeof(float);
@@ -1073,7 +1116,11 @@ static int t16_plan_dwtape(colnde_handle* h) {
             else want_rich = false;
         }
     }
-    if (!want) { h->t16_dwtape = 0; return 0; }
+    if (!want) {
+        if (h->ag_rows) return fail("the delta tape of this network (%zu B per column) does not fit in HBM beside the solve", per_col);
+        h->t16_dwtape = 0;
+        return 0;
+    }
     const int tiles_b = block / CT;
     const size_t n_rec = (size_t)tiles_b * n_steps * h->m.nst;
     const size_t need = n_rec * CT * R * sizeof(float);
@@ -1091,6 +1138,7 @@ static int t16_plan_dwtape(colnde_handle* h) {
         (void)hipGetLastError();
         if (h->d_dwtape) { (void)hipFree(h->d_dwtape); h->d_dwtape = nullptr; }
         h->t16_dwtape = 0;
+        if (h->ag_rows) return fail("allocating the delta tape (%zu B) failed: %s", need, hipGetErrorString(e));
         return 0;
     }
     h->t16_dwtape = 1;
@@ -1101,6 +1149,7 @@ static int t16_plan_dwtape(colnde_handle* h) {
             (void)hipGetLastError();
             (void)hipFree(h->d_dwtape); h->d_dwtape = nullptr;
             h->t16_dwtape = 0;
+            if (h->ag_rows) return fail("allocating the stage tape failed: %s", hipGetErrorString(e));
             return 0;
         }
     }
@@ -1119,6 +1168,8 @@ static int t16_plan_dwtape(colnde_handle* h) {
         (void)hipGetLastError();
         h->d_t16_ztape = nullptr;
     }
+    if ((h->ag_rows || need_z) && !h->d_t16_ztape)
+        return fail("this network's taped adjoint needs the pre-activation tape (COLNDE_T16_ZTAPE=0 or its allocation failed): no gradient path for it without one");
     return 0;
 }
 
@@ -1255,7 +1306,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
                                               h->d_bcs + (size_t)c0 * h->m.n_bc, h->d_times, h->cfg.n_save, h->cfg.substeps,
                                               h->d_sol + (size_t)c0 * h->cfg.n_save * ns, h->d_truth + (size_t)c0 * h->cfg.n_save * ns, h->d_tape,
                                               lw, h->d_slab + (size_t)(c0 / CT) * stride, nc, g,
-                                              (MODEL_FLOATS + (h->d_t16_ztape ? lds_floats_adjoint_noA(h->m) : lds_floats_adjoint(h->m))) * sizeof(float),
+                                              (MODEL_FLOATS + (h->ag_rows ? lds_floats_adjoint_ag(h->m) : (h->d_t16_ztape ? lds_floats_adjoint_noA(h->m) : lds_floats_adjoint(h->m)))) * sizeof(float),
                                               h->stream, h->d_dwtape, h->d_t16_ztape);
                 if (e != hipSuccess) return fail("adjoint (taped dW) launch failed: %s", hipGetErrorString(e));
             }
@@ -1279,7 +1330,7 @@ extern "C" int colnde_loss_grad_dev(colnde_handle* h, const float* d_weights, co
     if (forward_impl(h, d_weights, h->d_sol, true)) return 1;
     if (!h->geo_ok)
         return fail("network too large for the tile engine's in-register adjoint (%d weight-gradient tiles, %zu B of LDS) and its "
-                    "delta tape does not fit in HBM", h->m.n_tiles, h->lds_adj);
+                    "delta tape does not fit in HBM (or COLNDE_T16_DWTAPE=0)", h->m.n_tiles, h->lds_adj);
     if (!h->d_slab) {
         hipError_t e = hipMalloc((void**)&h->d_slab, (size_t)h->n_tiles * stride * sizeof(float));
         if (e != hipSuccess) return fail("hipMalloc of the partial-gradient slab failed: %s", hipGetErrorString(e));
@@ -1479,6 +1530,7 @@ extern "C" int colnde_flux_dev(colnde_handle* h, const float* d_x, const float* 
     if (n_columns < 1) return fail("n_columns must be >= 1");
     HIPCHK(hipSetDevice(h->device));
     if (pack(h, d_weights)) return 1;
+    if (ensure_ag(h, ((size_t)n_columns + CT - 1) / CT)) return 1;
     Timed tm(h, K_RHS);
     hipError_t e = launch_rhs(h->m, h->pk, d_weights, h->d_wf, d_x, d_bcs, t, nullptr, n_columns, 256, h->lds_fwd, h->stream, d_flux);
     if (e != hipSuccess) return fail("flux launch failed: %s", hipGetErrorString(e));
@@ -1856,6 +1908,7 @@ extern "C" int colnde_describe(const colnde_handle* h, char* buf, int capacity) 
     if (info[1]) { snprintf(t, sizeof t, " block=%dx%d", info[1], info[2]); s += t; } else s += " block=(not planned yet)";
     if (info[0] == COLNDE_ENGINE_MFMA) { snprintf(t, sizeof t, " z1_tape=%d", info[3]); s += t; }
     if (info[0] == COLNDE_ENGINE_FC32) { snprintf(t, sizeof t, " time_segments=%d tile_width=%d dw_slices=%d", info[3], h->fc_cw, info[5]); s += t; }
+    if (h->ag_rows) s += " activation_rows=global_memory(L2)";
     if (info[0] == COLNDE_ENGINE_GENERIC) {
         snprintf(t, sizeof t, " dw_taped=%d dw_slices=%d net_split_forward=%d net_split_adjoint=%d rich_tape=%d", info[4], info[5], info[6] & 1, (info[6] >> 1) & 1, (info[6] >> 2) & 1);
         s += t;

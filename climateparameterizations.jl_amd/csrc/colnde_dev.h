@@ -49,6 +49,10 @@ struct DevModel {
     // rkc = device table [6][RKC_LD] of (mu, nu, mu~, gamma~, c, 1 - mu - nu), index j = 0..s (nullptr: RK4)
     int nst;
     const float* rkc;
+    // Networks whose per-tile activation rows [net][CT][ld_a] do not fit the CU's LDS (the reference's wide wind-mixing architectures,
+    // 3 x 96-400-400-31: 160 KB of rows alone): the tile16 kernels then keep THAT array in a per-workgroup slab of global memory (L2-resident:
+    // written and read by the same workgroup between its own barriers) and everything else in LDS as before.  nullptr: rows in LDS.
+    float* ag;
 };
 #define RKC_LD 260
 

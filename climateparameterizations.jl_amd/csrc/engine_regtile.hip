@@ -802,6 +802,27 @@ __device__ __forceinline__ f32x16 rt_outer(f32x16 acc, const f32x16 TA, const f3
     return acc;
 }
 
+// A/B build only (-DRT_OUTER_SPLIT, VERDICT r4 task 4b): the same outer product on the bf16 pipe — both transposed tiles split exactly per 16-deep k-block
+// (k-block b = registers 8b .. 8b+7 of both operands: the two kernels' K orders agree), six bf16 products per block.  TA's split is passed in so that the
+// two layer-1 tiles of dW2 share it.
+struct Bf3x2 { Bf3 b[2]; };
+__device__ __forceinline__ Bf3x2 rt_split_tile(const f32x16 T) {
+    Bf3x2 o;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = T[8 * b + u];
+        o.b[b] = bf3_split8(v);
+    }
+    return o;
+}
+__device__ __forceinline__ f32x16 rt_outer_split(f32x16 acc, const Bf3x2& A, const Bf3x2& B) {
+    acc = mfma_bf3(A.b[0], B.b[0], acc);
+    acc = mfma_bf3(A.b[1], B.b[1], acc);
+    return acc;
+}
+
 __device__ __forceinline__ float rt_sum16(const f32x16 v) {
     float s = 0.0f;
 #pragma unroll
@@ -918,7 +939,11 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
     // taped layer-1 pre-activations of net n at (step, stage): registers G' < 25 of Z (padding registers untouched)
     // (RT_ZRICH: Z receives the taped activation values and Dz their derivatives; nothing is left to evaluate)
     auto load_z1 = [&](int step, int st, int n, f32x16 (&Z)[2], f32x16 (&Dz)[2]) {
-        const float* srcz = tpz + ((size_t)step * 4 + st) * RT_TAPEZ + n * 7 * 256;
+        size_t rec = (size_t)step * 4 + st;
+#ifdef RT_ABL_Z1_CACHED   // (ablation probe, results wrong: every stage reads the tile's FIRST Z1 record — the loads stay, the 50.7 GB of HBM reads go; VERDICT r4 task 4a)
+        { int z_ = 0; asm volatile("" : "+v"(z_)); rec = (size_t)z_; }      // (opaque, so that the loads are not hoisted out of the time loop)
+#endif
+        const float* srcz = tpz + rec * RT_TAPEZ + n * 7 * 256;
 #pragma unroll
         for (int grp = 0; grp < 7; grp++) {
             const f32x4v v = RT_TAPE_LOAD4(srcz + grp * 256);
@@ -1043,6 +1068,10 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                             Z2[r] = d0.x; Z2[r + 1] = d0.y; Z2[r + 2] = d1.x; Z2[r + 3] = d1.y;     // Z2 now holds act'(z2)
                         }
                         const f32x16 TB = rt_transpose(tb, A2, wbase, rbase);
+#ifdef RT_OUTER_SPLIT
+                        if constexpr (SPLIT) gW3[n] = rt_outer_split(gW3[n], rt_split_tile(TA), rt_split_tile(TB));
+                        else
+#endif
                         gW3[n] = rt_outer(gW3[n], TA, TB);
                     }
                     {
@@ -1069,9 +1098,17 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     {
                         const f32x16 TA = rt_transpose(tb, Z2, wbase, rbase);
                         b2acc[n] += rt_sum16(TA);
+#ifdef RT_OUTER_SPLIT
+                        Bf3x2 TAs;
+                        if constexpr (SPLIT) TAs = rt_split_tile(TA);
+#endif
 #pragma unroll
                         for (int t = 0; t < 2; t++) {
                             const f32x16 TB = rt_transpose(tb, A1[t], wbase, rbase);
+#ifdef RT_OUTER_SPLIT
+                            if constexpr (SPLIT) gW2[n][t] = rt_outer_split(gW2[n][t], TAs, rt_split_tile(TB));
+                            else
+#endif
                             gW2[n][t] = rt_outer(gW2[n][t], TA, TB);
                         }
                     }

@@ -25,6 +25,11 @@ static inline size_t lds_floats_adjoint(const DevModel& m) {
     return (size_t)3 * CT * m.ld_x + (size_t)2 * m.n_nets * CT * m.ld_a + (size_t)5 * CT * m.ld_f + CT * 8 + 16 * 8;
 }
 
+// DevModel::ag set (rows in global memory): what remains in LDS
+static inline size_t lds_floats_forward_ag(const DevModel& m) { return lds_floats_forward(m) - (size_t)m.n_nets * CT * m.ld_a; }
+static inline size_t lds_floats_adjoint_ag(const DevModel& m) { return lds_floats_adjoint(m) - (size_t)2 * m.n_nets * CT * m.ld_a; }
+static inline size_t ag_floats_per_tile(const DevModel& m) { return (size_t)m.n_nets * CT * m.ld_a; }
+
 // taped mode with the hidden pre-activations taped: no activation array on chip
 static inline size_t lds_floats_adjoint_noA(const DevModel& m) { return lds_floats_adjoint(m) - (size_t)m.n_nets * CT * m.ld_a; }
 

@@ -712,6 +712,8 @@ __device__ __forceinline__ void load_bcs(const DevModel& m, const float* __restr
 // ------------------------------------------------------------------------------------------------
 // single RHS evaluation (NDE / NDE! / ∂T∂t drop-in)
 // ------------------------------------------------------------------------------------------------
+// AG: the activation rows live in the workgroup's slab of m.ag (global memory) instead of LDS — see DevModel::ag
+template <bool AG = false>
 __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                            const float* __restrict__ x, const float* __restrict__ bcs, float t,
                            float* __restrict__ dx, float* __restrict__ flux, int n_col) {
@@ -719,8 +721,8 @@ __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
     float* xs = smem;
     float* kk = xs + CT * m.ld_x;
-    float* A = kk + CT * m.ld_x;
-    float* F = A + m.n_nets * CT * m.ld_a;
+    float* A = AG ? m.ag + (size_t)blockIdx.x * m.n_nets * CT * m.ld_a : kk + CT * m.ld_x;
+    float* F = AG ? kk + CT * m.ld_x : A + m.n_nets * CT * m.ld_a;
     float* Ri_l = F + 3 * CT * m.ld_f;
     float* bcl = Ri_l + CT * m.ld_f;
     const int total = (int)(bcl + CT * 8 - smem);
@@ -755,7 +757,7 @@ __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const
 // forward solve: classical RK4, S sub-steps per save interval, state at save points -> sol,
 // stage inputs of every step -> tape (read back by the adjoint kernel)
 // ------------------------------------------------------------------------------------------------
-template <bool WLDS, int NTH, bool RKC = false>
+template <bool WLDS, int NTH, bool RKC = false, bool AG = false>
 __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                                const float* __restrict__ x0, const float* __restrict__ bcs,
                                const float* __restrict__ save_times, int n_save, int substeps,
@@ -767,8 +769,8 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
     float* xs = smem + (WLDS ? ((m.n_params + 3) & ~3) + 128 : 0);
     float* kk = xs + CT * m.ld_x;
     const int zld = (m.n_nets * m.act_off[m.n_layers - 1] + 3) & ~3;      // floats per column of the hidden pre-activation tape
-    float* A = kk + CT * m.ld_x;
-    float* F = A + m.n_nets * CT * m.ld_a;
+    float* A = AG ? m.ag + (size_t)blockIdx.x * m.n_nets * CT * m.ld_a : kk + CT * m.ld_x;
+    float* F = AG ? kk + CT * m.ld_x : A + m.n_nets * CT * m.ld_a;
     float* Ri_l = F + 3 * CT * m.ld_f;
     float* bcl = Ri_l + CT * m.ld_f;
     const int total = (int)(bcl + CT * 8 - smem);
@@ -959,7 +961,7 @@ __global__ void loss_kernel(DevModel m, const float* __restrict__ sol, const flo
 // TAPEDW: the weight gradients are not accumulated here.  Each stage's layer inputs and deltas are written to `dwtape` as
 // [tile][step][stage][CT columns][xs | A of every net | dZ of every net] and contracted by dw_gemm_kernel (networks whose
 // weight-gradient tiles would not fit the register file: 64-256-256-63 has 384 of them).
-template <int MAXT, int NTH, int MAXR, bool WLDS, bool TAPEDW = false, bool RKC = false>
+template <int MAXT, int NTH, int MAXR, bool WLDS, bool TAPEDW = false, bool RKC = false, bool AG = false>
 __global__ void __launch_bounds__(NTH, (TAPEDW && NTH == 512) ? 4 : 1)   // taped mode, 512 threads: 128 registers, so that TWO workgroups share a CU and one's GEMMs cover the other's tape traffic
 adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const float* __restrict__ wf,
                const float* __restrict__ wb, const TileDesc* __restrict__ tiles, const int* __restrict__ bias_zoff,
@@ -978,12 +980,14 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
     float* xs = base + (WLDS ? ((m_arg.n_params + 3) & ~3) + 128 : 0);
     float* dbar = xs + CT * m_arg.ld_x;
     float* xb = dbar + CT * m_arg.ld_x;
-    float* Z = xb + CT * m_arg.ld_x;
+    static_assert(!AG || TAPEDW, "rows in global memory: the taped-dW adjoint only (the in-register one addresses its operands relative to LDS)");
+    // (AG: the delta rows in the workgroup's slab of m_arg.ag; only with the Z tape, so that no A array exists — the host guarantees it)
+    float* Z = AG ? m_arg.ag + (size_t)blockIdx.x * m_arg.n_nets * CT * m_arg.ld_a : xb + CT * m_arg.ld_x;
     // taped mode with the hidden pre-activations taped: the activations go from the Z tape straight into the delta tape and are never
     // needed on chip — no A array, and two workgroups of a 64-level network fit in a CU's LDS
     const bool noA = TAPEDW && ztape != nullptr;
-    float* A = Z + m_arg.n_nets * CT * m_arg.ld_a;
-    float* gb = noA ? A : A + m_arg.n_nets * CT * m_arg.ld_a;
+    float* A = AG ? Z : Z + m_arg.n_nets * CT * m_arg.ld_a;
+    float* gb = AG ? xb + CT * m_arg.ld_x : (noA ? A : A + m_arg.n_nets * CT * m_arg.ld_a);
     float* Ri_l = gb + 3 * CT * m_arg.ld_f;
     float* Rib_l = Ri_l + CT * m_arg.ld_f;
     float* bcl = Rib_l + CT * m_arg.ld_f;
@@ -1863,7 +1867,8 @@ hipError_t launch_pack(const DevModel& m, const PackInfo& pk, const float* w, fl
 
 hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x,
                       const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream, float* flux) {
-    hipLaunchKernelGGL(rhs_kernel, dim3((n_col + CT - 1) / CT), dim3(nthreads), lds_bytes, stream, m, pk, w, wf, x, bcs, t, dx, flux, n_col);
+    if (m.ag) hipLaunchKernelGGL((rhs_kernel<true>), dim3((n_col + CT - 1) / CT), dim3(nthreads), lds_bytes, stream, m, pk, w, wf, x, bcs, t, dx, flux, n_col);
+    else hipLaunchKernelGGL((rhs_kernel<false>), dim3((n_col + CT - 1) / CT), dim3(nthreads), lds_bytes, stream, m, pk, w, wf, x, bcs, t, dx, flux, n_col);
     return hipGetLastError();
 }
 
@@ -1880,6 +1885,14 @@ hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w,
             hipLaunchKernelGGL((forward_kernel<WL, NT, false>), grid, dim3(NT), lds_bytes, stream, m, pk, w, wf, x0, bcs,   \
                                save_times, n_save, substeps, sol, tape, n_col, ztape);                                      \
     } while (0)
+    if (m.ag) {        // rows in global memory (wide networks): weights streamed from L2, 256 threads
+        if (wlds || nthreads != 256) return hipErrorInvalidValue;
+        if (m.rkc)
+            hipLaunchKernelGGL((forward_kernel<false, 256, true, true>), grid, dim3(256), lds_bytes, stream, m, pk, w, wf, x0, bcs, save_times, n_save, substeps, sol, tape, n_col, ztape);
+        else
+            hipLaunchKernelGGL((forward_kernel<false, 256, false, true>), grid, dim3(256), lds_bytes, stream, m, pk, w, wf, x0, bcs, save_times, n_save, substeps, sol, tape, n_col, ztape);
+        return hipGetLastError();
+    }
     if (wlds && nthreads == 512) LAUNCH_FWD(true, 512);
     else if (wlds && nthreads == 256) LAUNCH_FWD(true, 256);
     else if (!wlds && nthreads == 512) LAUNCH_FWD(false, 512);
@@ -1902,6 +1915,17 @@ hipError_t launch_adjoint(const DevModel& m, const PackInfo& pk, const float* w,
                           const float* tape, const LossWeights& lw, float* slab, int n_col, const AdjointGeom& geo,
                           size_t lds_bytes, hipStream_t stream, float* dwtape, const float* ztape) {
     const int n_tiles = (n_col + CT - 1) / CT;
+    if (dwtape && m.ag) {
+        // rows in global memory (wide networks): the Z tape is required (no A array), 1,024 threads (n_bias <= MAXB * 1,024, CT * ns <= 2 * 1,024: checked by the host)
+        if (!ztape || CT * m.ns > 2 * 1024 || m.n_bias > MAXB * 1024) return hipErrorInvalidValue;
+        if (m.rkc)
+            hipLaunchKernelGGL((adjoint_kernel<1, 1024, 2, false, true, true, true>), dim3(n_tiles), dim3(1024), lds_bytes, stream, m, pk, w, wf, wb, tiles, bias_zoff,
+                               bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape, ztape);
+        else
+            hipLaunchKernelGGL((adjoint_kernel<1, 1024, 2, false, true, false, true>), dim3(n_tiles), dim3(1024), lds_bytes, stream, m, pk, w, wf, wb, tiles, bias_zoff,
+                               bias_goff, bcs, save_times, n_save, substeps, sol, truth, tape, lw, slab, n_col, dwtape, ztape);
+        return hipGetLastError();
+    }
     if (dwtape) {
         // Two 512-thread workgroups per CU (128 registers each) when two fit in the LDS: one's GEMMs then cover the other's tape
         // traffic, activations and physics (32-128-128-31: adjoint 84.6 -> 61.6 ms); one 1,024-thread workgroup (four waves per SIMD)
@@ -1968,7 +1992,12 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     hipError_t e;
     const int v = (int)max_lds_bytes;
 #define SETATTR(K) if ((e = hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, v)) != hipSuccess) return e
-    SETATTR(rhs_kernel);
+    SETATTR((rhs_kernel<false>));
+    SETATTR((rhs_kernel<true>));
+    SETATTR((forward_kernel<false, 256, false, true>));
+    SETATTR((forward_kernel<false, 256, true, true>));
+    SETATTR((adjoint_kernel<1, 1024, 2, false, true, false, true>));
+    SETATTR((adjoint_kernel<1, 1024, 2, false, true, true, true>));
     SETATTR(infer_kernel);
     SETATTR((forward_kernel<true, 512>));
     SETATTR((forward_kernel<true, 256>));

@@ -44,6 +44,8 @@ def test_wide_wind_mixing_networks_against_the_oracle(name, ma):
         sol_g = nde.forward(p.weights)
         tot_g, terms_g, grad_g = nde.loss_grad(p.weights, sc)
         plan = nde.plan()
+        desc = nde.describe()
+    assert ("activation_rows=global_memory" in desc) == (len(WIDE[name]["layer_sizes"]) == 4)       # 400-400: rows in global memory; 400: they fit the LDS
     _record("wide/%s/%s" % (name, ma), sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g))
     assert np.abs(sol_g - sol).max() < SOL_ATOL
     assert np.isclose(tot_g, tot, rtol=LOSS_RTOL)
@@ -58,7 +60,7 @@ def test_wide_wind_mixing_networks_against_the_oracle(name, ma):
                 assert _rel(grad_g[off:off + n], g[off:off + n]) < 4 * GRAD_REL, (net, a, b, n)
                 off += n
     assert off == p.cfg.n_params
-    # which pipe ran: the header says what tile16 does with a hidden width of 400 under each arithmetic
-    assert plan["matrix_arithmetic"] == ma and plan["engine"] == ENGINE_TILE16
-    if ma == "f32_mfma":
-        assert not (plan["bf16x3_forward"] or plan["bf16x3_adjoint"] or plan["bf16x3_dw"])
+    # which pipe ran (include/colnde.h says so): tile16's forward and adjoint are f32-MFMA kernels under either arithmetic, and the split dW GEMM needs a
+    # tile's records in LDS (these are 325 KB): all three kernels report f32
+    assert plan["matrix_arithmetic"] == ma and plan["engine"] == ENGINE_TILE16 and plan["dw_taped"]
+    assert not (plan["bf16x3_forward"] or plan["bf16x3_adjoint"] or plan["bf16x3_dw"])
