@@ -962,11 +962,14 @@ static void build_dw_macros(colnde_handle* h, size_t n_rec, std::vector<DwMacro>
         }
     h->n_macros = (int)mac.size();
     dw_split_free(h->dw_split);
-    if (dw_gemm_lds_fits((int)R, h->n_macros)) (void)dw_split_build(mac, matrix_of, (int)R, h->dw_split);
+    // the split (bf16-pipe) dW GEMM keeps only a pass's operand FEATURES in LDS, as planes: it also serves records that do not fit the LDS whole (the wide
+    // wind-mixing networks: 325 KB per 16-column record), with the large matrices cut into chunks of output blocks (dw_split_build)
+    const bool lds_fit = dw_gemm_lds_fits((int)R, h->n_macros);
+    const bool split_ok = dw_split_build(mac, matrix_of, (int)R, h->dw_split);
     const int n_groups = (h->n_macros + 3) / 4;
     size_t slices = std::max<size_t>(8, ((size_t)2048 / n_groups + 7) / 8 * 8);
     slices = std::min(slices, std::max<size_t>(8, (n_rec / 8 + 7) / 8 * 8));
-    if (dw_gemm_lds_fits((int)R, h->n_macros))       // one workgroup per CU (two records in LDS): two rounds of slices
+    if (lds_fit || (split_ok && h->sp_dw))           // one workgroup per CU (two records / two plane buffers in LDS): two rounds of slices
         slices = std::min<size_t>(512, std::max<size_t>(1, n_rec));
     h->dw_slices = (int)slices;
 }

@@ -1651,6 +1651,36 @@ bool dw_split_build(const std::vector<DwMacro>& mac, const std::vector<int>& mat
         }
         return dst;
     };
+    // A matrix too large for one pass (the wide wind-mixing layers: 400 x 400 = 49 blocks, 800 features) is cut along its OUTPUT blocks into chunks that fit
+    // (<= 16 blocks, <= 768 compact features): every chunk keeps all input features of the matrix and takes a run of output-block columns.
+    {
+        std::vector<Group> cut;
+        for (auto& g : groups) {
+            std::vector<DwSeg> sg;
+            if ((int)g.idx.size() <= 16 && segments(g.idx, sg) <= 768 && sg.size() <= 8) { cut.push_back(g); continue; }
+            std::vector<int> dcols;                                  // distinct output-block columns (d_feat) of this matrix, in order
+            for (int i : g.idx)
+                if (std::find(dcols.begin(), dcols.end(), mac[i].d_feat) == dcols.end()) dcols.push_back(mac[i].d_feat);
+            std::sort(dcols.begin(), dcols.end());
+            size_t c0 = 0;
+            while (c0 < dcols.size()) {
+                Group best{{}, 0};
+                for (size_t c1 = c0 + 1; c1 <= dcols.size(); c1++) {
+                    Group trial{{}, 0};
+                    for (int i : g.idx)
+                        if (mac[i].d_feat >= dcols[c0] && mac[i].d_feat <= dcols[c1 - 1]) trial.idx.push_back(i);
+                    std::vector<DwSeg> st;
+                    if ((int)trial.idx.size() > 16 || segments(trial.idx, st) > 768 || st.size() > 8) break;
+                    best = trial;
+                }
+                if (best.idx.empty()) return false;                   // one output-block column alone does not fit
+                const int last = mac[best.idx.back()].d_feat;
+                cut.push_back(best);
+                while (c0 < dcols.size() && dcols[c0] <= last) c0++;
+            }
+        }
+        groups.swap(cut);
+    }
     for (auto& g : groups) { std::vector<DwSeg> sg; g.feats = segments(g.idx, sg); }
     std::vector<int> order(groups.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
