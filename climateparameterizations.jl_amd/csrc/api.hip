@@ -456,7 +456,13 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         h->lds_fwd = rest;
         h->lds_fwd_solve = rest;
         h->fwd_wlds = false;
-        h->fwd_threads = 256;
+        // few tiles (<= 2 per CU): one 1,024-thread workgroup per tile, four waves per SIMD to hide the row loads from L2 (4,096 columns: 21.0 -> see DESIGN);
+        // many tiles: 256-thread workgroups, several per CU.  COLNDE_FWD_THREADS=256|1024 overrides.
+        h->fwd_threads = h->n_tiles <= 512 ? 1024 : 256;
+        {
+            const char* et = getenv("COLNDE_FWD_THREADS");
+            if (et && (atoi(et) == 256 || atoi(et) == 1024)) h->fwd_threads = atoi(et);
+        }
         h->geo_ok = false;
         if (ensure_ag(h, (size_t)h->n_tiles)) { delete h; return 1; }
     }

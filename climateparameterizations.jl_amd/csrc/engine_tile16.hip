@@ -1915,12 +1915,12 @@ hipError_t launch_forward(const DevModel& m, const PackInfo& pk, const float* w,
             hipLaunchKernelGGL((forward_kernel<WL, NT, false>), grid, dim3(NT), lds_bytes, stream, m, pk, w, wf, x0, bcs,   \
                                save_times, n_save, substeps, sol, tape, n_col, ztape);                                      \
     } while (0)
-    if (m.ag) {        // rows in global memory (wide networks): weights streamed from L2, 256 threads
-        if (wlds || nthreads != 256) return hipErrorInvalidValue;
-        if (m.rkc)
-            hipLaunchKernelGGL((forward_kernel<false, 256, true, true>), grid, dim3(256), lds_bytes, stream, m, pk, w, wf, x0, bcs, save_times, n_save, substeps, sol, tape, n_col, ztape);
-        else
-            hipLaunchKernelGGL((forward_kernel<false, 256, false, true>), grid, dim3(256), lds_bytes, stream, m, pk, w, wf, x0, bcs, save_times, n_save, substeps, sol, tape, n_col, ztape);
+    if (m.ag) {        // rows in global memory (wide networks): weights streamed from L2; 1,024 threads (four waves per SIMD hide the row loads) or 256
+        if (wlds || (nthreads != 256 && nthreads != 1024)) return hipErrorInvalidValue;
+#define LAUNCH_FWD_AG(NT, RK) hipLaunchKernelGGL((forward_kernel<false, NT, RK, true>), grid, dim3(NT), lds_bytes, stream, m, pk, w, wf, x0, bcs, save_times, n_save, substeps, sol, tape, n_col, ztape)
+        if (nthreads == 1024) { if (m.rkc) LAUNCH_FWD_AG(1024, true); else LAUNCH_FWD_AG(1024, false); }
+        else { if (m.rkc) LAUNCH_FWD_AG(256, true); else LAUNCH_FWD_AG(256, false); }
+#undef LAUNCH_FWD_AG
         return hipGetLastError();
     }
     if (wlds && nthreads == 512) LAUNCH_FWD(true, 512);
@@ -2026,6 +2026,8 @@ hipError_t set_kernel_attributes(size_t max_lds_bytes) {
     SETATTR((rhs_kernel<true>));
     SETATTR((forward_kernel<false, 256, false, true>));
     SETATTR((forward_kernel<false, 256, true, true>));
+    SETATTR((forward_kernel<false, 1024, false, true>));
+    SETATTR((forward_kernel<false, 1024, true, true>));
     SETATTR((adjoint_kernel<1, 1024, 2, false, true, false, true>));
     SETATTR((adjoint_kernel<1, 1024, 2, false, true, true, true>));
     SETATTR(infer_kernel);
