@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define COLNDE_VERSION 105
+#define COLNDE_VERSION 106
 #define COLNDE_MAX_LAYERS 8
 
 enum { COLNDE_MODEL_WIND_MIXING = 0,        /* NDE / NDE!: wind_mixing/src/NDE_training.jl:56-165 */
@@ -33,7 +33,14 @@ enum { COLNDE_ACT_IDENTITY = 0, COLNDE_ACT_RELU = 1, COLNDE_ACT_MISH = 2, COLNDE
        COLNDE_ACT_TANH = 4, COLNDE_ACT_LEAKYRELU = 5 };
 
 enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it is built for and there are > 8,192 columns, fc32 for its shape, else tile16 (with the net-split kernels where the shape is regtile's) */
-       COLNDE_ENGINE_GENERIC = 1,   /* tile16: 16-column MFMA tiles staged through LDS, any layer sizes / model */
+       COLNDE_ENGINE_GENERIC = 1,   /* tile16: 16-column MFMA tiles staged through LDS, any layer sizes / model.  Networks whose per-tile activation rows exceed
+                                       the CU's 160 KB of LDS — the reference's WIDE wind-mixing architectures, 3 x Chain(Dense(96,400,σ), Dense(400,400,σ),
+                                       Dense(400,31)) of wind_mixing/train_NDE.jl:101-102 and train_NDE_args.jl:150-166 (their rows alone are 160 KB) — run
+                                       with that one array in a per-workgroup slab of global memory (L2-resident) and the taped weight-gradient path
+                                       (colnde_describe: "activation_rows=global_memory"); 3 x (96-400-31) fits the LDS.  Which pipe: tile16's forward
+                                       and adjoint kernels are f32-MFMA kernels under EITHER matrix_arithmetic; its tape GEMM (dW) follows the
+                                       arithmetic asked for (colnde_plan info[7] bit 3).  4,096 columns x 32 steps of 3 x (96-400-400-31 swish),
+                                       fwd + adjoint: 41 ms = 48 algorithmic TFLOP/s (profiles/r05_wide_networks.log). */
        COLNDE_ENGINE_MFMA = 2,      /* regtile: 32 columns per wavefront resident in registers (static 96-50-20-31 wind-mixing
                                        shape; colnde_create fails if the configuration is not covered) */
        COLNDE_ENGINE_FC32 = 3 };    /* fc32: 32-column v_mfma_f32_32x32x2_f32 tiles (16-column v_mfma_f32_16x16x4_f32 tiles up to 4,096 columns)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "%s declared in colnde.h but not exported" % name
         assert name in bound, "%s declared in colnde.h but missing from the ctypes binding" % name
     header = open(os.path.join(ROOT, "include", "colnde.h")).read()
-    assert L.colnde_version() == int(re.search(r"#define COLNDE_VERSION (\d+)", header).group(1)) == 105
+    assert L.colnde_version() == int(re.search(r"#define COLNDE_VERSION (\d+)", header).group(1)) == 106
 
 
 def test_config_struct_layout_matches_header_order():
