@@ -51,8 +51,14 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #ifndef RT_ZRICH
 #define RT_ZRICH 0            // 1 (A/B build, VERDICT r3 task 3): the forward kernel tapes the layer-1 activation VALUES and DERIVATIVES (act(z1), act'(z1)) instead of
 #endif                        // z1 — twice the bytes of this tape (+50 GB written and read at the bench size), no layer-1 activation pairs in the adjoint's stage loop
+#ifndef RT_Z2TAPE
+#define RT_Z2TAPE 0           // 1 (A/B build, round 5): the forward kernel tapes the layer-2 pre-activations too (3 nets x 3 groups x 64 lanes x 4 behind the layer-1 record: +9.2 KB per
+#endif                        // 32-column stage, +19 GB at the bench size) and the adjoint drops its layer-2 recomputation (75 of its 336 f32 MFMAs per stage).  Measured SLOWER: forward
+                              // 27.5 -> 29.4-30.0 ms, adjoint 56.2 -> 61.9 ms (Z2 fetched one net ahead: scratch 536 -> 684 B) / 64.5 ms (fetched at the net's top: 668 B and the
+                              // latency exposed) — the recomputation's MFMAs ride under the vector phases, its replacement's registers do not exist (profiles/r05_ab_adjoint_variants.log)
 #define RT_TAPEZ_HALF (21 * 256)
-#define RT_TAPEZ ((RT_ZRICH ? 2 : 1) * RT_TAPEZ_HALF)   // floats per (tile, step, stage) of the layer-1 tape: 3 nets x 7 groups x 64 lanes x 4 (RT_ZRICH: values, then derivatives)
+#define RT_Z2OFF ((RT_ZRICH ? 2 : 1) * RT_TAPEZ_HALF)   // floats per (tile, step, stage) of the layer-1 tape: 3 nets x 7 groups x 64 lanes x 4 (RT_ZRICH: values, then derivatives)
+#define RT_TAPEZ (RT_Z2OFF + (RT_Z2TAPE ? 9 * 256 : 0)) // ... and of the whole pre-activation record (layer 2 behind layer 1: net n's register r < 10 = features 2r, 2r+1 is element r & 3 of group 3n + (r >> 2))
 #define RT_TAPE2 (20 * 256)   // ... of the layer-1 delta tape: 20 groups x 64 lanes x 4, the three nets' 25 registers stacked (G = 25 n + g)
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -962,6 +968,19 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
         }
     };
 
+    // taped layer-2 pre-activations of net n (RT_Z2TAPE): registers r < 10 of Z (the rest zero)
+    auto load_z2 = [&](int step, int st, int n, f32x16& Z) {
+        const float* srcz = tpz + ((size_t)step * 4 + st) * RT_TAPEZ + RT_Z2OFF + n * 3 * 256;
+#pragma unroll
+        for (int grp = 0; grp < 3; grp++) {
+            const f32x4v v = RT_TAPE_LOAD4(srcz + grp * 256);
+#pragma unroll
+            for (int e = 0; e < 4; e++) Z[4 * grp + e] = (4 * grp + e < 10) ? v[e] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 12; r < 16; r++) Z[r] = 0.0f;
+    };
+
     // stage input (taped by the forward kernel)
     auto load_x = [&](int step, int st) {
         const float* src = tp + ((size_t)step * 4 + st) * 3072;
@@ -1044,7 +1063,8 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     }
                     RT_STAMP(1);
                     f32x16 Z2;
-                    {
+                    if (ZT && RT_Z2TAPE) load_z2(step, st, n, Z2);      // taped by the forward kernel: in flight under the dO transposition and the W3^T chain below
+                    else {
                         f32x16 acc;
 #pragma unroll
                         for (int r = 0; r < 16; r++) acc[r] = r < 10 ? wl[RT_B2C + n * 20 + 2 * r + h] : 0.0f;
@@ -1054,7 +1074,8 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     }
                     RT_STAMP(2);
                     // (3) layer 3: weight/bias gradient, then dZ2 = (W3^T dO) .* act'(Z2)
-                    //     (evaluating the layer-2 activation pairs inside the W3^T chain instead was measured slower: 94.8 vs 89.7 ms)
+                    //     (evaluating the layer-2 activation pairs inside the W3^T chain instead was measured slower: 94.8 vs 89.7 ms; W3^T first, so that the taped
+                    //      Z2 has the chain to land under: more spills, slower — round 5)
                     {
                         const f32x16 TA = rt_transpose(tb, dOn, wbase, rbase);
                         b3acc[n] += rt_sum16(TA);
@@ -1864,6 +1885,15 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                         const int base = a2b[u] + n * 20 * RT_LD2, basel = a2l[u] + n * 20 * RT_LD2;
                         acc = rt16_chain<13, 13>(wl, acc, [=](int k) { return k < 12 ? base + 4 * k : basel; },
                                                  [&](int k) { return A1[(13 * n + k) >> 2][(13 * n + k) & 3]; });
+                        }
+                        if (RT_Z2TAPE && tz) {
+                            // layer-2 pre-activations in the adjoint's register-image format: feature f = 4 Q2 + g of net n is element (2 Q2 & 3) + (g >> 1) of group 3 n + (Q2 >> 1)
+                            float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ + RT_Z2OFF;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const int Q2 = 4 * u + r;
+                                if (Q2 < 5) oz[(3 * n + (Q2 >> 1)) * 256 + ((2 * Q2) & 3)] = acc[r];
+                            }
                         }
                         A2[u] = rt_act4<ACT>(acc);
                     }
