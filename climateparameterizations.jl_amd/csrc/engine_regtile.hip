@@ -1106,14 +1106,18 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     // fetch net n + 1's taped pre-activations now: dW2, W2^T and the first W1^T chunk cover the HBM latency
                     if (ZT && n < 2) load_z1(step, st, n + 1, A1n, D1n);
                     // (SPLIT) the nine l-plane operands of this net's W1^T products: from L2, issued before the dW2 outer products (one phase earlier than needed: 56.5 -> 55.6 ms)
+#ifndef RT_LPIPE
+#define RT_LPIPE 1        // round 5: the l planes fetched one k-block (three operands) ahead inside the W1^T products instead of all nine before dW2: 12-24 live registers instead of 36, scratch 536 -> 500 B, adjoint 56.2 -> 55.6 ms (0: A/B build)
+#endif
                     u32x4 Lr[9];
+                    const u32x4* lg = nullptr;
                     if constexpr (SPLIT) {
                         // (an opaque lane index per net: left loop-invariant, the 27 loads are hoisted out of the time loop and their 108 registers spilled)
                         int lz = lane;
                         asm volatile("" : "+v"(lz));
-                        const u32x4* lg = reinterpret_cast<const u32x4*>(wimg + RT_ASIMG_OFF + RT_ASIMG_L) + n * 9 * 64 + lz;
+                        lg = reinterpret_cast<const u32x4*>(wimg + RT_ASIMG_OFF + RT_ASIMG_L) + n * 9 * 64 + lz;
 #pragma unroll
-                        for (int u = 0; u < 9; u++) Lr[u] = lg[u * 64];
+                        for (int u = 0; u < (RT_LPIPE ? 3 : 9); u++) Lr[u] = lg[u * 64];
                     }
                     // (4) layer 2: weight/bias gradient
                     {
@@ -1176,6 +1180,10 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         const u32x4* hm = reinterpret_cast<const u32x4*>(rt_smem) + lane;
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
+                            if (RT_LPIPE && c < 2) {
+#pragma unroll
+                                for (int u = 0; u < 3; u++) Lr[3 * (c + 1) + u] = lg[(3 * (c + 1) + u) * 64];
+                            }
                             float d8[8];
 #pragma unroll
                             for (int u = 0; u < 8; u++) d8[u] = D1[(8 * c + u) >> 4][(8 * c + u) & 15];
