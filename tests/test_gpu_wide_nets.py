@@ -64,3 +64,39 @@ def test_wide_wind_mixing_networks_against_the_oracle(name, ma):
     # arithmetic asked for — dw_gemm_split_kernel with the 400 x 400 matrices cut into chunks of output blocks, or the f32 L2-streaming dw_gemm_kernel
     assert plan["matrix_arithmetic"] == ma and plan["engine"] == ENGINE_TILE16 and plan["dw_taped"]
     assert not (plan["bf16x3_forward"] or plan["bf16x3_adjoint"]) and plan["bf16x3_dw"] == (ma == "bf16x3_exact")
+
+
+def test_wide_networks_other_paths_rkc2_inplace_rhs_and_column_blocks(monkeypatch):
+    """The other kernels that keep the activation rows in global memory for 3 x (96-400-400-31): the RKC2 instantiations (the wind-mixing convective-adjustment
+    branch, kappa = 10, `ROCK4` in the reference: train_NDE.jl:143) — solve and gradient against the oracle; the in-place `NDE!` arithmetic through `rhs_kernel`
+    for MORE columns than the handle was created with (the slab grows); and the gradient path cut into column blocks (COLNDE_T16_BLOCK)."""
+    kw = WIDE["96-400-400-31_swish"]
+    p = synthetic.wind_mixing_problem(24, n_frames=3, weight_divisor=1e2, modified_pacanowski_philander=False, zero_weights=False, convective_adjustment=True,
+                                      kappa=10.0, stepper="rkc2", substeps=1, **kw)
+    truth = O.solve(p.cfg, p.x0, p.bcs, p.weights_truth).astype(np.float32)
+    sc = O.default_loss_scalings(p.cfg)
+    tot, terms, g, sol = O.loss_and_grad(p.cfg, p.x0, p.bcs, p.weights, truth, sc)
+    with colnde.ColumnNDE(p.cfg, 24) as nde:
+        assert "activation_rows=global_memory" in nde.describe() and "rkc2" in nde.describe()
+        nde.set_problem(p.x0, p.bcs, truth)
+        sol_g = nde.forward(p.weights)
+        tot_g, _, grad_g = nde.loss_grad(p.weights, sc)
+        assert nde.plan()["approximate_gradient"]                       # one switch pattern per RKC2 step (include/colnde.h), as in the oracle
+    _record("wide/rkc2_kappa10", sol_abs=np.abs(sol_g - sol).max(), loss_rel=abs(tot_g - tot) / tot, grad_rel=_rel(grad_g, g))
+    assert np.abs(sol_g - sol).max() < 1e-4 and np.isclose(tot_g, tot, rtol=2e-3) and _rel(grad_g, g) < 2e-3
+
+    q = synthetic.wind_mixing_problem(70, n_frames=3, weight_divisor=10.0, inplace_variant=True, **kw)
+    with colnde.ColumnNDE(q.cfg, 8) as nde:                             # created for 8 columns, asked for 70: the slab of rows grows
+        got = nde.rhs(q.x0, q.weights, q.bcs, 0.0)
+    assert _rel(got, O.rhs(q.cfg, q.x0, q.bcs, q.weights)) < 1e-6
+
+    r = synthetic.wind_mixing_problem(80, n_frames=4, weight_divisor=1e2, **kw)
+    truth = O.solve(r.cfg, r.x0, r.bcs, r.weights_truth).astype(np.float32)
+    tot, terms, g, sol = O.loss_and_grad(r.cfg, r.x0, r.bcs, r.weights, truth, sc)
+    monkeypatch.setenv("COLNDE_T16_BLOCK", "32")
+    with colnde.ColumnNDE(r.cfg, 80) as nde:
+        nde.set_problem(r.x0, r.bcs, truth)
+        tot_g, terms_g, grad_g = nde.loss_grad(r.weights, sc)
+        assert nde.plan()["n_blocks"] == 3
+    np.testing.assert_allclose(terms_g, terms, rtol=10 * LOSS_RTOL, atol=0)
+    assert _rel(grad_g, g) < GRAD_REL
