@@ -1624,6 +1624,38 @@ __device__ __forceinline__ f32x4t rt16_chain_fill(const float* wl, f32x4t acc, A
     return acc;
 }
 
+// Z1 tape store of layer-1 tile tt of the 16-column forward kernels (the adjoint's per-net register-image format: feature f = 4 qq + g of net n is element
+// 2 (qq & 1) + (g >> 1) of group qq >> 1 at lane32 = j + 16 half + 32 (g & 1)).  Round 5 A/B (-DRT_Z1_DWORD=0): 16-byte stores instead of dword stores.  The lanes g and g ^ 2
+// (= lane ^ 32) hold the two halves of every group; two v_permlane32_swap per FOUR consecutive qq hand lanes g < 2 the complete group qq0 >> 1 and lanes
+// g >= 2 the complete next group, so a net's twelve quads leave with three 16-byte stores per lane (all 64 lanes storing) instead of twelve dword stores;
+// quad 12 (features 48, 49: lanes g < 2) keeps its dword store.  A chunk of four quads may straddle two tiles: the pre-activations wait in zpre (compile-time indices).
+// MEASURED SLOWER: forward 28.0 -> 31.7 ms (bit-identical tapes; 39 dword stores become 9 16-byte stores + 3 dword stores + 18 swaps per lane and stage, but the swaps and the
+// waiting pre-activations cost the 128-register kernel more than the store instructions did) — the dword stores stay.
+#ifndef RT_Z1_DWORD
+#define RT_Z1_DWORD 1         // 1: dword stores (shipped); 0: the 16-byte variant (A/B build)
+#endif
+__device__ __forceinline__ void rt16_tape_z1(float* oz /* tz + record offset (lane part and (g >> 1) folded in) */, float (&zpre)[40], const f32x4t z, int tt, int g) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int Q = 4 * tt + r, qq = Q % 13, net = Q / 13;
+        if (Q >= 39) continue;
+        if (RT_Z1_DWORD) {
+            if (qq < 12 || g < 2) oz[(net * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = z[r];
+            continue;
+        }
+        zpre[Q] = z[r];
+        if (qq == 12) {
+            if (g < 2) oz[(net * 7 + 6) * 256] = z[r];
+        } else if ((qq & 3) == 3) {
+            const int Q0 = Q - 3;
+            const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(zpre[Q0]), __float_as_uint(zpre[Q0 + 2]), false, false);
+            const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(zpre[Q0 + 1]), __float_as_uint(zpre[Q0 + 3]), false, false);
+            const f32x4v v = {__uint_as_float(s02[0]), __uint_as_float(s02[1]), __uint_as_float(s13[0]), __uint_as_float(s13[1])};
+            *reinterpret_cast<f32x4v*>(oz - (g >> 1) + (net * 7 + ((qq - 3) >> 1) + (g >> 1)) * 256) = v;
+        }
+    }
+}
+
 template <int ACT, bool SPLIT = false>
 __global__ void __launch_bounds__(512)
 rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __restrict__ x0, const float* __restrict__ bcs,
@@ -1730,6 +1762,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                 RT_STAMP(0);
                 // ---- three MLPs -------------------------------------------------------------------------------------
                 f32x4t A1[10];
+                float zpre[40];             // layer-1 pre-activations waiting for their 16-byte tape store (rt16_tape_z1): at most one tile's worth is live
                 // operand addresses stay (lane base + immediate): left loop-invariant, all ~150 of them are computed outside the time loop and spilled
                 int lz = lane;
                 if constexpr (SPLIT) asm volatile("" : "+v"(lz));
@@ -1754,14 +1787,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                             const int nx = q * 10 + t + 1;                                        // the group after (q, t) in this order
                             if (nx < 30) Apf = rt16_ldA(simg, 3 * (nx % 10) + nx / 10, lz);
                             auto finish = [&](int tt) {        // tile tt is complete: tape store, activation
-                                if (tz && !RT_ZRICH) {
-                                    float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
-#pragma unroll
-                                    for (int r = 0; r < 4; r++) {
-                                        const int Q = 4 * tt + r, qq = Q % 13;
-                                        if (Q < 39 && (qq < 12 || g < 2)) oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = A1[tt][r];
-                                    }
-                                }
+                                if (tz && !RT_ZRICH) rt16_tape_z1(tz + ((size_t)step * 4 + st) * RT_TAPEZ, zpre, A1[tt], tt, g);
                                 // (side-effect-free arithmetic is not ordered against the scheduling fences when the block is linearised: the empty
                                 //  asm statements pin the activation's inputs below the products' issue point and its results above the closing fence)
 #pragma unroll
@@ -1809,14 +1835,7 @@ rt16_forward_kernel(DevModel m, const float* __restrict__ wimg, const float* __r
                     }
                 } else {
                 auto finish1 = [&](int tt) {          // tile tt of layer 1 is complete: Z1 tape store, activation (pinned: see rt16_chain_fill)
-                    if (tz && !RT_ZRICH) {
-                        float* oz = tz + ((size_t)step * 4 + st) * RT_TAPEZ;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int Q = 4 * tt + r, qq = Q % 13;
-                            if (Q < 39 && (qq < 12 || g < 2)) oz[((Q / 13) * 7 + (qq >> 1)) * 256 + ((2 * qq) & 3)] = A1[tt][r];
-                        }
-                    }
+                    if (tz && !RT_ZRICH) rt16_tape_z1(tz + ((size_t)step * 4 + st) * RT_TAPEZ, zpre, A1[tt], tt, g);
 #pragma unroll
                     for (int r = 0; r < 4; r++) asm volatile("" : "+v"(A1[tt][r]));
                     if (RT_ZRICH && tz) {
