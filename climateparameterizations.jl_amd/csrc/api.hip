@@ -97,6 +97,8 @@ struct colnde_handle {
     int min_substeps = 1;           // least RK4 sub-steps per save interval inside the diffusive stability bound
     bool auto_substeps = false;     // cfg.substeps = 0 at creation: the first solve call chooses the sub-step count from cfg.reltol (choose_substeps)
     float last_estimate = -1.0f;    // ... and the error estimate it settled on
+    unsigned* d_sf = nullptr;       // DevModel::sf / sb: bf16 plane images of the dense chains (networks with rows in global memory, BF16X3_EXACT)
+    unsigned* d_sb = nullptr;
     float* d_ag = nullptr;          // DevModel::ag: per-tile activation / delta rows in global memory (networks whose rows do not fit the LDS)
     size_t ag_tiles = 0;            // ... tiles it holds
     std::vector<float> rkc_host;    // host copy of the RKC2 coefficient table in use (refresh_rkc)
@@ -331,6 +333,9 @@ static void resolve_arithmetic(colnde_handle* h) {
     h->sp_fwd = ov("COLNDE_FWD_SPLIT");
     h->sp_adj = ov("COLNDE_ADJ_SPLIT");
     h->sp_dw = ov("COLNDE_DW_SPLIT");
+    // tile16 with rows in global memory: the dense chains follow the arithmetic (plane images packed beside the f32 ones)
+    h->m.sf = (h->ag_rows && h->sp_fwd) ? h->d_sf : nullptr;
+    h->m.sb = (h->ag_rows && h->sp_adj) ? h->d_sb : nullptr;
 }
 
 // DevModel::ag for `tiles` workgroups (zero-filled once: the pad slots behind a layer's last feature are never written and must read as zero)
@@ -465,6 +470,23 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         }
         h->geo_ok = false;
         if (ensure_ag(h, (size_t)h->n_tiles)) { delete h; return 1; }
+        // plane images of the dense chains (16-byte items): forward [16-row tile][32-deep k-block][3 planes][64 lanes], transposed likewise
+        int fo = 0, bo = 0;
+        for (int l = 0; l < h->m.n_layers; l++) {
+            const int ni = h->m.sizes[l], no = h->m.sizes[l + 1];
+            h->m.sf_off[l] = fo;
+            h->m.sb_off[l] = bo;
+            fo += ((no + 15) / 16) * ((ni + 31) / 32) * 3 * 64;
+            bo += ((ni + 15) / 16) * ((no + 31) / 32) * 3 * 64;
+        }
+        h->m.sf_net = fo;
+        h->m.sb_net = bo;
+        if (hipMalloc((void**)&h->d_sf, (size_t)fo * h->m.n_nets * 16) != hipSuccess || hipMalloc((void**)&h->d_sb, (size_t)bo * h->m.n_nets * 16) != hipSuccess) {
+            (void)hipGetLastError();
+            colnde_destroy(h);
+            return fail("allocating the bf16 plane images failed");
+        }
+        resolve_arithmetic(h);
     }
     if (h->lds_adj > lds_cap) h->geo_ok = false;
     {
@@ -571,7 +593,7 @@ extern "C" void colnde_destroy(colnde_handle* h) {
     (void)hipSetDevice(h->device);
     drain_events(h);
     void* ptrs[] = {h->d_rt_tapez, h->d_rt_tape, h->d_rt_tape2, h->d_rt_slab, h->d_wimg, h->d_w, h->d_wf, h->d_wb, h->d_x0, h->d_bcs, h->d_truth, h->d_sol, h->d_tape, h->d_slab, h->d_out,
-                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc, h->d_ag,
+                    h->d_times, h->d_partial, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, h->d_tiles, h->d_bias_zoff, h->d_bias_goff, h->d_dwtape, h->d_macros, h->d_t16_ztape, h->d_rkc, h->d_ag, h->d_sf, h->d_sb,
                     h->d_fc_imgf, h->d_fc_imgb, h->d_fc_bias, h->d_fc_masks, h->d_fc_switch, h->d_fc_lam, h->d_fc_simgf, h->d_fc_simgb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -673,6 +695,10 @@ extern "C" int colnde_set_problem_dev(colnde_handle* h, const float* x0, const f
 static int pack(colnde_handle* h, const float* d_weights) {
     hipError_t e = launch_pack(h->m, h->pk, d_weights, h->d_wf, h->d_wb, h->stream);
     if (e != hipSuccess) return fail("pack_weights launch failed: %s", hipGetErrorString(e));
+    if (h->d_sf && (h->m.sf || h->m.sb)) {
+        e = launch_pack_planes(h->m, d_weights, h->d_sf, h->d_sb, h->stream);
+        if (e != hipSuccess) return fail("pack_planes launch failed: %s", hipGetErrorString(e));
+    }
     return 0;
 }
 
@@ -1865,8 +1891,8 @@ extern "C" int colnde_plan(const colnde_handle* h, int info[8]) {
         bf_adj = h->sp_adj && fc_split_supported(h->fc_cw);
         bf_dw = h->sp_dw && (h->d_dwtape ? !h->dw_split.passes.empty() : true);
     } else {
-        bf_fwd = h->sp_fwd && h->fwd_split && h->fwd_helper;
-        bf_adj = h->sp_adj && h->adj_split && rt_adjoint_split_has_bf16(h->m, h->adj_helper) && (h->t16_dwtape < 0 || (h->t16_dwtape == 1 && h->d_t16_ztape));
+        bf_fwd = (h->sp_fwd && h->fwd_split && h->fwd_helper) || h->m.sf != nullptr;
+        bf_adj = (h->sp_adj && h->adj_split && rt_adjoint_split_has_bf16(h->m, h->adj_helper) && (h->t16_dwtape < 0 || (h->t16_dwtape == 1 && h->d_t16_ztape))) || h->m.sb != nullptr;
         bf_dw = h->sp_dw && h->t16_dwtape == 1 && !h->dw_split.passes.empty();
     }
     info[7] |= (bf_fwd ? 2 : 0) | (bf_adj ? 4 : 0) | (bf_dw ? 8 : 0);

@@ -53,6 +53,12 @@ struct DevModel {
     // 3 x 96-400-400-31: 160 KB of rows alone): the tile16 kernels then keep THAT array in a per-workgroup slab of global memory (L2-resident:
     // written and read by the same workgroup between its own barriers) and everything else in LDS as before.  nullptr: rows in LDS.
     float* ag;
+    // ... and, for those networks under COLNDE_MATRIX_BF16X3_EXACT, the dense chains of the tile16 kernels run on the bf16 pipe from pre-split weight planes (round 5):
+    // sf / sb = forward / transposed A-operand images [net][layer][16-row tile][32-deep k-block][plane h, m, l][64 lanes] of 16 bytes (8 bf16: k = 32 S + 8 (lane >> 4) + e),
+    // offsets in 16-byte units.  nullptr: f32 chains (packed f32 images).
+    const unsigned* sf;
+    const unsigned* sb;
+    int sf_off[COLNDE_MAX_LAYERS], sb_off[COLNDE_MAX_LAYERS], sf_net, sb_net;
 };
 #define RKC_LD 260
 

@@ -35,6 +35,8 @@ static inline size_t lds_floats_adjoint_noA(const DevModel& m) { return lds_floa
 
 hipError_t set_kernel_attributes(size_t max_lds_bytes);
 hipError_t launch_pack(const DevModel& m, const PackInfo& pk, const float* w, float* wf, float* wb, hipStream_t stream);
+// bf16 plane images of the dense chains (DevModel::sf / sb; offsets and sizes in m, 16-byte units): the weights split exactly, once per call
+hipError_t launch_pack_planes(const DevModel& m, const float* w, unsigned* sf, unsigned* sb, hipStream_t stream);
 // dx [n_col][ns] tendencies and / or flux [n_col][n_nets][Nz + 1] face fluxes (predict_flux); either may be null
 hipError_t launch_rhs(const DevModel& m, const PackInfo& pk, const float* w, const float* wf, const float* x,
                       const float* bcs, float t, float* dx, int n_col, int nthreads, size_t lds_bytes, hipStream_t stream, float* flux = nullptr);

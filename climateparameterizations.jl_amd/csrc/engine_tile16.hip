@@ -276,6 +276,208 @@ __device__ __forceinline__ void mlp_backward(const DevModel& m, const PackInfo& 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The dense chains on the bf16 pipe (round 5; networks whose activation rows live in global memory — DevModel::ag — under COLNDE_MATRIX_BF16X3_EXACT): exact
+// three-way operand split (split_bf16.h), six v_mfma_f32_16x16x32_bf16 per 32-deep k-block and 16-row tile.  The weights are split ONCE per call by
+// pack_planes_kernel; the activation row's eight values of a lane are split once per k-block and shared by the TG row tiles a wave owns (the split costs
+// as much vector time as six of these MFMAs cost matrix time: one tile per split would buy nothing).
+// ------------------------------------------------------------------------------------------------
+typedef float t16_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 t16_mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 t16_mfma_bf3(const Bf3& a, const Bf3& b, f32x4 c) {     // smallest products first
+    c = t16_mfma_bf(a.m, b.m, c);
+    c = t16_mfma_bf(a.l, b.h, c);
+    c = t16_mfma_bf(a.h, b.l, c);
+    c = t16_mfma_bf(a.m, b.h, c);
+    c = t16_mfma_bf(a.h, b.m, c);
+    c = t16_mfma_bf(a.h, b.h, c);
+    return c;
+}
+#define T16_TG 5      // row tiles per wave and split (25 tiles of a 400-row layer: five jobs per net)
+
+__global__ void pack_planes_kernel(DevModel m, const float* __restrict__ w, unsigned* __restrict__ sf, unsigned* __restrict__ sb) {
+    const long total_f = (long)m.sf_net * m.n_nets, total_b = (long)m.sb_net * m.n_nets;         // 16-byte items
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)gridDim.x * blockDim.x) {
+        const bool fwd = idx < total_f;
+        long e = fwd ? idx : idx - total_f;
+        const int pn = fwd ? m.sf_net : m.sb_net;
+        const int net = (int)(e / pn);
+        e -= (long)net * pn;
+        int l = 0;
+        while (l + 1 < m.n_layers && e >= (fwd ? m.sf_off[l + 1] : m.sb_off[l + 1])) l++;
+        e -= fwd ? m.sf_off[l] : m.sb_off[l];
+        const int ni = m.sizes[l], no = m.sizes[l + 1];
+        const int lane = (int)(e & 63), plane = (int)((e >> 6) % 3);
+        const long blk = (e >> 6) / 3;
+        const int nS = fwd ? (ni + 31) >> 5 : (no + 31) >> 5;
+        const int tile = (int)(blk / nS), S = (int)(blk - (long)tile * nS);
+        const float* W = w + (size_t)net * m.net_size + m.w_off[l];
+        const int i = tile * 16 + (lane & 15);
+        unsigned out[4];
+#pragma unroll
+        for (int pr = 0; pr < 4; pr++) {
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int k = 32 * S + 8 * (lane >> 4) + 2 * pr + q;
+                float x = 0.0f;
+                if (fwd) { if (i < no && k < ni) x = W[(size_t)k * no + i]; }            // A[i = out row][k = in]
+                else { if (i < ni && k < no) x = W[(size_t)i * no + k]; }               // A[i = in row][k = out]
+                const float hh = __uint_as_float(__float_as_uint(x) & 0xffff0000u), r1 = x - hh;
+                const float mm = __uint_as_float(__float_as_uint(r1) & 0xffff0000u), ll = r1 - mm;
+                v[q] = plane == 0 ? hh : (plane == 1 ? mm : ll);
+            }
+            out[pr] = (__float_as_uint(v[1]) & 0xffff0000u) | (__float_as_uint(v[0]) >> 16);
+        }
+        unsigned* dst = (fwd ? sf : sb) + (size_t)(fwd ? idx : idx - total_f) * 4;
+        dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+    }
+}
+
+// eight consecutive floats of an activation / delta row (8-byte aligned) as a split B operand
+__device__ __forceinline__ Bf3 t16_row_split8(const float* p) {
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float2 v = *reinterpret_cast<const float2*>(p + 2 * q);
+        x[2 * q] = v.x; x[2 * q + 1] = v.y;
+    }
+    return bf3_split8(x);
+}
+
+// forward pass of all nets with the chains on the bf16 pipe (the f32 twin is mlp_forward<false, false>)
+__device__ __forceinline__ void mlp_forward_split(const DevModel& m, const float* w, const float* xs, float* A, int wave, int nwaves, int lane,
+                                                  float* __restrict__ zrec = nullptr, int zld = 0) {
+    const int c = lane & 15, kq = lane >> 4;
+    const u32x4* sf = reinterpret_cast<const u32x4*>(m.sf);
+    for (int l = 0; l < m.n_layers; l++) {
+        const int ni = m.sizes[l], no = m.sizes[l + 1];
+        const int nmt = (no + 15) >> 4, nS = (ni + 31) >> 5, ngrp = (nmt + T16_TG - 1) / T16_TG;
+        const int act = m.acts[l];
+        for (int job = wave; job < ngrp * m.n_nets; job += nwaves) {
+            const int net = job / ngrp, mt0 = (job - net * ngrp) * T16_TG;
+            const float* bl = w + (size_t)net * m.net_size + m.b_off[l];
+            const float* in = (l == 0) ? xs + c * m.ld_x : A + (net * CT + c) * m.ld_a + m.act_off[l - 1];
+            f32x4 acc[T16_TG];
+#pragma unroll
+            for (int t = 0; t < T16_TG; t++) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            const u32x4* ap = sf + (size_t)net * m.sf_net + m.sf_off[l] + (size_t)mt0 * nS * 3 * 64 + lane;
+            // the A planes run TWO tiles ahead of their products (L2 latency under the other waves' and this wave's MFMAs); tiles past the layer's last
+            // one read the last tile's planes again (never used)
+            const int ntl = min(T16_TG, nmt - mt0);
+            auto ldA = [&](int q) {                      // q = S * T16_TG + t, clamped
+                const int S = min(q / T16_TG, nS - 1), t = min(q % T16_TG, ntl - 1);
+                const u32x4* a = ap + ((size_t)t * nS + S) * 3 * 64;
+                Bf3 r;
+                r.h = a[0]; r.m = a[64]; r.l = a[128];
+                return r;
+            };
+            Bf3 A0 = ldA(0), A1_ = ldA(1);
+            for (int S = 0; S < nS; S++) {
+                const Bf3 B = t16_row_split8(in + 32 * S + 8 * kq);
+#pragma unroll
+                for (int t = 0; t < T16_TG; t++) {
+                    const Bf3 Aop = A0;
+                    A0 = A1_;
+                    A1_ = ldA(S * T16_TG + t + 2);
+                    if (t < ntl) acc[t] = t16_mfma_bf3(Aop, B, acc[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T16_TG; t++) {
+                const int mt = mt0 + t;
+                if (mt >= nmt) continue;
+                const int ro = (net * CT + c) * m.ld_a + m.act_off[l];
+                float zv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = mt * 16 + 4 * kq + r;
+                    zv[r] = acc[t][r] + bl[min(row, no - 1)];
+                    if (row < no) A[ro + row] = dev_act(act, zv[r]);
+                }
+                if (zrec && l + 1 < m.n_layers) {
+                    float* zo = zrec + c * zld + net * m.act_off[m.n_layers - 1] + m.act_off[l] + mt * 16 + 4 * kq;
+                    if (mt * 16 + 4 * kq + 3 < no) *reinterpret_cast<float4*>(zo) = make_float4(zv[0], zv[1], zv[2], zv[3]);
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (mt * 16 + 4 * kq + r < no) zo[r] = zv[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// backward pass, layers L-1 .. 1 on the bf16 pipe (the layer-0 pullback into xb — 6 row tiles, a sum over the nets — stays on the f32 chain: 3 % of the work)
+__device__ __forceinline__ void mlp_backward_split(const DevModel& m, const PackInfo& pk, const float* __restrict__ wb, float* Z, float* xb, int wave, int nwaves, int lane) {
+    const int c = lane & 15, jq = lane >> 4;
+    const u32x4* sb = reinterpret_cast<const u32x4*>(m.sb);
+    for (int l = m.n_layers - 1; l >= 1; l--) {
+        const int ni = m.sizes[l], no = m.sizes[l + 1];
+        const int nit = (ni + 15) >> 4, nS = (no + 31) >> 5, ngrp = (nit + T16_TG - 1) / T16_TG;
+        const int actp = m.acts[l - 1];
+        for (int job = wave; job < ngrp * m.n_nets; job += nwaves) {
+            const int net = job / ngrp, it0 = (job - net * ngrp) * T16_TG;
+            const float* dz = Z + (net * CT + c) * m.ld_a + m.act_off[l];
+            f32x4 acc[T16_TG];
+#pragma unroll
+            for (int t = 0; t < T16_TG; t++) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            const u32x4* ap = sb + (size_t)net * m.sb_net + m.sb_off[l] + (size_t)it0 * nS * 3 * 64 + lane;
+            const int ntl = min(T16_TG, nit - it0);
+            auto ldA = [&](int q) {
+                const int S = min(q / T16_TG, nS - 1), t = min(q % T16_TG, ntl - 1);
+                const u32x4* a = ap + ((size_t)t * nS + S) * 3 * 64;
+                Bf3 r;
+                r.h = a[0]; r.m = a[64]; r.l = a[128];
+                return r;
+            };
+            Bf3 A0 = ldA(0), A1_ = ldA(1);
+            for (int S = 0; S < nS; S++) {
+                const Bf3 B = t16_row_split8(dz + 32 * S + 8 * jq);
+#pragma unroll
+                for (int t = 0; t < T16_TG; t++) {
+                    const Bf3 Aop = A0;
+                    A0 = A1_;
+                    A1_ = ldA(S * T16_TG + t + 2);
+                    if (t < ntl) acc[t] = t16_mfma_bf3(Aop, B, acc[t]);
+                }
+            }
+            const int ro = (net * CT + c) * m.ld_a + m.act_off[l - 1];
+#pragma unroll
+            for (int t = 0; t < T16_TG; t++) {
+                if (it0 + t >= nit) continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = (it0 + t) * 16 + 4 * jq + r;
+                    if (row < ni) Z[ro + row] = acc[t][r] * dev_act_grad(actp, Z[ro + row]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {   // l = 0: xb += sum over nets of W_1^T dZ_1 (f32 chain from the packed image)
+        const int ni = m.sizes[0], no = m.sizes[1];
+        const int nit = (ni + 15) >> 4, nS = (no + 15) >> 4;
+        for (int it = wave; it < nit; it += nwaves) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int net = 0; net < m.n_nets; net++) {
+                const float* dz = Z + (net * CT + c) * m.ld_a + m.act_off[0];
+                const float4* ap4 = reinterpret_cast<const float4*>(wb + (size_t)net * pk.pb_net + pk.pb_off[0]) + (size_t)it * nS * 64 + lane;
+                acc = gemm_chain4<GU4>(ap4, dz + 4 * jq, nS, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = it * 16 + 4 * jq + r;
+                if (row < ni) xb[c * m.ld_x + row] += acc[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // physics
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float filt3(const float* x, int i, int N) {   // (F x)[i], filtering_operators.jl:1-14
@@ -735,7 +937,8 @@ __global__ void __launch_bounds__(256) rhs_kernel(DevModel m, PackInfo pk, const
         xs[c * m.ld_x + i] = x[(size_t)min(col0 + c, n_col - 1) * m.ns + i];
     }
     __syncthreads();
-    mlp_forward<false, false>(m, pk, w, wf, xs, nullptr, A, wave, nwaves, lane);
+    if (AG && m.sf) mlp_forward_split(m, w, xs, A, wave, nwaves, lane);
+    else mlp_forward<false, false>(m, pk, w, wf, xs, nullptr, A, wave, nwaves, lane);
     physics_forward(m, xs, A, F, Ri_l, bcl, t, kk, tid, nth);
     if (dx)
         for (int it = tid; it < CT * m.ns; it += nth) {
@@ -842,6 +1045,9 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
                     }
                     __syncthreads();
                     if (last) break;
+                    if (AG && m.sf) mlp_forward_split(m, wsrc, xs, A, wave, nwaves, lane,
+                                             ztape ? ztape + ((size_t)blockIdx.x * n_steps * nst + (size_t)step * nst + st) * ((size_t)CT * zld) : nullptr, zld);
+                    else
                     mlp_forward<false, WLDS>(m, pk, wsrc, wf, xs, nullptr, A, wave, nwaves, lane,
                                              ztape ? ztape + ((size_t)blockIdx.x * n_steps * nst + (size_t)step * nst + st) * ((size_t)CT * zld) : nullptr, zld);
                     physics_forward(m, xs, A, F, Ri_l, bcl, ts + c_t[st] * dt, kk, tid, nth);
@@ -876,6 +1082,9 @@ __global__ void __launch_bounds__(NTH) forward_kernel(DevModel m, PackInfo pk, c
                     }
                 }
                 __syncthreads();
+                if (AG && m.sf) mlp_forward_split(m, wsrc, xs, A, wave, nwaves, lane,
+                                         ztape ? ztape + ((size_t)blockIdx.x * n_steps * 4 + (size_t)step * 4 + st) * ((size_t)CT * zld) : nullptr, zld);
+                else
                 mlp_forward<false, WLDS>(m, pk, wsrc, wf, xs, nullptr, A, wave, nwaves, lane,
                                          ztape ? ztape + ((size_t)blockIdx.x * n_steps * 4 + (size_t)step * 4 + st) * ((size_t)CT * zld) : nullptr, zld);
                 physics_forward(m, xs, A, F, Ri_l, bcl, ts + ca * dt, kk, tid, nth);
@@ -1194,7 +1403,8 @@ adjoint_kernel(DevModel m_arg, PackInfo pk, const float* __restrict__ w, const f
                 STAMP(1);
                 physics_vjp(m, xs, dbar, Z, xb, gb, Ri_l, Rib_l, tid, nth, rkc ? (st == nst - 1 ? 1 : 2) : 0);
                 STAMP(2);
-                mlp_backward<WLDS>(m, pk, wsrc, wb, Z, xb, wave, nwaves, lane);
+                if (AG && m.sb) mlp_backward_split(m, pk, wb, Z, xb, wave, nwaves, lane);
+                else mlp_backward<WLDS>(m, pk, wsrc, wb, Z, xb, wave, nwaves, lane);
                 STAMP(3);
                 // weight gradients: dW += A_{l-1}^T dZ_l over the tile's 16 columns; operands of slot sl+1 are read
                 // while the MFMAs of slot sl run
@@ -1892,6 +2102,12 @@ bool pick_adjoint_geom(const DevModel& m, AdjointGeom* geo, int force) {
 hipError_t launch_pack(const DevModel& m, const PackInfo& pk, const float* w, float* wf, float* wb, hipStream_t stream) {
     const int total = (pk.pf_net + pk.pb_net) * m.n_nets;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, m, pk, w, wf, wb);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_planes(const DevModel& m, const float* w, unsigned* sf, unsigned* sb, hipStream_t stream) {
+    const long total = ((long)m.sf_net + m.sb_net) * m.n_nets;
+    hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 65535)), dim3(256), 0, stream, m, w, sf, sb);
     return hipGetLastError();
 }
 

@@ -37,10 +37,12 @@ enum { COLNDE_ENGINE_AUTO = 0,      /* regtile when the configuration is one it 
                                        the CU's 160 KB of LDS — the reference's WIDE wind-mixing architectures, 3 x Chain(Dense(96,400,σ), Dense(400,400,σ),
                                        Dense(400,31)) of wind_mixing/train_NDE.jl:101-102 and train_NDE_args.jl:150-166 (their rows alone are 160 KB) — run
                                        with that one array in a per-workgroup slab of global memory (L2-resident) and the taped weight-gradient path
-                                       (colnde_describe: "activation_rows=global_memory"); 3 x (96-400-31) fits the LDS.  Which pipe: tile16's forward
-                                       and adjoint kernels are f32-MFMA kernels under EITHER matrix_arithmetic; its tape GEMM (dW) follows the
-                                       arithmetic asked for (colnde_plan info[7] bit 3).  4,096 columns x 32 steps of 3 x (96-400-400-31 swish),
-                                       fwd + adjoint: 41 ms = 48 algorithmic TFLOP/s (profiles/r05_wide_networks.log). */
+                                       (colnde_describe: "activation_rows=global_memory"); 3 x (96-400-31) fits the LDS.  Which pipe: for the networks with rows in
+                                       global memory the dense chains of the forward and the taped adjoint AND the tape GEMM (dW) follow matrix_arithmetic
+                                       (BF16X3_EXACT: pre-split weight planes, v_mfma_f32_16x16x32_bf16; colnde_plan info[7] bits 1-3); every other
+                                       tile16 shape runs f32-MFMA forward / adjoint kernels under either arithmetic and only its tape GEMM follows it.
+                                       4,096 columns x 32 steps of 3 x (96-400-400-31 swish), fwd + adjoint: 41 ms = 48 algorithmic TFLOP/s
+                                       (52 ms under F32_MFMA; profiles/r05_wide_networks.log — bound by the weight stream from L2, not by the pipe). */
        COLNDE_ENGINE_MFMA = 2,      /* regtile: 32 columns per wavefront resident in registers (static 96-50-20-31 wind-mixing
                                        shape; colnde_create fails if the configuration is not covered) */
        COLNDE_ENGINE_FC32 = 3 };    /* fc32: 32-column v_mfma_f32_32x32x2_f32 tiles (16-column v_mfma_f32_16x16x4_f32 tiles up to 4,096 columns)

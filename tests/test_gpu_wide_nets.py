@@ -63,7 +63,8 @@ def test_wide_wind_mixing_networks_against_the_oracle(name, ma):
     # which pipe ran (include/colnde.h says so): tile16's forward and adjoint are f32-MFMA kernels under either arithmetic; the tape GEMM (dW) follows the
     # arithmetic asked for — dw_gemm_split_kernel with the 400 x 400 matrices cut into chunks of output blocks, or the f32 L2-streaming dw_gemm_kernel
     assert plan["matrix_arithmetic"] == ma and plan["engine"] == ENGINE_TILE16 and plan["dw_taped"]
-    assert not (plan["bf16x3_forward"] or plan["bf16x3_adjoint"]) and plan["bf16x3_dw"] == (ma == "bf16x3_exact")
+    wide2 = len(WIDE[name]["layer_sizes"]) == 4            # 400-400: rows in global memory, dense chains on the bf16 pipe under the default arithmetic
+    assert plan["bf16x3_forward"] == plan["bf16x3_adjoint"] == (wide2 and ma == "bf16x3_exact") and plan["bf16x3_dw"] == (ma == "bf16x3_exact")
 
 
 def test_wide_networks_other_paths_rkc2_inplace_rhs_and_column_blocks(monkeypatch):
