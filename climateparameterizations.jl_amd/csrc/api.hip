@@ -461,9 +461,9 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
         h->lds_fwd = rest;
         h->lds_fwd_solve = rest;
         h->fwd_wlds = false;
-        // few tiles (<= 2 per CU): one 1,024-thread workgroup per tile, four waves per SIMD to hide the row loads from L2 (4,096 columns: 21.0 -> see DESIGN);
-        // many tiles: 256-thread workgroups, several per CU.  COLNDE_FWD_THREADS=256|1024 overrides.
-        h->fwd_threads = h->n_tiles <= 512 ? 1024 : 256;
+        // one 1,024-thread workgroup per tile (four waves per SIMD hide the row and weight loads from L2): 12.4 M column-timesteps/s forward at 4,096 ... 32,768
+        // columns against 8.6 M with 256-thread workgroups (tools/wide_threads.py).  COLNDE_FWD_THREADS=256|1024 overrides.
+        h->fwd_threads = 1024;
         {
             const char* et = getenv("COLNDE_FWD_THREADS");
             if (et && (atoi(et) == 256 || atoi(et) == 1024)) h->fwd_threads = atoi(et);
