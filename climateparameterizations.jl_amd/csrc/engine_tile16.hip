@@ -335,14 +335,16 @@ __global__ void pack_planes_kernel(DevModel m, const float* __restrict__ w, unsi
     }
 }
 
-// eight consecutive floats of an activation / delta row (8-byte aligned) as a split B operand
-__device__ __forceinline__ Bf3 t16_row_split8(const float* p) {
-    float x[8];
+// eight consecutive floats of an activation / delta row (8-byte aligned): fetched one k-block ahead of the split that makes them a B operand (the rows live in global memory)
+struct T16Row8 { float2 v[4]; };
+__device__ __forceinline__ T16Row8 t16_row_load8(const float* p) {
+    T16Row8 r;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float2 v = *reinterpret_cast<const float2*>(p + 2 * q);
-        x[2 * q] = v.x; x[2 * q + 1] = v.y;
-    }
+    for (int q = 0; q < 4; q++) r.v[q] = *reinterpret_cast<const float2*>(p + 2 * q);
+    return r;
+}
+__device__ __forceinline__ Bf3 t16_row_split8(const T16Row8& r) {
+    const float x[8] = {r.v[0].x, r.v[0].y, r.v[1].x, r.v[1].y, r.v[2].x, r.v[2].y, r.v[3].x, r.v[3].y};
     return bf3_split8(x);
 }
 
@@ -374,8 +376,10 @@ __device__ __forceinline__ void mlp_forward_split(const DevModel& m, const float
                 return r;
             };
             Bf3 A0 = ldA(0), A1_ = ldA(1);
+            T16Row8 rown = t16_row_load8(in + 8 * kq);
             for (int S = 0; S < nS; S++) {
-                const Bf3 B = t16_row_split8(in + 32 * S + 8 * kq);
+                const Bf3 B = t16_row_split8(rown);
+                rown = t16_row_load8(in + 32 * min(S + 1, nS - 1) + 8 * kq);
 #pragma unroll
                 for (int t = 0; t < T16_TG; t++) {
                     const Bf3 Aop = A0;
@@ -434,8 +438,10 @@ __device__ __forceinline__ void mlp_backward_split(const DevModel& m, const Pack
                 return r;
             };
             Bf3 A0 = ldA(0), A1_ = ldA(1);
+            T16Row8 rown = t16_row_load8(dz + 8 * jq);
             for (int S = 0; S < nS; S++) {
-                const Bf3 B = t16_row_split8(dz + 32 * S + 8 * jq);
+                const Bf3 B = t16_row_split8(rown);
+                rown = t16_row_load8(dz + 32 * min(S + 1, nS - 1) + 8 * jq);
 #pragma unroll
                 for (int t = 0; t < T16_TG; t++) {
                     const Bf3 Aop = A0;
