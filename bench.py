@@ -724,6 +724,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the block that times the other BASELINE configs after the headline (N = 1 only)")
     args = ap.parse_args()
 
+    if args.substeps < 1 or args.steps < 1 or args.frames < 2:
+        raise SystemExit("bench.py times a FIXED discretisation: --substeps >= 1 (the library's substeps = 0 picks a count from reltol at run time), --steps >= 1, --frames >= 2")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # invoked plainly with N > 1: become the launcher.  Nothing in this process touches HIP or imports torch;
         # the ranks are fresh children, never an exec of a process that holds a HIP context.
