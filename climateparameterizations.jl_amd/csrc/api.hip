@@ -418,7 +418,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
             return fail("allocating the RKC coefficient table failed");
         }
         h->m.rkc = h->d_rkc;
-        if (refresh_rkc(h)) { delete h; return 1; }
+        if (refresh_rkc(h)) { colnde_destroy(h); return 1; }
     }
     std::vector<TileDesc> tiles;
     std::vector<int> bz, bg;
@@ -469,7 +469,7 @@ extern "C" int colnde_create(const colnde_config* cfg, colnde_handle** out) {
             if (et && (atoi(et) == 256 || atoi(et) == 1024)) h->fwd_threads = atoi(et);
         }
         h->geo_ok = false;
-        if (ensure_ag(h, (size_t)h->n_tiles)) { delete h; return 1; }
+        if (ensure_ag(h, (size_t)h->n_tiles)) { colnde_destroy(h); return 1; }
         // plane images of the dense chains (16-byte items): forward [16-row tile][32-deep k-block][3 planes][64 lanes], transposed likewise
         int fo = 0, bo = 0;
         for (int l = 0; l < h->m.n_layers; l++) {
