@@ -97,6 +97,16 @@ def test_wide_networks_other_paths_rkc2_inplace_rhs_and_column_blocks(monkeypatc
     monkeypatch.setenv("COLNDE_T16_BLOCK", "32")
     with colnde.ColumnNDE(r.cfg, 80) as nde:
         nde.set_problem(r.x0, r.bcs, truth)
+        # the diagnostics of round 4 on this shape: loss without gradient, predict_flux, loss_per_tstep, the Richardson error estimate
+        tot_l, terms_l = nde.loss(r.weights, sc)
+        assert np.isclose(tot_l, tot, rtol=LOSS_RTOL)
+        fl = nde.flux(r.x0[:5], r.weights, r.bcs[:5], 0.0)
+        assert _rel(fl, O.predict_flux(r.cfg, r.x0[:5], r.bcs[:5], r.weights)) < 1e-6
+        lpt = nde.loss_per_tstep(r.weights)
+        np.testing.assert_allclose(lpt.mean(axis=(0, 2)), O.loss_terms(r.cfg, sol, truth), rtol=10 * LOSS_RTOL)
+        est = nde.error_estimate(r.weights)
+        est64 = O.error_estimate(r.cfg, r.x0, r.bcs, r.weights)
+        assert 0.5 * est64 < est < 2.0 * est64 or est < 2e-4                     # (float32's floor in this norm)
         tot_g, terms_g, grad_g = nde.loss_grad(r.weights, sc)
         assert nde.plan()["n_blocks"] == 3
     np.testing.assert_allclose(terms_g, terms, rtol=10 * LOSS_RTOL, atol=0)
