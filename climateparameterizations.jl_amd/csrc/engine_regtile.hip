@@ -1077,8 +1077,10 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                     //     (evaluating the layer-2 activation pairs inside the W3^T chain instead was measured slower: 94.8 vs 89.7 ms; W3^T first, so that the taped
                     //      Z2 has the chain to land under: more spills, slower — round 5)
                     {
+#ifndef RT_ABL_NO_OUTER     // (ablation probe, results wrong: what the dW2 / dW3 outer products and their five LDS transpositions per net cost the adjoint — DESIGN section 0.6)
                         const f32x16 TA = rt_transpose(tb, dOn, wbase, rbase);
                         b3acc[n] += rt_sum16(TA);
+#endif
                         f32x16 A2;
 #pragma unroll
                         for (int r = 0; r < 16; r += 4) {
@@ -1088,12 +1090,16 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                             A2[r] = a0.x; A2[r + 1] = a0.y; A2[r + 2] = a1.x; A2[r + 3] = a1.y;
                             Z2[r] = d0.x; Z2[r + 1] = d0.y; Z2[r + 2] = d1.x; Z2[r + 3] = d1.y;     // Z2 now holds act'(z2)
                         }
+#ifndef RT_ABL_NO_OUTER
                         const f32x16 TB = rt_transpose(tb, A2, wbase, rbase);
 #ifdef RT_OUTER_SPLIT
                         if constexpr (SPLIT) gW3[n] = rt_outer_split(gW3[n], rt_split_tile(TA), rt_split_tile(TB));
                         else
 #endif
                         gW3[n] = rt_outer(gW3[n], TA, TB);
+#else
+                        gW3[n][0] += A2[0];
+#endif
                     }
                     {
                         const int base = b3T + n * 31 * RT_LD3;
@@ -1120,6 +1126,9 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                         for (int u = 0; u < (RT_LPIPE ? 3 : 9); u++) Lr[u] = lg[u * 64];
                     }
                     // (4) layer 2: weight/bias gradient
+#ifdef RT_ABL_NO_OUTER
+                    gW2[n][0][0] += Z2[0] * A1[0][0]; gW2[n][1][0] += Z2[1] * A1[1][0];
+#else
                     {
                         const f32x16 TA = rt_transpose(tb, Z2, wbase, rbase);
                         b2acc[n] += rt_sum16(TA);
@@ -1137,6 +1146,7 @@ rt_adjoint_kernel(DevModel m, const float* __restrict__ wimg, const float* __res
                             gW2[n][t] = rt_outer(gW2[n][t], TA, TB);
                         }
                     }
+#endif
                     RT_STAMP(4);
                     // (5) dZ1 = (W2^T dZ2) .* act'(Z1), in place; taped for the streaming dW1 kernel
 #pragma unroll
